@@ -1,0 +1,179 @@
+"""CPU: the numpy oracle (oracle/ctr_oracle.py) against the reference's golden vectors.
+
+The goldens under tests/golden/ were produced by the reference's own layer classes
+(tools/make_golden.py).  These tests pin the oracle before it is trusted as the
+on-box checker of the HIP path.  Tolerance: 1e-5 relative here (both sides are CPU
+fp32 and differ only in summation order); the HIP tests use BASELINE.json's 1e-4.
+"""
+import numpy as np
+import pytest
+
+from oracle import ctr_oracle as O
+from tests.helpers import assert_close, cfg_of, cin_full_params, fields_of, group, load
+
+EMB_CASES = ["emb_movielens_mean", "emb_movielens_sum", "emb_movielens_max", "emb_criteo_d16",
+             "emb_criteo_d32", "emb_layers_test_schema"]
+
+
+@pytest.mark.parametrize("case", EMB_CASES)
+def test_embedding_forward(case):
+    g = load(case)
+    fields, params, batch = fields_of(g), group(g, "param/"), group(g, "batch/")
+    fo, fe, fl = O.embedding_forward(fields, params, batch, int(g["fm_dim"]))
+    assert_close(fo, g["out/first_order"], 1e-5, what="first_order")
+    assert_close(fe, g["out/field_embeddings"], 1e-5, what="field_embeddings")
+    assert_close(fl, g["out/flat_embeddings"], 1e-5, what="flat_embeddings")
+    # pure index gather must be bit-exact (BASELINE.json): SPARSE fields without projection
+    off = 0
+    for i, f in enumerate(fields):
+        if f["type"] == "sparse":
+            assert np.array_equal(fl[:, off:off + f["dim"]], g["out/flat_embeddings"][:, off:off + f["dim"]])
+        off += f["dim"]
+
+
+@pytest.mark.parametrize("case", EMB_CASES)
+def test_embedding_backward(case):
+    g = load(case)
+    fields, params, batch = fields_of(g), group(g, "param/"), group(g, "batch/")
+    grads = O.embedding_backward(fields, params, batch, int(g["fm_dim"]), g["upstream/first_order"],
+                                 g["upstream/field_embeddings"], g["upstream/flat_embeddings"])
+    want = group(g, "grad/")
+    assert set(grads) == set(want)
+    for k in want:
+        assert_close(grads[k], want[k], 1e-5, what=k)
+        if k.endswith(".weight") and want[k].shape[0] > 1 and "projections" not in k:
+            f = next(f for f in fields if f["name"] == k.split(".")[1])
+            if f["type"] != "dense":
+                assert not grads[k][0].any(), "padding row 0 must get no gradient"
+
+
+def test_embedding_padding_row_zero():
+    """tests/test_layers.py:43-51 — all-zero ids give exactly zero outputs."""
+    g = load("emb_layers_test_schema")
+    fields, params = fields_of(g), group(g, "param/")
+    batch = {f["name"]: np.zeros(2, dtype=np.int64) for f in fields}
+    for out in O.embedding_forward(fields, params, batch, 16):
+        assert np.abs(out).sum() == 0.0
+
+
+def test_fm():
+    g = load("fm")
+    assert_close(O.fm_forward(g["x"]), g["out"], 1e-5, what="fm")
+    assert_close(O.fm_backward(g["x"], g["upstream"]), g["d_x"], 1e-5, what="fm d_x")
+    # reference known answers
+    assert float(O.fm_forward(g["known_x"])[0, 0]) == 67.0 == float(g["known_out"][0, 0])  # notes/deepfm.md:72-90
+    assert np.allclose(O.fm_forward(g["single_x"]), 0.0, atol=1e-5)                         # test_layers.py:94-98
+    assert_close(O.fm_forward(g["x"]), O.fm_pairwise(g["x"]), 1e-4, what="pairwise")        # test_layers.py:79-92
+
+
+CIN_CASES = ["cin_small_split", "cin_small_nosplit", "cin_single_layer", "cin_odd_split", "cin_criteo_full"]
+
+
+@pytest.mark.parametrize("case", CIN_CASES)
+def test_cin(case):
+    g = load(case)
+    sizes, split = [int(s) for s in g["layer_sizes"]], bool(g["split_half"])
+    params = cin_full_params() if bool(g["hashed"]) else group(g, "param/")
+    F = g["x"].shape[1]
+    _, direct, nxt, odim = O.cin_layout(F, sizes, split)
+    assert direct == list(g["direct_sizes"]) and nxt == list(g["next_sizes"]) and odim == int(g["output_dim"])
+    out = O.cin_forward(g["x"], params, sizes, split)
+    assert_close(out, g["out"], 1e-5, what="cin out")
+    d_x, grads = O.cin_backward(g["x"], params, sizes, split, g["upstream"])
+    assert_close(d_x, g["d_x"], 2e-5, what="cin d_x")
+    if bool(g["hashed"]):
+        for k, want in group(g, "grad_sample/").items():
+            got = grads[k].reshape(-1)
+            got = got[::97] if k.endswith("weight") else got
+            assert_close(got, want, 2e-5, what=k)
+    else:
+        for k, want in group(g, "grad/").items():
+            assert_close(grads[k], want, 2e-5, what=k)
+
+
+def test_cin_output_dim_reference_shapes():
+    """tests/test_layers.py:143-159: [64,64] no-split -> 128; split reduces it."""
+    assert O.cin_layout(3, [64, 64], False)[3] == 128
+    assert O.cin_layout(3, [64, 64], True)[3] == 32 + 64
+
+
+ATTN_CASES = ["attn_cfg4", "attn_two_layers", "attn_no_residual", "attn_odd"]
+
+
+@pytest.mark.parametrize("case", ATTN_CASES)
+def test_attention(case):
+    g = load(case)
+    params = group(g, "param/")
+    heads, layers, res = int(g["num_heads"]), int(g["num_layers"]), bool(g["use_residual"])
+    out = O.attention_forward(g["x"], params, heads, layers, res)
+    assert_close(out, g["out"], 1e-5, what="attn out")
+    d_x, grads = O.attention_backward(g["x"], params, heads, layers, res, g["upstream"])
+    assert_close(d_x, g["d_x"], 5e-5, what="attn d_x")
+    for k, want in group(g, "grad/").items():
+        # d/d(W_k.bias) is identically 0 (softmax is invariant to a per-query shift):
+        # the reference value is rounding noise, so it gets an absolute floor.
+        assert_close(grads[k], want, 5e-5, what=k, floor=2e-5 if k.endswith("W_k.bias") else 0.0)
+
+
+def _model_cfg(c):
+    cfg = dict(fm_dim=c["fm_dim"], hidden_units=c["hidden_units"])
+    if c["kind"] == "xdeepfm":
+        cfg.update(cin_layer_sizes=c["cin_sizes"], cin_split_half=c["cin_split"])
+    if c["kind"] == "attention_deepfm":
+        cfg.update(num_heads=c["heads"], num_layers=c["layers"], use_residual=c["residual"])
+    return cfg
+
+
+@pytest.mark.parametrize("case", ["model_deepfm", "model_xdeepfm", "model_attention_deepfm",
+                                  "model_deepfm_movielens"])
+def test_model_logits(case):
+    g = load(case)
+    c = cfg_of(g)
+    fields, params, batch = fields_of(g), group(g, "param/"), group(g, "batch/")
+    cfg = _model_cfg(c)
+    assert_close(O.model_logits(c["kind"], fields, params, batch, cfg, training=False),
+                 g["logits_eval"], 1e-5, what="eval logits")
+    assert_close(O.model_logits(c["kind"], fields, params, batch, cfg, training=True),
+                 g["logits_train"], 1e-5, what="train logits")
+    loss, _ = O.bce_with_logits(g["logits_train"], g["labels"])
+    assert abs(float(loss) - float(g["loss"])) < 1e-6
+
+
+def test_dnn_backward_against_model_grads():
+    """DNN + head gradients of the deepfm golden (BCE loss, train-mode BN)."""
+    g = load("model_deepfm")
+    c = cfg_of(g)
+    fields, params, batch = fields_of(g), group(g, "param/"), group(g, "batch/")
+    fo, fe, fl = O.embedding_forward(fields, O._sub(params, "embedding."), batch, c["fm_dim"])
+    dnn_p = O._sub(params, "dnn.")
+    n = len(c["hidden_units"])
+    h = O.dnn_forward(fl, dnn_p, n, training=True)
+    logits = fo + O.fm_forward(fe) + O.linear_forward(h, params, "output_linear.")
+    _, dz = O.bce_with_logits(logits, g["labels"])
+    want = group(g, "grad/")
+    assert_close(dz.T @ h, want["output_linear.weight"], 2e-5, what="head W")
+    d_h = dz @ params["output_linear.weight"]
+    d_fl, dnn_g = O.dnn_backward(fl, dnn_p, n, d_h, training=True)
+    for k, v in dnn_g.items():
+        # a Linear bias in front of train-mode BatchNorm has an identically-zero gradient
+        # (BN subtracts the batch mean): the reference value is rounding noise.
+        pre_bn_bias = k.endswith(".bias") and int(k.split(".")[1]) % 4 == 0
+        assert_close(v, want["dnn." + k], 5e-5, what=k, floor=1e-6 if pre_bn_bias else 0.0)
+    # embedding grads through all three paths
+    d_fe = O.fm_backward(fe, dz)
+    emb_g = O.embedding_backward(fields, O._sub(params, "embedding."), batch, c["fm_dim"], dz, d_fe, d_fl)
+    for k, v in emb_g.items():
+        assert_close(v, want["embedding." + k], 5e-5, what=k)
+
+
+def test_rowsparse_matches_dense():
+    rng = np.random.default_rng(0)
+    ids = rng.integers(0, 20, size=200).astype(np.int64)
+    g2 = rng.standard_normal((200, 8)).astype(np.float32)
+    g1 = rng.standard_normal(200).astype(np.float32)
+    uniq, r2, r1 = O.rowsparse_from_batch(ids, g2, g1)
+    assert uniq[0] != 0 and np.all(np.diff(uniq) > 0)
+    dense = np.zeros((20, 8), np.float32)
+    keep = ids != 0
+    np.add.at(dense, ids[keep], g2[keep])
+    assert_close(r2, dense[uniq], 1e-5, what="row grads")
