@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""Headline benchmark: train samples/s, DeepFM Criteo-shape (26 sparse x 1M vocab, 13 dense,
+embed_dim 16), batch 4096 per GPU, data-parallel over N GPUs of one node.
+
+    python bench.py --gpus 1 --steps 100 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path over one batch already resident in HBM:
+fused embedding gather -> FM + DNN forward -> BCE(+L2) -> backward -> row gradients ->
+(DP exchange) -> clip + row-wise Adam on touched rows + dense Adam.
+Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
+`roofline` for the embedding gather kernel (HIP events around every launch of it inside
+the timed region) and `cpu_baseline` (the numpy oracle's same step on the host cores).
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=4096, help="per-GPU batch")
+    ap.add_argument("--vocab", type=int, default=1_000_000)
+    ap.add_argument("--dim", type=int, default=16)
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    return ap.parse_args()
+
+
+def gather_bytes_per_sample(n_sparse: int, n_dense: int, dim: int) -> int:
+    """Algorithmic HBM bytes of the embedding gather: rows + first-order
+    scalars + ids + dense values read; field_embeddings (aliased as flat) + first_order written."""
+    reads = n_sparse * (dim * 4 + 4 + 8) + n_dense * 4
+    writes = (n_sparse + n_dense) * dim * 4 + 4
+    return reads + writes
+
+
+def make_pool(n_batches, n_sparse, n_dense, B, V, seed, device):
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    ids = torch.randint(1, V, (n_batches, n_sparse, B), generator=g, device=device, dtype=torch.int64)
+    pad = torch.rand((n_batches, n_sparse, B), generator=g, device=device) < 0.01
+    ids.masked_fill_(pad, 0)                                       # 1 % padding ids
+    dense = torch.rand((n_batches, n_dense, B), generator=g, device=device)
+    labels = (torch.rand((n_batches, B), generator=g, device=device) < 0.25).float()
+    return ids, dense, labels
+
+
+def cpu_baseline(model, fields, cfg, hp, ids, dense, labels, seconds):
+    """The oracle's row-sparse DeepFM step on the host cores, on a bounded sample of the
+    same synthetic batches (kind 'port': numpy fp32; BLAS threads = cores reported)."""
+    from oracle import ctr_oracle as O
+    params = {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()
+              if not k.endswith("num_batches_tracked")}
+    state = {}
+    for k, v in params.items():
+        if "running_" in k:
+            continue
+        state["m/" + k] = np.zeros_like(v)
+        state["v/" + k] = np.zeros_like(v)
+    ocfg = dict(fm_dim=cfg.feature.fm_embed_dim, hidden_units=cfg.dnn.hidden_units)
+    ids_h, dense_h, labels_h = ids.cpu().numpy(), dense.cpu().numpy(), labels.cpu().numpy()
+    names_s = [f["name"] for f in fields if f["type"] == "sparse"]
+    names_d = [f["name"] for f in fields if f["type"] == "dense"]
+    done, t0 = 0, time.perf_counter()
+    while True:
+        i = done % ids_h.shape[0]
+        batch = {n: ids_h[i, j] for j, n in enumerate(names_s)}
+        batch.update({n: dense_h[i, j] for j, n in enumerate(names_d)})
+        O.deepfm_train_step_rowsparse(fields, params, state, batch, labels_h[i], ocfg, hp, done + 1)
+        done += 1
+        el = time.perf_counter() - t0
+        if el >= seconds or done >= ids_h.shape[0]:
+            break
+    B = ids_h.shape[2]
+    try:
+        import threadpoolctl
+        threads = max([p.get("num_threads", 1) for p in threadpoolctl.threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    return {"value": done * B / el, "unit": "samples/s", "cores": int(threads), "kind": "port",
+            "sample": f"{done} steps of batch {B} (numpy oracle, row-sparse step, {el:.1f} s)",
+            "host_cpus": os.cpu_count()}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from deepfm_amd.config import ExperimentConfig
+    from deepfm_amd.models import create_model
+    from deepfm_amd.training.rowsparse import RowSparseAdam
+    from deepfm_amd.training.step import RowSparseTrainStep
+    from tests.helpers import schema_from_fields
+    from tools_shared import criteo_fields
+
+    B, V, D = args.batch, args.vocab, args.dim
+    fields = criteo_fields(V, D)
+    n_sparse, n_dense = 26, 13
+    cfg = ExperimentConfig()
+    cfg.feature.fm_embed_dim = D
+    torch.manual_seed(0)                      # identical replicas on every rank
+    with torch.device(dev):
+        model = create_model("deepfm", schema_from_fields(fields), cfg)
+    model.train()
+    model.embedding.set_grad_mode("rowsparse")
+    hp = dict(lr=cfg.training.lr, l2=cfg.feature.embedding_l2_reg, max_grad_norm=cfg.training.gradient_clip_norm)
+    opt = RowSparseAdam(model, lr=hp["lr"], l2=hp["l2"], max_grad_norm=hp["max_grad_norm"])
+    step = RowSparseTrainStep(model, opt, B, use_graph=not args.no_graph)
+
+    total = args.steps + args.warmup
+    ids, dense, labels = make_pool(total, n_sparse, n_dense, B, V, 1 + rank, dev)
+    step.load_batch(ids[0], dense[0], labels[0])
+    step.capture()
+
+    def run(i, timed):
+        step.load_batch(ids[i], dense[i], labels[i])
+        step.run(time_gather=timed)
+
+    for i in range(args.warmup):
+        run(i, False)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, total):
+        run(i, True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss = float(step.loss.item())
+
+    gather_ms = [s.elapsed_time(e) for s, e in (step.gather_events or [])]
+    gather_avg_s = (sum(gather_ms) / len(gather_ms)) * 1e-3 if gather_ms else float("nan")
+    algo_bytes = gather_bytes_per_sample(n_sparse, n_dense, D) * B
+    achieved = algo_bytes / gather_avg_s / 1e9
+
+    if rank == 0:
+        out = {
+            "metric": "train samples/sec DeepFM Criteo-shape bs4096",
+            "value": args.steps * B * world / elapsed,
+            "unit": "samples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"DeepFM synthetic Criteo-shape: {n_sparse} sparse x {V} vocab, {n_dense} dense, "
+                            f"embed_dim {D}, batch {B}/GPU; step = fwd + BCE + L2 + bwd + clip + "
+                            "row-wise Adam on touched rows (lazy L2) + dense Adam",
+                "global_batch": B * world,
+                "parallelism": f"dp{world}",
+                "hip_graph": not args.no_graph,
+                "final_loss": loss,
+            },
+            "roofline": {
+                "kernel": f"emb_fwd_uniform<{D},8> (fused gather of all {n_sparse + n_dense} fields)",
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "algorithmic_bytes_per_launch": algo_bytes,
+                "avg_launch_us": gather_avg_s * 1e6,
+                "launches_timed": len(gather_ms),
+                "timer": "HIP events around each launch on the launch stream, inside the timed region",
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(model, fields, cfg, hp, ids[:8], dense[:8], labels[:8],
+                                               args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,115 @@
+"""ctypes binding of the C ABI declared in ``include/deepfm_hip.h``.
+
+The library is built in-tree by ``deepfm_amd/csrc/Makefile`` (``__graft_entry__.build()``)
+into ``deepfm_amd/lib/libdeepfm_hip.so``.  There is no CPU fallback: if the library is
+missing, or a tensor is not on a HIP device, the callers raise.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdeepfm_hip.so")
+
+MAX_FIELDS = 64
+ROWPLAN_CHUNK = 4096
+SPARSE, DENSE, SEQUENCE = 0, 1, 2
+COMBINER = {"mean": 0, "sum": 1, "max": 2}
+
+c_float_p = C.c_void_p  # device pointers travel as integers
+c_int_p = C.c_void_p
+
+
+class Field(C.Structure):
+    """struct dfm_field"""
+    _fields_ = [("kind", C.c_int32), ("dim", C.c_int32), ("vocab", C.c_int32), ("max_len", C.c_int32),
+                ("combiner", C.c_int32), ("flat_offset", C.c_int32),
+                ("w2", C.c_void_p), ("b2", C.c_void_p), ("w1", C.c_void_p), ("b1", C.c_void_p),
+                ("proj", C.c_void_p)]
+
+
+class FieldGrad(C.Structure):
+    """struct dfm_field_grad"""
+    _fields_ = [("w2", C.c_void_p), ("b2", C.c_void_p), ("w1", C.c_void_p), ("b1", C.c_void_p),
+                ("proj", C.c_void_p)]
+
+
+class Table(C.Structure):
+    """struct dfm_table"""
+    _fields_ = [("w2", C.c_void_p), ("m2", C.c_void_p), ("v2", C.c_void_p),
+                ("w1", C.c_void_p), ("m1", C.c_void_p), ("v1", C.c_void_p)]
+
+
+# name -> (restype, argtypes); must list every symbol of include/deepfm_hip.h
+_P, _I, _L, _F, _SZ = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
+SIGNATURES = {
+    "dfm_abi_version": (_I, []),
+    "dfm_last_error": (C.c_char_p, []),
+    "dfm_device_info": (_I, [_P, _P, C.c_char_p, _I]),
+    "dfm_embedding_plan_create": (_I, [C.POINTER(Field), _I, _I, C.POINTER(_P)]),
+    "dfm_embedding_plan_destroy": (_I, [_P]),
+    "dfm_embedding_plan_is_uniform": (_I, [_P]),
+    "dfm_embedding_workspace_bytes": (_SZ, [_P, _L]),
+    "dfm_embedding_forward": (_I, [_P, C.POINTER(_P), _L, _P, _P, _P, _P, _P, _P, _P]),
+    "dfm_embedding_backward_dense": (_I, [_P, C.POINTER(_P), _L, _P, _P, _P, C.POINTER(FieldGrad), _P, _P]),
+    "dfm_embedding_backward_dense_fields": (_I, [_P, C.POINTER(_P), _L, _P, _P, _P, C.POINTER(FieldGrad), _P]),
+    "dfm_rowplan_build": (_I, [C.POINTER(_P), C.POINTER(C.c_int32), _I, _L, _P, _P, _P, _P, _P, _P]),
+    "dfm_rowgrad_build": (_I, [C.POINTER(C.c_int32), _I, _I, _I, _L, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "dfm_rowadam_merge": (_I, [C.POINTER(Table), _I, _I, _I, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P]),
+    "dfm_rowadam_workspace_bytes": (_SZ, [_I, _I]),
+    "dfm_rowadam_apply": (_I, [C.POINTER(Table), _I, _I, _I, _P, _P, _P, _P, _P, _P, _F, _F, _F, _F, _P, _P]),
+    "dfm_fm_forward": (_I, [_P, _L, _I, _I, _P, _P]),
+    "dfm_fm_backward": (_I, [_P, _P, _L, _I, _I, _P, _P]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load the library once; raise loudly when it is absent (no fallback path exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C deepfm_amd/csrc`). deepfm_amd has no CPU or eager-PyTorch fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if lib.dfm_abi_version() != 1:
+        raise HipLibraryError(f"ABI version mismatch: library {lib.dfm_abi_version()} != binding 1")
+    _lib = lib
+    return lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        msg = load().dfm_last_error().decode("utf-8", "replace")
+        raise HipLibraryError(f"deepfm_hip error {rc}: {msg}")
+
+
+def ptr(t) -> int:
+    """Device pointer of a torch tensor (0 for None)."""
+    return 0 if t is None else t.data_ptr()
+
+
+def stream_handle() -> int:
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_device(t, what: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"{what} is on {t.device}: deepfm_amd runs on an MI355X HIP device only "
+            "(there is no CPU fallback; use the reference implementation on CPU).")

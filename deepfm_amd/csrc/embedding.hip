@@ -1,0 +1,550 @@
+// FeatureEmbedding forward / dense-gradient backward for gfx950.
+//
+// Reference semantics: deepfm/models/layers/embedding.py:76-126 (forward) and its
+// autograd (dense V x d gradients, nn.Embedding(sparse=False), embedding.py:35-40).
+//
+// Two forward paths:
+//   * emb_fwd_uniform<D,W>  — every field SPARSE or DENSE with dim == fm_dim == D and no
+//     projection (the Criteo shape).  ONE launch gathers all tables: a wave owns one field
+//     for 64/(D/4) consecutive samples, so ids are read as one coalesced line, rows as
+//     16-byte pieces, and the field table is read with scalar loads.  first_order and the
+//     FM value are reduced across the block's waves through LDS in a fixed order.
+//   * emb_fwd_general — any schema (mixed dims, projections, SEQUENCE bags): one thread
+//     per (sample, field).  Correctness path for MovieLens-shaped schemas.
+#include "common.h"
+
+#include <vector>
+
+using namespace dfm;
+
+struct dfm_embedding_plan {
+  int num_fields = 0;
+  int fm_dim = 0;
+  int total_dim = 0;
+  int uniform = 0;
+  int max_dim = 0;
+  std::vector<dfm_field> h_fields;
+  std::vector<int32_t> h_sparse, h_dense, h_proj;
+  dfm_field* d_fields = nullptr;
+  int32_t* d_sparse = nullptr;
+  int32_t* d_dense = nullptr;
+  int32_t* d_proj = nullptr;
+};
+
+// ======================================================================================
+// uniform fused gather
+// ======================================================================================
+template <int D, int W>
+__global__ __launch_bounds__(W * 64) void emb_fwd_uniform(
+    const dfm_field* __restrict__ fields, const int32_t* __restrict__ sparse_list, int ns,
+    const int32_t* __restrict__ dense_list, int nd, PtrTable in, int64_t B, int F,
+    float* __restrict__ first_order, float* __restrict__ fe, float* __restrict__ fm_out,
+    int32_t* error_flag) {
+  constexpr int LPR = D / 4;        // lanes per row (16 B each)
+  constexpr int SPW = kWave / LPR;  // samples per wave == samples per block
+  constexpr int U = 4;              // fields in flight per wave
+  const int lane = lane_id();
+  const int wave = wave_id_uniform();
+  const int s = lane / LPR, q = lane % LPR;
+  const int64_t b = static_cast<int64_t>(blockIdx.x) * SPW + s;
+  const bool live = b < B;
+  const int64_t bc = live ? b : B - 1;  // clamped: dead lanes load valid addresses
+
+  float4 S = make_float4(0.f, 0.f, 0.f, 0.f);   // sum_f e
+  float4 SQ = make_float4(0.f, 0.f, 0.f, 0.f);  // sum_f e^2
+  float fo = 0.f;
+
+  // ---- SPARSE fields: id line -> row gather -------------------------------------------
+  for (int i0 = wave; i0 < ns; i0 += W * U) {
+    int f[U];
+    bool ok[U];
+    int64_t id[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = i0 + u * W;
+      ok[u] = i < ns;
+      f[u] = sparse_list[ok[u] ? i : ns - 1];
+      id[u] = static_cast<const int64_t*>(in.p[f[u]])[bc];
+    }
+    float4 row[U];
+    float w1v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const dfm_field& fd = fields[f[u]];
+      id[u] = checked_id(id[u], fd.vocab, error_flag);
+      row[u] = ld4(fd.w2 + id[u] * D + q * 4);
+      w1v[u] = (q == 0) ? fd.w1[id[u]] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (ok[u]) {
+        const float4 e = row[u];
+        if (live) st4(fe + (b * F + f[u]) * D + q * 4, e);
+        S.x += e.x; S.y += e.y; S.z += e.z; S.w += e.w;
+        SQ.x = fmaf(e.x, e.x, SQ.x); SQ.y = fmaf(e.y, e.y, SQ.y);
+        SQ.z = fmaf(e.z, e.z, SQ.z); SQ.w = fmaf(e.w, e.w, SQ.w);
+        fo += w1v[u];
+      }
+    }
+  }
+  // ---- DENSE fields: x * W + b  (Linear(1,D), Linear(1,1)) ------------------------------
+  for (int i0 = wave; i0 < nd; i0 += W * U) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = i0 + u * W;
+      if (i < nd) {
+        const int f = dense_list[i];
+        const dfm_field& fd = fields[f];
+        const float x = static_cast<const float*>(in.p[f])[bc];
+        const float4 w = ld4(fd.w2 + q * 4);
+        const float4 bb = ld4(fd.b2 + q * 4);
+        float4 e;
+        e.x = fmaf(x, w.x, bb.x); e.y = fmaf(x, w.y, bb.y);
+        e.z = fmaf(x, w.z, bb.z); e.w = fmaf(x, w.w, bb.w);
+        if (live) st4(fe + (b * F + f) * D + q * 4, e);
+        S.x += e.x; S.y += e.y; S.z += e.z; S.w += e.w;
+        SQ.x = fmaf(e.x, e.x, SQ.x); SQ.y = fmaf(e.y, e.y, SQ.y);
+        SQ.z = fmaf(e.z, e.z, SQ.z); SQ.w = fmaf(e.w, e.w, SQ.w);
+        if (q == 0) fo += fmaf(x, fd.w1[0], fd.b1[0]);
+      }
+    }
+  }
+  // ---- fixed-order reduction over the block's waves --------------------------------------
+  __shared__ float red[W][9][kWave];
+  red[wave][0][lane] = S.x;  red[wave][1][lane] = S.y;  red[wave][2][lane] = S.z;
+  red[wave][3][lane] = S.w;  red[wave][4][lane] = SQ.x; red[wave][5][lane] = SQ.y;
+  red[wave][6][lane] = SQ.z; red[wave][7][lane] = SQ.w; red[wave][8][lane] = fo;
+  __syncthreads();
+  if (wave == 0) {
+    float acc[9];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) acc[c] = red[0][c][lane];
+    for (int w = 1; w < W; ++w) {
+#pragma unroll
+      for (int c = 0; c < 9; ++c) acc[c] += red[w][c][lane];
+    }
+    // 0.5 * sum_d (S_d^2 - SQ_d)   (fm.py:20-22)
+    float t = (acc[0] * acc[0] - acc[4]) + (acc[1] * acc[1] - acc[5]) +
+              (acc[2] * acc[2] - acc[6]) + (acc[3] * acc[3] - acc[7]);
+#pragma unroll
+    for (int m = 1; m < LPR; m <<= 1) t += __shfl_xor(t, m, kWave);
+    if (live && q == 0) {
+      first_order[b] = acc[8];
+      if (fm_out) fm_out[b] = 0.5f * t;
+    }
+  }
+}
+
+// ======================================================================================
+// general path
+// ======================================================================================
+__device__ __forceinline__ float bag_pool(const float* __restrict__ table, int stride, int j,
+                                          const int64_t* __restrict__ ids, int L, int vocab,
+                                          int combiner, int32_t* error_flag) {
+  float acc = 0.f;
+  int count = 0;
+  bool first = true;
+  for (int l = 0; l < L; ++l) {
+    const int64_t id = checked_id(ids[l], vocab, error_flag);
+    if (id == 0) continue;
+    const float v = table[id * stride + j];
+    if (combiner == DFM_MAX) {
+      if (first || v > acc) acc = v;
+      first = false;
+    } else {
+      acc += v;
+    }
+    ++count;
+  }
+  if (combiner == DFM_MEAN && count > 0) acc = acc / static_cast<float>(count);
+  return acc;
+}
+
+__global__ void emb_fwd_general(const dfm_field* __restrict__ fields, PtrTable in, int64_t B, int F,
+                                int fm_dim, int total_dim, float* __restrict__ fo_parts,
+                                float* __restrict__ fe, float* __restrict__ flat,
+                                int32_t* error_flag) {
+  const int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= B * F) return;
+  const int f = static_cast<int>(t % F);
+  const int64_t b = t / F;
+  const dfm_field fd = fields[f];
+  const int d = fd.dim;
+  float* flat_row = flat + b * total_dim + fd.flat_offset;
+  float* fe_row = fe + (b * F + f) * fm_dim;
+  float fo;
+  if (fd.kind == DFM_SPARSE) {
+    const int64_t id = checked_id(static_cast<const int64_t*>(in.p[f])[b], fd.vocab, error_flag);
+    const float* row = fd.w2 + id * d;
+    for (int j = 0; j < d; ++j) flat_row[j] = row[j];
+    fo = fd.w1[id];
+  } else if (fd.kind == DFM_DENSE) {
+    const float x = static_cast<const float*>(in.p[f])[b];
+    for (int j = 0; j < d; ++j) flat_row[j] = fmaf(x, fd.w2[j], fd.b2[j]);
+    fo = fmaf(x, fd.w1[0], fd.b1[0]);
+  } else {
+    const int64_t* ids = static_cast<const int64_t*>(in.p[f]) + b * fd.max_len;
+    for (int j = 0; j < d; ++j)
+      flat_row[j] = bag_pool(fd.w2, d, j, ids, fd.max_len, fd.vocab, fd.combiner, error_flag);
+    fo = bag_pool(fd.w1, 1, 0, ids, fd.max_len, fd.vocab, fd.combiner, error_flag);
+  }
+  fo_parts[b * F + f] = fo;
+  if (fd.proj) {
+    for (int k = 0; k < fm_dim; ++k) {
+      float acc = 0.f;
+      for (int j = 0; j < d; ++j) acc = fmaf(flat_row[j], fd.proj[k * d + j], acc);
+      fe_row[k] = acc;
+    }
+  } else {
+    for (int j = 0; j < d; ++j) fe_row[j] = flat_row[j];
+  }
+}
+
+__global__ void first_order_sum(const float* __restrict__ fo_parts, int64_t B, int F,
+                                float* __restrict__ first_order) {
+  const int64_t b = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float acc = 0.f;
+  for (int f = 0; f < F; ++f) acc += fo_parts[b * F + f];
+  first_order[b] = acc;
+}
+
+// ======================================================================================
+// dense-gradient backward
+// ======================================================================================
+// gradient w.r.t. the raw (pre-projection) embedding element j of (b, f)
+__device__ __forceinline__ float raw_grad(const dfm_field& fd, int f, int64_t b, int j, int F,
+                                          int fm_dim, int total_dim,
+                                          const float* __restrict__ g_field,
+                                          const float* __restrict__ g_flat) {
+  float g = g_flat ? g_flat[b * total_dim + fd.flat_offset + j] : 0.f;
+  const float* gf = g_field + (b * F + f) * fm_dim;
+  if (fd.proj) {
+    for (int k = 0; k < fm_dim; ++k) g = fmaf(gf[k], fd.proj[k * fd.dim + j], g);
+  } else {
+    g += gf[j];
+  }
+  return g;
+}
+
+// SPARSE + SEQUENCE rows: float atomics into the dense (V, d) gradients.
+__global__ void emb_bwd_scatter(const dfm_field* __restrict__ fields, PtrTable in, GradTable gt,
+                                int64_t B, int F, int fm_dim, int total_dim,
+                                const float* __restrict__ g_first,
+                                const float* __restrict__ g_field,
+                                const float* __restrict__ g_flat) {
+  const int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= B * F) return;
+  const int f = static_cast<int>(t % F);
+  const int64_t b = t / F;
+  const dfm_field fd = fields[f];
+  if (fd.kind == DFM_DENSE) return;
+  const int d = fd.dim;
+  const dfm_field_grad g = gt.g[f];
+  const float gfo = g_first[b];
+  if (fd.kind == DFM_SPARSE) {
+    int64_t id = static_cast<const int64_t*>(in.p[f])[b];
+    if (id <= 0 || id >= fd.vocab) return;  // padding row: no gradient
+    for (int j = 0; j < d; ++j)
+      atomicAdd(g.w2 + id * d + j, raw_grad(fd, f, b, j, F, fm_dim, total_dim, g_field, g_flat));
+    atomicAdd(g.w1 + id, gfo);
+    return;
+  }
+  // SEQUENCE
+  const int64_t* ids = static_cast<const int64_t*>(in.p[f]) + b * fd.max_len;
+  const int L = fd.max_len;
+  int count = 0;
+  for (int l = 0; l < L; ++l) count += (ids[l] > 0 && ids[l] < fd.vocab) ? 1 : 0;
+  if (count == 0) return;
+  if (fd.combiner == DFM_MAX) {
+    for (int j = 0; j <= d; ++j) {  // j == d: the (V,1) first-order table
+      const float* table = j < d ? fd.w2 : fd.w1;
+      const int stride = j < d ? d : 1, col = j < d ? j : 0;
+      int64_t best = 0;
+      float bestv = 0.f;
+      for (int l = 0; l < L; ++l) {
+        const int64_t id = ids[l];
+        if (id <= 0 || id >= fd.vocab) continue;
+        const float v = table[id * stride + col];
+        if (best == 0 || v > bestv) { best = id; bestv = v; }
+      }
+      if (j < d)
+        atomicAdd(g.w2 + best * d + j, raw_grad(fd, f, b, j, F, fm_dim, total_dim, g_field, g_flat));
+      else
+        atomicAdd(g.w1 + best, gfo);
+    }
+    return;
+  }
+  const float scale = fd.combiner == DFM_MEAN ? 1.f / static_cast<float>(count) : 1.f;
+  for (int j = 0; j < d; ++j) {
+    const float gj = raw_grad(fd, f, b, j, F, fm_dim, total_dim, g_field, g_flat) * scale;
+    for (int l = 0; l < L; ++l) {
+      const int64_t id = ids[l];
+      if (id > 0 && id < fd.vocab) atomicAdd(g.w2 + id * d + j, gj);
+    }
+  }
+  for (int l = 0; l < L; ++l) {
+    const int64_t id = ids[l];
+    if (id > 0 && id < fd.vocab) atomicAdd(g.w1 + id, gfo * scale);
+  }
+}
+
+// Block-wide fixed-order sum of two values (256 threads).
+__device__ __forceinline__ void block_sum2(float& a, float& b2) {
+  __shared__ float sa[4], sb[4];
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    a += __shfl_xor(a, m, kWave);
+    b2 += __shfl_xor(b2, m, kWave);
+  }
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane_id() == 0) { sa[w] = a; sb[w] = b2; }
+  __syncthreads();
+  a = sa[0] + sa[1] + sa[2] + sa[3];
+  b2 = sb[0] + sb[1] + sb[2] + sb[3];
+}
+
+// DENSE fields: dW2[j] = sum_b x_b * g_raw[b,j], db2[j] = sum_b g_raw[b,j]; block (i, j);
+// j == dim handles the first-order Linear(1,1).
+__global__ __launch_bounds__(256) void emb_bwd_dense_fields(
+    const dfm_field* __restrict__ fields, const int32_t* __restrict__ dense_list, PtrTable in,
+    GradTable gt, int64_t B, int F, int fm_dim, int total_dim, const float* __restrict__ g_first,
+    const float* __restrict__ g_field, const float* __restrict__ g_flat) {
+  const int f = dense_list[blockIdx.x];
+  const dfm_field fd = fields[f];
+  const int j = blockIdx.y;
+  if (j > fd.dim) return;
+  const float* x = static_cast<const float*>(in.p[f]);
+  float sw = 0.f, sb = 0.f;
+  for (int64_t b = threadIdx.x; b < B; b += 256) {
+    const float g = j < fd.dim ? raw_grad(fd, f, b, j, F, fm_dim, total_dim, g_field, g_flat)
+                               : g_first[b];
+    sw = fmaf(x[b], g, sw);
+    sb += g;
+  }
+  block_sum2(sw, sb);
+  if (threadIdx.x == 0) {
+    const dfm_field_grad g = gt.g[f];
+    if (j < fd.dim) { g.w2[j] += sw; g.b2[j] += sb; }
+    else            { g.w1[0] += sw; g.b1[0] += sb; }
+  }
+}
+
+// Projection gradient dP[k,j] = sum_b g_field[b,f,k] * raw[b,j]; block (i, k*max_dim + j).
+__global__ __launch_bounds__(256) void emb_bwd_proj(
+    const dfm_field* __restrict__ fields, const int32_t* __restrict__ proj_list, GradTable gt,
+    int64_t B, int F, int fm_dim, int total_dim, int max_dim, const float* __restrict__ g_field,
+    const float* __restrict__ flat_saved) {
+  const int f = proj_list[blockIdx.x];
+  const dfm_field fd = fields[f];
+  const int k = blockIdx.y / max_dim, j = blockIdx.y % max_dim;
+  if (j >= fd.dim) return;
+  float acc = 0.f, unused = 0.f;
+  for (int64_t b = threadIdx.x; b < B; b += 256)
+    acc = fmaf(g_field[(b * F + f) * fm_dim + k], flat_saved[b * total_dim + fd.flat_offset + j], acc);
+  block_sum2(acc, unused);
+  if (threadIdx.x == 0) gt.g[f].proj[k * fd.dim + j] += acc;
+}
+
+// ======================================================================================
+// C ABI
+// ======================================================================================
+extern "C" int dfm_embedding_plan_create(const dfm_field* fields, int num_fields, int fm_dim,
+                              dfm_embedding_plan** out_plan) {
+  DFM_REQUIRE(fields && out_plan, "null argument");
+  DFM_REQUIRE(num_fields > 0 && num_fields <= DFM_MAX_FIELDS,
+              "num_fields %d outside [1, %d]", num_fields, DFM_MAX_FIELDS);
+  DFM_REQUIRE(fm_dim > 0, "fm_dim must be positive");
+  auto* plan = new dfm_embedding_plan();
+  plan->num_fields = num_fields;
+  plan->fm_dim = fm_dim;
+  plan->h_fields.assign(fields, fields + num_fields);
+  bool uniform = (fm_dim % 4 == 0) && (kWave % (fm_dim / 4) == 0) && fm_dim <= 256;
+  int off = 0;
+  for (int f = 0; f < num_fields; ++f) {
+    dfm_field& fd = plan->h_fields[f];
+    if (fd.dim <= 0 || !fd.w2 || !fd.w1 || (fd.kind == DFM_DENSE && (!fd.b2 || !fd.b1)) ||
+        (fd.kind != DFM_DENSE && fd.vocab <= 0) || (fd.kind == DFM_SEQUENCE && fd.max_len <= 0) ||
+        fd.kind < 0 || fd.kind > 2 || fd.combiner < 0 || fd.combiner > 2 ||
+        ((fd.dim != fm_dim) != (fd.proj != nullptr))) {
+      delete plan;
+      return fail(DFM_ERR_INVALID, "field %d: inconsistent descriptor", f);
+    }
+    fd.flat_offset = off;
+    off += fd.dim;
+    plan->max_dim = fd.dim > plan->max_dim ? fd.dim : plan->max_dim;
+    if (fd.kind == DFM_SPARSE) plan->h_sparse.push_back(f);
+    if (fd.kind == DFM_DENSE) plan->h_dense.push_back(f);
+    if (fd.proj) plan->h_proj.push_back(f);
+    if (fd.kind == DFM_SEQUENCE || fd.proj || fd.dim != fm_dim) uniform = false;
+  }
+  plan->total_dim = off;
+  plan->uniform = uniform ? 1 : 0;
+  auto upload = [](const void* src, size_t bytes, void** dst) -> hipError_t {
+    if (bytes == 0) { *dst = nullptr; return hipSuccess; }
+    hipError_t e = hipMalloc(dst, bytes);
+    if (e != hipSuccess) return e;
+    return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+  };
+  hipError_t e = upload(plan->h_fields.data(), sizeof(dfm_field) * num_fields, (void**)&plan->d_fields);
+  if (e == hipSuccess) e = upload(plan->h_sparse.data(), 4 * plan->h_sparse.size(), (void**)&plan->d_sparse);
+  if (e == hipSuccess) e = upload(plan->h_dense.data(), 4 * plan->h_dense.size(), (void**)&plan->d_dense);
+  if (e == hipSuccess) e = upload(plan->h_proj.data(), 4 * plan->h_proj.size(), (void**)&plan->d_proj);
+  if (e != hipSuccess) {
+    dfm_embedding_plan_destroy(plan);
+    return fail(DFM_ERR_HIP, "plan upload failed: %s", hipGetErrorString(e));
+  }
+  *out_plan = plan;
+  return DFM_OK;
+}
+
+extern "C" int dfm_embedding_plan_destroy(dfm_embedding_plan* plan) {
+  if (!plan) return DFM_OK;
+  (void)hipFree(plan->d_fields);
+  (void)hipFree(plan->d_sparse);
+  (void)hipFree(plan->d_dense);
+  (void)hipFree(plan->d_proj);
+  delete plan;
+  return DFM_OK;
+}
+
+extern "C" int dfm_embedding_plan_is_uniform(const dfm_embedding_plan* plan) { return plan ? plan->uniform : 0; }
+
+extern "C" size_t dfm_embedding_workspace_bytes(const dfm_embedding_plan* plan, int64_t batch) {
+  if (!plan || plan->uniform || batch <= 0) return 0;
+  return sizeof(float) * static_cast<size_t>(batch) * plan->num_fields;  // fo_parts
+}
+
+static int fill_ptrs(const dfm_embedding_plan* plan, const void* const* inputs, PtrTable* t) {
+  memset(t, 0, sizeof(*t));
+  for (int f = 0; f < plan->num_fields; ++f) {
+    DFM_REQUIRE(inputs[f] != nullptr, "input %d is null", f);
+    t->p[f] = inputs[f];
+  }
+  return DFM_OK;
+}
+
+template <int D>
+static int launch_uniform(const dfm_embedding_plan* plan, const PtrTable& in, int64_t B,
+                          float* fo, float* fe, float* fm_out, int32_t* err, hipStream_t st) {
+  constexpr int W = 8;
+  constexpr int SPW = kWave / (D / 4);
+  const int64_t blocks = (B + SPW - 1) / SPW;
+  hipLaunchKernelGGL((emb_fwd_uniform<D, W>), dim3(static_cast<unsigned>(blocks)), dim3(W * 64), 0, st,
+                     plan->d_fields, plan->d_sparse, static_cast<int>(plan->h_sparse.size()),
+                     plan->d_dense, static_cast<int>(plan->h_dense.size()), in, B, plan->num_fields,
+                     fo, fe, fm_out, err);
+  DFM_LAUNCH_CHECK();
+  return DFM_OK;
+}
+
+extern "C" int dfm_embedding_forward(const dfm_embedding_plan* plan, const void* const* inputs, int64_t batch,
+                          float* d_first_order, float* d_field_emb, float* d_flat_emb,
+                          float* d_fm_out, void* d_workspace, int32_t* d_error_flag,
+                          dfm_stream_t stream) {
+  DFM_REQUIRE(plan && inputs && d_first_order && d_field_emb, "null argument");
+  DFM_REQUIRE(batch >= 0 && batch < (int64_t(1) << 31), "batch %lld out of range", (long long)batch);
+  if (batch == 0) return DFM_OK;
+  PtrTable in;
+  if (int rc = fill_ptrs(plan, inputs, &in)) return rc;
+  hipStream_t st = as_stream(stream);
+  if (plan->uniform && (d_flat_emb == nullptr || d_flat_emb == d_field_emb)) {
+    switch (plan->fm_dim) {
+      case 4:   return launch_uniform<4>(plan, in, batch, d_first_order, d_field_emb, d_fm_out, d_error_flag, st);
+      case 8:   return launch_uniform<8>(plan, in, batch, d_first_order, d_field_emb, d_fm_out, d_error_flag, st);
+      case 16:  return launch_uniform<16>(plan, in, batch, d_first_order, d_field_emb, d_fm_out, d_error_flag, st);
+      case 32:  return launch_uniform<32>(plan, in, batch, d_first_order, d_field_emb, d_fm_out, d_error_flag, st);
+      case 64:  return launch_uniform<64>(plan, in, batch, d_first_order, d_field_emb, d_fm_out, d_error_flag, st);
+      case 128: return launch_uniform<128>(plan, in, batch, d_first_order, d_field_emb, d_fm_out, d_error_flag, st);
+      case 256: return launch_uniform<256>(plan, in, batch, d_first_order, d_field_emb, d_fm_out, d_error_flag, st);
+      default: break;
+    }
+  }
+  DFM_REQUIRE(d_fm_out == nullptr, "fused FM output needs a uniform plan");
+  DFM_REQUIRE(d_flat_emb && d_flat_emb != d_field_emb, "general plan needs a separate flat_embeddings buffer");
+  DFM_REQUIRE(d_workspace, "general plan needs workspace (dfm_embedding_workspace_bytes)");
+  float* fo_parts = static_cast<float*>(d_workspace);
+  const int64_t total = batch * plan->num_fields;
+  hipLaunchKernelGGL(emb_fwd_general, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, st,
+                     plan->d_fields, in, batch, plan->num_fields, plan->fm_dim, plan->total_dim,
+                     fo_parts, d_field_emb, d_flat_emb, d_error_flag);
+  DFM_LAUNCH_CHECK();
+  hipLaunchKernelGGL(first_order_sum, dim3(static_cast<unsigned>((batch + 255) / 256)), dim3(256), 0, st,
+                     fo_parts, batch, plan->num_fields, d_first_order);
+  DFM_LAUNCH_CHECK();
+  return DFM_OK;
+}
+
+static int fill_grads(const dfm_embedding_plan* plan, const dfm_field_grad* grads, GradTable* gt,
+                      bool dense_only) {
+  memset(gt, 0, sizeof(*gt));
+  for (int f = 0; f < plan->num_fields; ++f) {
+    const dfm_field& fd = plan->h_fields[f];
+    const dfm_field_grad& g = grads[f];
+    if (fd.kind == DFM_DENSE) {
+      DFM_REQUIRE(g.w2 && g.b2 && g.w1 && g.b1, "field %d: missing DENSE gradient buffer", f);
+    } else if (!dense_only) {
+      DFM_REQUIRE(g.w2 && g.w1, "field %d: missing table gradient buffer", f);
+    }
+    if (fd.proj && !dense_only) DFM_REQUIRE(g.proj, "field %d: missing projection gradient buffer", f);
+    gt->g[f] = g;
+  }
+  return DFM_OK;
+}
+
+static int launch_dense_fields(const dfm_embedding_plan* plan, const PtrTable& in, const GradTable& gt,
+                               int64_t batch, const float* g_first, const float* g_field,
+                               const float* g_flat, hipStream_t st) {
+  const int nd = static_cast<int>(plan->h_dense.size());
+  if (nd == 0) return DFM_OK;
+  hipLaunchKernelGGL(emb_bwd_dense_fields, dim3(nd, plan->max_dim + 1), dim3(256), 0, st,
+                     plan->d_fields, plan->d_dense, in, gt, batch, plan->num_fields, plan->fm_dim,
+                     plan->total_dim, g_first, g_field, g_flat);
+  DFM_LAUNCH_CHECK();
+  return DFM_OK;
+}
+
+extern "C" int dfm_embedding_backward_dense(const dfm_embedding_plan* plan, const void* const* inputs,
+                                 int64_t batch, const float* d_g_first, const float* d_g_field,
+                                 const float* d_g_flat, const dfm_field_grad* grads,
+                                 void* d_workspace, dfm_stream_t stream) {
+  DFM_REQUIRE(plan && inputs && d_g_first && d_g_field && grads, "null argument");
+  DFM_REQUIRE(plan->uniform || d_g_flat, "general plan needs d_g_flat");
+  if (batch == 0) return DFM_OK;
+  PtrTable in;
+  GradTable gt;
+  if (int rc = fill_ptrs(plan, inputs, &in)) return rc;
+  if (int rc = fill_grads(plan, grads, &gt, false)) return rc;
+  hipStream_t st = as_stream(stream);
+  const int64_t total = batch * plan->num_fields;
+  hipLaunchKernelGGL(emb_bwd_scatter, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, st,
+                     plan->d_fields, in, gt, batch, plan->num_fields, plan->fm_dim, plan->total_dim,
+                     d_g_first, d_g_field, d_g_flat);
+  DFM_LAUNCH_CHECK();
+  if (int rc = launch_dense_fields(plan, in, gt, batch, d_g_first, d_g_field, d_g_flat, st)) return rc;
+  const int np = static_cast<int>(plan->h_proj.size());
+  if (np > 0) {
+    // projections need the forward's flat_embeddings (raw rows): passed through d_workspace
+    DFM_REQUIRE(d_workspace, "projection gradients need the saved flat_embeddings in d_workspace");
+    hipLaunchKernelGGL(emb_bwd_proj, dim3(np, plan->fm_dim * plan->max_dim), dim3(256), 0, st,
+                       plan->d_fields, plan->d_proj, gt, batch, plan->num_fields, plan->fm_dim,
+                       plan->total_dim, plan->max_dim, d_g_field, static_cast<const float*>(d_workspace));
+    DFM_LAUNCH_CHECK();
+  }
+  return DFM_OK;
+}
+
+extern "C" int dfm_embedding_backward_dense_fields(const dfm_embedding_plan* plan, const void* const* inputs,
+                                        int64_t batch, const float* d_g_first,
+                                        const float* d_g_field, const float* d_g_flat,
+                                        const dfm_field_grad* grads, dfm_stream_t stream) {
+  DFM_REQUIRE(plan && inputs && d_g_first && d_g_field && grads, "null argument");
+  if (batch == 0) return DFM_OK;
+  PtrTable in;
+  GradTable gt;
+  if (int rc = fill_ptrs(plan, inputs, &in)) return rc;
+  if (int rc = fill_grads(plan, grads, &gt, true)) return rc;
+  return launch_dense_fields(plan, in, gt, batch, d_g_first, d_g_field, d_g_flat, as_stream(stream));
+}
+

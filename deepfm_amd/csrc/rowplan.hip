@@ -1,0 +1,214 @@
+// Row plan: per SPARSE field, the batch's ids sorted into runs of equal id — the
+// deterministic, atomic-free form of the embedding backward scatter-add
+// (reference: autograd of embedding.py:95-98 = aten::embedding_dense_backward, which
+// accumulates duplicate ids; row 0 = padding_idx gets no gradient).
+//
+// One 1024-thread workgroup sorts one chunk of up to 4096 ids of one field entirely in
+// LDS (bitonic network on 64-bit keys id<<32 | position: keys are distinct, so the order
+// is "by id, then by sample position" = stable).  Ids 0 / out of range become a sentinel
+// that sorts to the end.  Run heads are found with a block scan.  The plan depends on the
+// ids only, so the host can enqueue it ahead of the forward pass.
+//
+// rowgrad: D/4 lanes per distinct id add that id's contributions in sorted (= sample)
+// order and write one gradient row: plain 16-byte stores, bitwise reproducible.
+#include "common.h"
+
+using namespace dfm;
+
+namespace {
+constexpr int CH = DFM_ROWPLAN_CHUNK;  // 4096
+constexpr int SORT_THREADS = 1024;
+constexpr int PER_THREAD = CH / SORT_THREADS;  // 4
+constexpr unsigned long long SENTINEL = ~0ull;
+
+struct IdTable {
+  const int64_t* p[DFM_MAX_FIELDS];
+  int32_t vocab[DFM_MAX_FIELDS];
+};
+struct FieldMap {
+  int32_t f[DFM_MAX_FIELDS];
+};
+}  // namespace
+
+__global__ __launch_bounds__(SORT_THREADS) void rowplan_sort(
+    IdTable ids, int S, int64_t n, int32_t* __restrict__ sorted_pos, int32_t* __restrict__ uniq_rows,
+    int32_t* __restrict__ seg_start, int32_t* __restrict__ num_uniq, int32_t* error_flag) {
+  __shared__ unsigned long long keys[CH];
+  __shared__ int wave_tot[SORT_THREADS / kWave];
+  const int s = blockIdx.x, c = blockIdx.y;
+  const int tid = threadIdx.x;
+  const int64_t base = static_cast<int64_t>(c) * CH;
+  const int len = static_cast<int>(n - base < CH ? n - base : CH);
+  const int64_t* src = ids.p[s];
+  const int vocab = ids.vocab[s];
+
+  // load (coalesced) and form keys
+  for (int i = tid; i < CH; i += SORT_THREADS) {
+    unsigned long long k = SENTINEL;
+    if (i < len) {
+      const int64_t id = src[base + i];
+      if (id < 0 || id >= vocab) {
+        if (error_flag) atomicOr(error_flag, 1);
+      } else if (id != 0) {
+        k = (static_cast<unsigned long long>(id) << 32) | static_cast<unsigned>(i);
+      }
+    }
+    keys[i] = k;
+  }
+  __syncthreads();
+
+  // bitonic sort, ascending
+  for (int k = 2; k <= CH; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+#pragma unroll
+      for (int r = 0; r < CH / 2 / SORT_THREADS; ++r) {
+        const int t = tid + r * SORT_THREADS;
+        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+        const int l = i | j;
+        const unsigned long long a = keys[i], b = keys[l];
+        const bool up = (i & k) == 0;
+        if ((a > b) == up) { keys[i] = b; keys[l] = a; }
+      }
+      __syncthreads();
+    }
+  }
+
+  // run heads over the valid prefix; thread owns PER_THREAD consecutive entries
+  const int e0 = tid * PER_THREAD;
+  unsigned long long mine[PER_THREAD];
+  unsigned long long prev = e0 > 0 ? keys[e0 - 1] : SENTINEL;
+  int head[PER_THREAD];
+  int cnt = 0, valid = 0;
+#pragma unroll
+  for (int r = 0; r < PER_THREAD; ++r) {
+    mine[r] = keys[e0 + r];
+    const bool ok = mine[r] != SENTINEL;
+    const bool h = ok && (e0 + r == 0 || (mine[r] >> 32) != (prev >> 32));
+    head[r] = h ? 1 : 0;
+    cnt += head[r];
+    valid += ok ? 1 : 0;
+    prev = mine[r];
+  }
+  // block-wide exclusive scan of cnt, and total of valid
+  const int lane = lane_id(), w = tid >> 6;
+  int incl = cnt, vsum = valid;
+#pragma unroll
+  for (int o = 1; o < kWave; o <<= 1) {
+    const int t = __shfl_up(incl, o, kWave);
+    if (lane >= o) incl += t;
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) vsum += __shfl_xor(vsum, m, kWave);
+  __shared__ int wave_valid[SORT_THREADS / kWave];
+  if (lane == kWave - 1) wave_tot[w] = incl;
+  if (lane == 0) wave_valid[w] = vsum;
+  __syncthreads();
+  int wave_off = 0, total_u = 0, total_valid = 0;
+  for (int i = 0; i < SORT_THREADS / kWave; ++i) {
+    if (i < w) wave_off += wave_tot[i];
+    total_u += wave_tot[i];
+    total_valid += wave_valid[i];
+  }
+  int slot = wave_off + incl - cnt;  // exclusive prefix
+
+  const size_t list = static_cast<size_t>(c) * S + s;
+  int32_t* o_pos = sorted_pos + list * CH;
+  int32_t* o_rows = uniq_rows + list * CH;
+  int32_t* o_seg = seg_start + list * (CH + 1);
+#pragma unroll
+  for (int r = 0; r < PER_THREAD; ++r) {
+    const int p = e0 + r;
+    const bool ok = mine[r] != SENTINEL;
+    o_pos[p] = ok ? static_cast<int32_t>(base + (mine[r] & 0xffffffffu)) : -1;
+    if (head[r]) {
+      o_rows[slot] = static_cast<int32_t>(mine[r] >> 32);
+      o_seg[slot] = p;
+      ++slot;
+    }
+  }
+  if (tid == 0) {
+    o_seg[total_u] = total_valid;
+    num_uniq[list] = total_u;
+  }
+}
+
+// One row gradient per distinct id: sum of its contributions in sample order.
+__global__ __launch_bounds__(256) void rowgrad_kernel(
+    FieldMap fmap, int S, int F, int D, int lists, const float* __restrict__ g_first,
+    const float* __restrict__ g_field, const int32_t* __restrict__ sorted_pos,
+    const int32_t* __restrict__ seg_start, const int32_t* __restrict__ num_uniq,
+    float* __restrict__ row_g2, float* __restrict__ row_g1) {
+  const int lpr = D / 4;
+  const int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const int q = static_cast<int>(t % lpr);
+  const int64_t entry = t / lpr;  // (list, u)
+  const int64_t list = entry / CH;
+  const int u = static_cast<int>(entry % CH);
+  if (list >= lists) return;
+  if (u >= num_uniq[list]) return;
+  const int s = static_cast<int>(list % S);
+  const int f = fmap.f[s];
+  const int32_t* seg = seg_start + list * (CH + 1);
+  const int32_t* pos = sorted_pos + list * CH;
+  const int p0 = seg[u], p1 = seg[u + 1];
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  float acc1 = 0.f;
+  for (int p = p0; p < p1; ++p) {
+    const int64_t b = pos[p];
+    const float4 g = ld4(g_field + (b * F + f) * D + q * 4);
+    acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
+    if (q == 0) acc1 += g_first[b];
+  }
+  st4(row_g2 + (list * CH + u) * D + q * 4, acc);
+  if (q == 0) row_g1[list * CH + u] = acc1;
+}
+
+extern "C" {
+
+int dfm_rowplan_build(const int64_t* const* ids, const int32_t* vocab, int num_sparse, int64_t n,
+                      int32_t* d_sorted_pos, int32_t* d_uniq_rows, int32_t* d_seg_start,
+                      int32_t* d_num_uniq, int32_t* d_error_flag, dfm_stream_t stream) {
+  DFM_REQUIRE(ids && vocab && d_sorted_pos && d_uniq_rows && d_seg_start && d_num_uniq, "null argument");
+  DFM_REQUIRE(num_sparse > 0 && num_sparse <= DFM_MAX_FIELDS, "num_sparse %d outside [1, %d]", num_sparse, DFM_MAX_FIELDS);
+  DFM_REQUIRE(n > 0 && n < (int64_t(1) << 31), "n out of range");
+  IdTable t;
+  memset(&t, 0, sizeof(t));
+  for (int s = 0; s < num_sparse; ++s) {
+    DFM_REQUIRE(ids[s] != nullptr && vocab[s] > 0, "sparse field %d: bad ids/vocab", s);
+    t.p[s] = ids[s];
+    t.vocab[s] = vocab[s];
+  }
+  const int chunks = static_cast<int>((n + CH - 1) / CH);
+  hipLaunchKernelGGL(rowplan_sort, dim3(num_sparse, chunks), dim3(SORT_THREADS), 0, as_stream(stream),
+                     t, num_sparse, n, d_sorted_pos, d_uniq_rows, d_seg_start, d_num_uniq, d_error_flag);
+  DFM_LAUNCH_CHECK();
+  return DFM_OK;
+}
+
+int dfm_rowgrad_build(const int32_t* field_of_sparse, int num_sparse, int num_fields, int dim,
+                      int64_t n, const float* d_g_first, const float* d_g_field,
+                      const int32_t* d_sorted_pos, const int32_t* d_seg_start,
+                      const int32_t* d_num_uniq, float* d_row_g2, float* d_row_g1,
+                      dfm_stream_t stream) {
+  DFM_REQUIRE(field_of_sparse && d_g_first && d_g_field && d_sorted_pos && d_seg_start && d_num_uniq &&
+              d_row_g2 && d_row_g1, "null argument");
+  DFM_REQUIRE(num_sparse > 0 && num_sparse <= DFM_MAX_FIELDS, "num_sparse out of range");
+  DFM_REQUIRE(dim > 0 && dim % 4 == 0, "dim must be a multiple of 4");
+  DFM_REQUIRE(n > 0, "n must be positive");
+  FieldMap fm;
+  memset(&fm, 0, sizeof(fm));
+  for (int s = 0; s < num_sparse; ++s) {
+    DFM_REQUIRE(field_of_sparse[s] >= 0 && field_of_sparse[s] < num_fields, "field_of_sparse[%d] out of range", s);
+    fm.f[s] = field_of_sparse[s];
+  }
+  const int chunks = static_cast<int>((n + CH - 1) / CH);
+  const int lists = chunks * num_sparse;
+  const int64_t threads = static_cast<int64_t>(lists) * CH * (dim / 4);
+  hipLaunchKernelGGL(rowgrad_kernel, dim3(static_cast<unsigned>((threads + 255) / 256)), dim3(256), 0,
+                     as_stream(stream), fm, num_sparse, num_fields, dim, lists, d_g_first, d_g_field,
+                     d_sorted_pos, d_seg_start, d_num_uniq, d_row_g2, d_row_g1);
+  DFM_LAUNCH_CHECK();
+  return DFM_OK;
+}
+
+}  // extern "C"

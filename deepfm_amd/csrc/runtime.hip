@@ -1,0 +1,38 @@
+// Error plumbing and device queries of the C ABI.
+#include "common.h"
+
+namespace dfm {
+char* last_error_buf() {
+  static thread_local char buf[512] = {0};
+  return buf;
+}
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(last_error_buf(), 512, fmt, ap);
+  va_end(ap);
+  return code;
+}
+}  // namespace dfm
+
+extern "C" {
+
+int dfm_abi_version(void) { return DFM_ABI_VERSION; }
+
+const char* dfm_last_error(void) { return dfm::last_error_buf(); }
+
+int dfm_device_info(int* cu_count, int* wave_size, char* arch, int arch_len) {
+  int dev = 0;
+  DFM_HIP_TRY(hipGetDevice(&dev));
+  hipDeviceProp_t prop;
+  DFM_HIP_TRY(hipGetDeviceProperties(&prop, dev));
+  if (cu_count) *cu_count = prop.multiProcessorCount;
+  if (wave_size) *wave_size = prop.warpSize;
+  if (arch && arch_len > 0) {
+    strncpy(arch, prop.gcnArchName, arch_len - 1);
+    arch[arch_len - 1] = 0;
+  }
+  return DFM_OK;
+}
+
+}  // extern "C"

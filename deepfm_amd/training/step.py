@@ -1,0 +1,136 @@
+"""One training step of a BaseCTRModel on the HIP path, optionally as a HIP graph.
+
+Step = the body of the reference's ``Trainer._train_epoch`` (trainer.py:212-240):
+forward -> BCEWithLogits (+ L2 term) -> backward -> clip -> Adam, with the embedding
+tables in row-sparse mode (``RowSparseAdam``).  Layout of one step on the stream:
+
+    [eager]  fused embedding gather (``dfm_embedding_forward``)  <- optionally bracketed by
+             HIP events so bench.py can time exactly this kernel in the timed region
+    [graph A] row plan, interaction layers + DNN forward, loss, backward, row gradients
+    [eager]  data-parallel exchange (RCCL all-reduce / all-gather), world_size > 1 only
+    [graph B] merge + clip + row-wise Adam + dense Adam
+
+With one rank A and B are a single graph.  No host synchronisation inside a step.
+"""
+
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.nn.functional as Fnn
+
+from deepfm_amd.data.schema import FeatureType
+from deepfm_amd.training.rowsparse import RowSparseAdam
+
+
+class RowSparseTrainStep:
+    def __init__(self, model, optimizer: RowSparseAdam, batch_size: int, use_graph: bool = True,
+                 add_l2_term: bool = True) -> None:
+        self.model, self.opt, self.B = model, optimizer, batch_size
+        self.emb = model.embedding
+        if self.emb.grad_mode != "rowsparse":
+            raise ValueError("RowSparseTrainStep needs model.embedding in 'rowsparse' grad mode")
+        dev = optimizer.device
+        specs = list(model.schema.fields.values())
+        self.n_sparse = sum(s.feature_type is FeatureType.SPARSE for s in specs)
+        self.n_dense = sum(s.feature_type is FeatureType.DENSE for s in specs)
+        # static, packed inputs: one row per field; the per-field (B,) views keep the dict contract
+        self.ids = torch.zeros(max(self.n_sparse, 1), batch_size, dtype=torch.int64, device=dev)
+        self.dense = torch.zeros(max(self.n_dense, 1), batch_size, dtype=torch.float32, device=dev)
+        self.labels = torch.zeros(batch_size, dtype=torch.float32, device=dev)
+        self.inputs: List[torch.Tensor] = []
+        si = di = 0
+        for s in specs:
+            if s.feature_type is FeatureType.SPARSE:
+                self.inputs.append(self.ids[si]); si += 1
+            else:
+                self.inputs.append(self.dense[di]); di += 1
+        F, D = len(specs), self.emb.fm_embed_dim
+        self.fo = torch.empty(batch_size, 1, dtype=torch.float32, device=dev)
+        self.fe = torch.empty(batch_size, F, D, dtype=torch.float32, device=dev)
+        self.loss = torch.zeros((), dtype=torch.float32, device=dev)
+        self.add_l2_term = add_l2_term
+        self.use_graph = use_graph
+        self.graph_a: Optional[torch.cuda.CUDAGraph] = None
+        self.graph_b: Optional[torch.cuda.CUDAGraph] = None
+        self.dense_grads = {id(p): p.grad for p in self.emb.non_table_parameters() if p.grad is not None}
+        self.gather_events = None          # list of (start, end) torch.cuda.Event pairs when timing
+
+    # ------------------------------------------------------------------ pieces
+    def load_batch(self, ids: torch.Tensor, dense: torch.Tensor, labels: torch.Tensor) -> None:
+        """ids (S,B) int64, dense (Dn,B) float32, labels (B,) — device-to-device copies."""
+        if self.n_sparse:
+            self.ids.copy_(ids, non_blocking=True)
+        if self.n_dense:
+            self.dense.copy_(dense, non_blocking=True)
+        self.labels.copy_(labels, non_blocking=True)
+
+    def _gather(self) -> None:
+        self.emb.forward_into(self.inputs, self.B, self.fo, self.fe)
+
+    def _body_a(self) -> None:
+        self.opt.zero_grad()
+        self.emb.build_rowplan(self.inputs, self.B)
+        fo = self.fo.detach().requires_grad_()
+        fe = self.fe.detach().requires_grad_()
+        logits = self.model._forward_components(fo, fe, fe.view(self.B, -1))
+        loss = Fnn.binary_cross_entropy_with_logits(logits.view(-1), self.labels)
+        if self.add_l2_term:
+            loss = loss + self.model.get_l2_reg_loss()
+        loss.backward()
+        self.loss.copy_(loss.detach())
+        self.emb.backward_rowsparse(self.inputs, fo.grad, fe.grad, self.dense_grads)
+
+    def _body_b(self) -> None:
+        self.opt.apply()
+
+    # ------------------------------------------------------------------ capture / run
+    def capture(self, warmup_iters: int = 3) -> None:
+        """Warm up eagerly on a side stream, then capture graph A (and B)."""
+        if not self.use_graph:
+            return
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup_iters):
+                self._gather()
+                self._body_a()
+                self.opt.exchange()
+                self._body_b()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self._gather()
+        single = self.opt.world == 1
+        self.graph_a = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph_a):
+            self._body_a()
+            if single:
+                self._body_b()
+        if not single:
+            self.opt.exchange()
+            self.graph_b = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_b):
+                self._body_b()
+        torch.cuda.synchronize()
+
+    def run(self, time_gather: bool = False) -> None:
+        if time_gather:
+            start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            start.record()
+            self._gather()
+            end.record()
+            if self.gather_events is None:
+                self.gather_events = []
+            self.gather_events.append((start, end))
+        else:
+            self._gather()
+        if self.graph_a is not None:
+            self.graph_a.replay()
+            if self.graph_b is not None:
+                self.opt.exchange()
+                self.graph_b.replay()
+        else:
+            self._body_a()
+            self.opt.exchange()
+            self._body_b()

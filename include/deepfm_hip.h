@@ -1,0 +1,179 @@
+/*
+ * deepfm_hip.h — C ABI of the MI355X (gfx950) CTR feature-interaction library.
+ *
+ * The reference (CodexploreRepo/deepfm) has no FFI layer: its operator interface is
+ * the forward() of four torch.nn modules plus autograd.  Each entry point below is
+ * the native replacement of one of those Python call sites; the host-side mirror in
+ * deepfm_amd/models/layers/ binds them with ctypes.
+ *
+ * Conventions
+ *   - every pointer named d_* / in the "device" column is a DEVICE pointer (HBM);
+ *     pointer tables passed as `const T* const*` are HOST arrays of device pointers;
+ *   - all floating point is IEEE fp32, ids are int64 (reference dataset.py:28-38);
+ *   - `stream` is a hipStream_t (NULL = the null stream); calls only enqueue work,
+ *     they never synchronise and are safe under hipGraph stream capture;
+ *   - return value: 0 = DFM_OK, otherwise an error code; dfm_last_error() gives text;
+ *   - id range errors (id < 0 or id >= vocabulary) never fault: the id is treated as
+ *     the padding id 0 and bit 0 of *d_error_flag is set (the reference raises
+ *     IndexError from ATen; the Python mirror raises IndexError when it reads the flag).
+ */
+#ifndef DEEPFM_HIP_H
+#define DEEPFM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DFM_ABI_VERSION 1
+#define DFM_MAX_FIELDS 64      /* per-call pointer tables travel as kernel arguments */
+#define DFM_ROWPLAN_CHUNK 4096 /* ids per sorted list (one LDS-resident sort) */
+
+enum dfm_status { DFM_OK = 0, DFM_ERR_INVALID = 1, DFM_ERR_HIP = 2, DFM_ERR_UNSUPPORTED = 3 };
+enum dfm_field_kind { DFM_SPARSE = 0, DFM_DENSE = 1, DFM_SEQUENCE = 2 };
+enum dfm_combiner { DFM_MEAN = 0, DFM_SUM = 1, DFM_MAX = 2 };
+
+typedef void* dfm_stream_t;
+
+int dfm_abi_version(void);
+const char* dfm_last_error(void);
+/* CU count, wavefront size and gcnArchName of the current device. */
+int dfm_device_info(int* cu_count, int* wave_size, char* arch, int arch_len);
+
+/* ---------------------------------------------------------------------------------
+ * FeatureEmbedding  (reference deepfm/models/layers/embedding.py:20-126)
+ * ------------------------------------------------------------------------------- */
+
+/* One schema field with its parameter tensors (reference embedding.py:32-62):
+ *   SPARSE / SEQUENCE: w2 = second_order_embeddings.<f>.weight (vocab, dim),
+ *                      w1 = first_order_embeddings.<f>.weight  (vocab, 1)
+ *   DENSE:             w2 = Linear(1,dim).weight (dim,1), b2 = .bias (dim),
+ *                      w1 = Linear(1,1).weight (1,1),     b1 = .bias (1)
+ *   proj = projections.<f>.weight (fm_dim, dim) or NULL when dim == fm_dim. */
+typedef struct dfm_field {
+  int32_t kind;        /* dfm_field_kind */
+  int32_t dim;         /* embedding_dim of the field */
+  int32_t vocab;       /* rows of w2 / w1 (0 for DENSE) */
+  int32_t max_len;     /* SEQUENCE: ids per bag (L) */
+  int32_t combiner;    /* SEQUENCE: dfm_combiner */
+  int32_t flat_offset; /* column of this field inside flat_embeddings */
+  const float* w2;
+  const float* b2;
+  const float* w1;
+  const float* b1;
+  const float* proj;
+} dfm_field;
+
+/* Gradient buffers matching dfm_field (dense, same shapes as the parameters). */
+typedef struct dfm_field_grad {
+  float* w2;
+  float* b2;
+  float* w1;
+  float* b1;
+  float* proj;
+} dfm_field_grad;
+
+typedef struct dfm_embedding_plan dfm_embedding_plan;
+
+/* Uploads the field table once.  `fields` is a host array in schema order. */
+int dfm_embedding_plan_create(const dfm_field* fields, int num_fields, int fm_dim,
+                              dfm_embedding_plan** out_plan);
+int dfm_embedding_plan_destroy(dfm_embedding_plan* plan);
+/* 1 when every field is SPARSE or DENSE with dim == fm_dim (dim % 4 == 0) and no
+ * projection: flat_embeddings is then field_embeddings reshaped (same bytes) and the
+ * fused gather kernel is used. */
+int dfm_embedding_plan_is_uniform(const dfm_embedding_plan* plan);
+/* Bytes of scratch the forward/backward calls need for a batch of `batch` samples. */
+size_t dfm_embedding_workspace_bytes(const dfm_embedding_plan* plan, int64_t batch);
+
+/* FeatureEmbedding.forward (embedding.py:76-126).
+ *   inputs[f]: SPARSE int64 (B,), SEQUENCE int64 (B, L) row-major, DENSE float (B,)
+ *   d_first_order (B,1)  d_field_emb (B,F,fm_dim)  d_flat_emb (B, sum dim)
+ * For a uniform plan d_flat_emb may be NULL or equal to d_field_emb (aliased).
+ * d_fm_out (B,1), optional (uniform plans only): the FMInteraction value
+ * 0.5*sum_d[(sum_f e)^2 - sum_f e^2] (fm.py:18-23) computed from the rows while they
+ * are in registers. */
+int dfm_embedding_forward(const dfm_embedding_plan* plan, const void* const* inputs, int64_t batch,
+                          float* d_first_order, float* d_field_emb, float* d_flat_emb,
+                          float* d_fm_out, void* d_workspace, int32_t* d_error_flag,
+                          dfm_stream_t stream);
+
+/* Autograd of the forward w.r.t. every parameter as DENSE gradients — the reference
+ * semantics (nn.Embedding(sparse=False), embedding.py:35-40).  Gradients are ADDED
+ * into the buffers of `grads` (caller zero-fills them); row 0 receives none.
+ * d_g_flat may be NULL for a uniform plan whose flat view aliases field_emb (the
+ * caller has already summed both into d_g_field). */
+int dfm_embedding_backward_dense(const dfm_embedding_plan* plan, const void* const* inputs,
+                                 int64_t batch, const float* d_g_first, const float* d_g_field,
+                                 const float* d_g_flat, const dfm_field_grad* grads,
+                                 void* d_workspace, dfm_stream_t stream);
+
+/* Gradients of the DENSE fields' Linear parameters only (deterministic tree
+ * reduction over the batch); used by the row-sparse mode together with
+ * dfm_rowgrad_build for the SPARSE fields. */
+int dfm_embedding_backward_dense_fields(const dfm_embedding_plan* plan, const void* const* inputs,
+                                        int64_t batch, const float* d_g_first,
+                                        const float* d_g_field, const float* d_g_flat,
+                                        const dfm_field_grad* grads, dfm_stream_t stream);
+
+/* ---------------------------------------------------------------------------------
+ * Row plan + row-wise gradient: the backward scatter-add of the SPARSE fields without
+ * atomics (reference: autograd of embedding.py:95-98, i.e. aten::embedding_dense_backward)
+ * ------------------------------------------------------------------------------- */
+
+/* For each of `num_sparse` id vectors (n ids each) and each chunk of DFM_ROWPLAN_CHUNK
+ * ids: stable sort by id, drop id 0, find the distinct ids.  With C = ceil(n/chunk):
+ *   d_sorted_pos (C, S, chunk) int32  sample position of every sorted entry
+ *   d_uniq_rows  (C, S, chunk) int32  distinct ids, ascending
+ *   d_seg_start  (C, S, chunk+1) int32  first sorted entry of every distinct id
+ *   d_num_uniq   (C, S) int32
+ * Depends on the ids only, so it can run ahead of the forward pass. */
+int dfm_rowplan_build(const int64_t* const* ids, const int32_t* vocab, int num_sparse, int64_t n,
+                      int32_t* d_sorted_pos, int32_t* d_uniq_rows, int32_t* d_seg_start,
+                      int32_t* d_num_uniq, int32_t* d_error_flag, dfm_stream_t stream);
+
+/* Row gradients of the distinct ids, contributions added in increasing sample order:
+ *   d_row_g2 (C, S, chunk, dim)   d_row_g1 (C, S, chunk)
+ * `field_of_sparse[s]` is the schema position of sparse field s inside d_g_field
+ * (B, F, dim); d_g_first is (B,1).  Uniform plans only (dim == fm_dim). */
+int dfm_rowgrad_build(const int32_t* field_of_sparse, int num_sparse, int num_fields, int dim,
+                      int64_t n, const float* d_g_first, const float* d_g_field,
+                      const int32_t* d_sorted_pos, const int32_t* d_seg_start,
+                      const int32_t* d_num_uniq, float* d_row_g2, float* d_row_g1,
+                      dfm_stream_t stream);
+
+/* Row-wise Adam over `num_lists` = ranks x chunks lists (all-gathered under data
+ * parallelism).  A row present in several lists is owned by its first list; the owner
+ * adds the other lists' gradients in list order (bit-identical on every replica),
+ * then:  g = grad_scale * sum + 2*l2*w ;  g *= clip ;  Adam(w, m, v, g)
+ * (reference trainer.py:224-237 restricted to the rows the batch touched — DESIGN.md).
+ * Pass A (dfm_rowadam_merge) writes the merged gradients in place and the squared
+ * norm of g into d_sq_norm[0]; pass B (dfm_rowadam_apply) reads *d_clip_coef. */
+typedef struct dfm_table { float* w2; float* m2; float* v2; float* w1; float* m1; float* v1; } dfm_table;
+
+int dfm_rowadam_merge(const dfm_table* tables, int num_sparse, int dim, int num_lists,
+                      const int32_t* d_uniq_rows, const int32_t* d_num_uniq, float* d_row_g2,
+                      float* d_row_g1, int32_t* d_owner_flag, float grad_scale, float l2,
+                      float* d_sq_norm, void* d_workspace, dfm_stream_t stream);
+size_t dfm_rowadam_workspace_bytes(int num_sparse, int num_lists);
+int dfm_rowadam_apply(const dfm_table* tables, int num_sparse, int dim, int num_lists,
+                      const int32_t* d_uniq_rows, const int32_t* d_num_uniq, const float* d_row_g2,
+                      const float* d_row_g1, const int32_t* d_owner_flag, const float* d_clip_coef,
+                      float lr, float beta1, float beta2, float eps, const int32_t* d_step,
+                      dfm_stream_t stream);
+
+/* ---------------------------------------------------------------------------------
+ * FMInteraction  (reference deepfm/models/layers/fm.py:18-23)
+ * ------------------------------------------------------------------------------- */
+int dfm_fm_forward(const float* d_field_emb, int64_t batch, int num_fields, int dim, float* d_out,
+                   dfm_stream_t stream);
+/* d e[b,f,:] = g[b] * (S[b,:] - e[b,f,:]) */
+int dfm_fm_backward(const float* d_field_emb, const float* d_g_out, int64_t batch, int num_fields,
+                    int dim, float* d_g_field, dfm_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEEPFM_HIP_H */

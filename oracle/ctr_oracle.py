@@ -610,3 +610,75 @@ def clip_coef(total_sq_norm: float, max_norm: float) -> F32:
     """clip_grad_norm_ scale (trainer.py:232-235): min(1, max_norm/(norm+1e-6))."""
     norm = math.sqrt(float(total_sq_norm))
     return F32(min(1.0, max_norm / (norm + 1e-6)))
+
+
+def rowsparse_reduce_fast(ids: Array, g_rows: Array, g_first: Array):
+    """Vectorised rowsparse_from_batch (same result up to fp32 summation order inside a
+    run of duplicates): used by the CPU-baseline timing and the large-shape checks."""
+    order = np.argsort(ids, kind="stable")
+    sid = ids[order]
+    keep = sid != 0
+    order, sid = order[keep], sid[keep]
+    if sid.size == 0:
+        return sid, np.zeros((0, g_rows.shape[1]), F32), np.zeros((0,), F32)
+    starts = np.flatnonzero(np.r_[True, sid[1:] != sid[:-1]])
+    return (sid[starts], np.add.reduceat(g_rows[order], starts, axis=0).astype(F32),
+            np.add.reduceat(g_first[order], starts).astype(F32))
+
+
+def deepfm_train_step_rowsparse(fields, params: Dict[str, Array], state: Dict[str, Array],
+                                batch, labels: Array, cfg: dict, hp: dict, step: int,
+                                exact_order: bool = False) -> F32:
+    """One DeepFM training step in the build's row-sparse mode, in place on ``params`` /
+    ``state`` (``m/<key>``, ``v/<key>`` Adam moments): forward (embedding.py:76-126,
+    fm.py:18-23, dnn.py:45-59, deepfm.py:30-42), BCE + L2 on the non-table embedding
+    parameters (trainer.py:221-225), backward, lazy L2 on touched rows, global-norm clip
+    (trainer.py:232-235), Adam (trainer.py:237).  hp: lr, l2, max_grad_norm, betas, eps."""
+    emb_p = _sub(params, "embedding.")
+    fo, fe, fl = embedding_forward(fields, emb_p, batch, cfg["fm_dim"])
+    n_hidden = len(cfg["hidden_units"])
+    dnn_p = _sub(params, "dnn.")
+    h = dnn_forward(fl, dnn_p, n_hidden, training=True)
+    logits = fo + fm_forward(fe) + linear_forward(h, params, "output_linear.")
+    loss, dz = bce_with_logits(logits, labels)
+    grads: Dict[str, Array] = {}
+    grads["output_linear.weight"] = (dz.T @ h).astype(F32)
+    grads["output_linear.bias"] = dz.sum(axis=0, dtype=F32)
+    d_fl, dnn_g = dnn_backward(fl, dnn_p, n_hidden, dz @ params["output_linear.weight"], training=True)
+    grads.update({"dnn." + k: v for k, v in dnn_g.items()})
+    d_fe = fm_backward(fe, dz) + d_fl.reshape(fe.shape)      # uniform schema: flat == fe reshaped
+    l2 = F32(hp["l2"])
+    rows = {}
+    sq = 0.0
+    for fidx, spec in enumerate(fields):
+        name = spec["name"]
+        k2, k1 = f"embedding.second_order_embeddings.{name}.weight", f"embedding.first_order_embeddings.{name}.weight"
+        if spec["type"] == "sparse":
+            red = rowsparse_from_batch if exact_order else rowsparse_reduce_fast
+            uniq, r2, r1 = red(batch[name], d_fe[:, fidx, :], dz[:, 0])
+            r2 = (r2 + 2 * l2 * params[k2][uniq]).astype(F32)
+            r1 = (r1 + 2 * l2 * params[k1][uniq, 0]).astype(F32)
+            rows[name] = (uniq, r2, r1)
+            sq += float((r2.astype(np.float64) ** 2).sum() + (r1.astype(np.float64) ** 2).sum())
+        else:
+            x = batch[name].astype(F32)
+            g = d_fe[:, fidx, :]
+            b2k, b1k = k2.replace("weight", "bias"), k1.replace("weight", "bias")
+            grads[k2] = ((x[:, None] * g).sum(axis=0, dtype=F32)[:, None] + 2 * l2 * params[k2]).astype(F32)
+            grads[b2k] = (g.sum(axis=0, dtype=F32) + 2 * l2 * params[b2k]).astype(F32)
+            grads[k1] = (np.array([[np.dot(x, dz[:, 0])]], dtype=F32) + 2 * l2 * params[k1]).astype(F32)
+            grads[b1k] = (np.array([dz[:, 0].sum(dtype=F32)], dtype=F32) + 2 * l2 * params[b1k]).astype(F32)
+    for g in grads.values():
+        sq += float((g.astype(np.float64) ** 2).sum())
+    coef = clip_coef(sq, hp["max_grad_norm"]) if hp.get("max_grad_norm") else F32(1.0)
+    b1, b2 = hp.get("betas", (0.9, 0.999))
+    eps = hp.get("eps", 1e-8)
+    for k, g in grads.items():
+        adam_update(params[k], state["m/" + k], state["v/" + k], g * coef, step, hp["lr"], b1, b2, eps)
+    for name, (uniq, r2, r1) in rows.items():
+        for key, g in ((f"embedding.second_order_embeddings.{name}.weight", r2),
+                       (f"embedding.first_order_embeddings.{name}.weight", r1[:, None])):
+            w, m, v = params[key][uniq], state["m/" + key][uniq], state["v/" + key][uniq]
+            adam_update(w, m, v, g * coef, step, hp["lr"], b1, b2, eps)
+            params[key][uniq], state["m/" + key][uniq], state["v/" + key][uniq] = w, m, v
+    return loss

@@ -70,3 +70,45 @@ def cin_full_params(F=39, layer_sizes=(128, 128, 128), split_half=True):
         params[f"conv_layers.{li}.bias"] = hashed_weights((size,), 2 * li + 2, 0.1)
         prev = size - size // 2 if (split_half and li < len(layer_sizes) - 1) else size
     return params
+
+
+# ---- glue between the golden "fields" description and the package's schema objects ----
+
+def schema_from_fields(fields):
+    from deepfm_amd.data.schema import DatasetSchema, FeatureType, FieldSchema
+    kind = {"sparse": FeatureType.SPARSE, "dense": FeatureType.DENSE, "sequence": FeatureType.SEQUENCE}
+    return DatasetSchema(fields={
+        f["name"]: FieldSchema(name=f["name"], feature_type=kind[f["type"]], vocabulary_size=f["vocab"],
+                               embedding_dim=f["dim"], max_length=f["max_len"], combiner=f["combiner"])
+        for f in fields})
+
+
+def load_params(module, params: Dict[str, np.ndarray], device="cuda"):
+    """Copy golden/oracle parameters (state_dict-keyed numpy arrays) into a torch module."""
+    import torch
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in params.items()}
+    missing, unexpected = module.load_state_dict(sd, strict=True), None
+    return module.to(device)
+
+
+def to_device_batch(batch: Dict[str, np.ndarray], device="cuda"):
+    import torch
+    return {k: torch.from_numpy(v).to(device) for k, v in batch.items()}
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+def random_fields_batch(fields, B, rng, zero_frac=0.01):
+    batch = {}
+    for f in fields:
+        if f["type"] == "sparse":
+            x = rng.integers(1, f["vocab"], size=B, dtype=np.int64)
+            x[rng.random(B) < zero_frac] = 0
+        elif f["type"] == "sequence":
+            x = rng.integers(0, f["vocab"], size=(B, f["max_len"]), dtype=np.int64)
+        else:
+            x = rng.random(B).astype(np.float32)
+        batch[f["name"]] = x
+    return batch

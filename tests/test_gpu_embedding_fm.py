@@ -1,0 +1,141 @@
+"""GPU parity: FeatureEmbedding / FMInteraction HIP kernels (through the C ABI) against the
+reference's golden vectors and the numpy oracle.
+
+Bars (BASELINE.json): SPARSE row gathers bit-exact; everything floating point within
+1e-4 relative (helpers.assert_close: |err| <= 1e-4*|ref| + 1e-5*max|ref|).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ctr_oracle as O
+from tests.helpers import (assert_close, fields_of, group, load, load_params, npy, random_fields_batch,
+                           schema_from_fields, to_device_batch)
+
+pytestmark = pytest.mark.gpu
+
+EMB_CASES = ["emb_movielens_mean", "emb_movielens_sum", "emb_movielens_max", "emb_criteo_d16",
+             "emb_criteo_d32", "emb_layers_test_schema"]
+
+
+def _module(g):
+    from deepfm_amd.models.layers.embedding import FeatureEmbedding
+    emb = FeatureEmbedding(schema_from_fields(fields_of(g)), fm_embed_dim=int(g["fm_dim"]))
+    emb.strict_indices = True
+    return load_params(emb, group(g, "param/"))
+
+
+@pytest.mark.parametrize("case", EMB_CASES)
+def test_embedding_forward_backward_vs_golden(case):
+    g = load(case)
+    fields = fields_of(g)
+    emb = _module(g)
+    assert sorted(emb.state_dict().keys()) == sorted(group(g, "param/").keys())
+    fo, fe, fl = emb(to_device_batch(group(g, "batch/")))
+    assert fo.shape == g["out/first_order"].shape and fe.shape == g["out/field_embeddings"].shape
+    assert fl.shape == g["out/flat_embeddings"].shape
+    assert_close(npy(fo), g["out/first_order"], what="first_order")
+    assert_close(npy(fe), g["out/field_embeddings"], what="field_embeddings")
+    assert_close(npy(fl), g["out/flat_embeddings"], what="flat_embeddings")
+    off = 0
+    for f in fields:                                   # pure gathers: bit-exact
+        if f["type"] == "sparse":
+            assert np.array_equal(npy(fl)[:, off:off + f["dim"]], g["out/flat_embeddings"][:, off:off + f["dim"]]), f["name"]
+        off += f["dim"]
+    up = {k: torch.from_numpy(g["upstream/" + k]).cuda() for k in ("first_order", "field_embeddings", "flat_embeddings")}
+    loss = (fo * up["first_order"]).sum() + (fe * up["field_embeddings"]).sum() + (fl * up["flat_embeddings"]).sum()
+    loss.backward()
+    want = group(g, "grad/")
+    for k, p in emb.named_parameters():
+        assert p.grad is not None, k                   # tests/test_layers.py:53-62
+        assert_close(npy(p.grad), want[k], what=k)
+
+
+def test_padding_idx_zero_gives_exact_zeros():
+    """tests/test_layers.py:43-51"""
+    g = load("emb_layers_test_schema")
+    emb = _module(g)
+    batch = {f["name"]: torch.zeros(2, dtype=torch.long, device="cuda") for f in fields_of(g)}
+    with torch.no_grad():
+        for out in emb(batch):
+            assert float(out.abs().sum()) == 0.0
+
+
+def test_out_of_range_index_raises_index_error():
+    g = load("emb_layers_test_schema")
+    emb = _module(g)
+    batch = {f["name"]: torch.ones(2, dtype=torch.long, device="cuda") for f in fields_of(g)}
+    batch["g"] = torch.tensor([1, 3], device="cuda")           # vocab of "g" is 3
+    with pytest.raises(IndexError):
+        emb(batch)
+    with pytest.raises(KeyError):
+        emb({"u": batch["u"]})
+
+
+def test_empty_batch_and_ragged_tail():
+    g = load("emb_criteo_d16")
+    emb = _module(g)
+    fields, params = fields_of(g), group(g, "param/")
+    rng = np.random.default_rng(5)
+    for B in (0, 1, 15, 17, 33):
+        batch = random_fields_batch(fields, B, rng, zero_frac=0.2)
+        with torch.no_grad():
+            fo, fe, fl = emb(to_device_batch(batch))
+        assert fo.shape == (B, 1) and fe.shape == (B, 39, 16) and fl.shape == (B, 624)
+        if B:
+            ofo, ofe, ofl = O.embedding_forward(fields, params, batch, 16)
+            assert np.array_equal(npy(fe)[:, :26], ofe[:, :26])
+            assert_close(npy(fo), ofo, what="fo")
+            assert_close(npy(fl), ofl, what="flat")
+
+
+def test_criteo_batch4096_vs_oracle_and_fused_fm():
+    """Full batch size of BASELINE.json config 2 at a vocabulary the oracle handles in seconds."""
+    from tools_shared import criteo_fields
+    fields = criteo_fields(20000, 16)
+    from deepfm_amd.models.layers.embedding import FeatureEmbedding
+    torch.manual_seed(0)
+    emb = FeatureEmbedding(schema_from_fields(fields), 16).cuda()
+    params = {k: npy(v) for k, v in emb.state_dict().items()}
+    rng = np.random.default_rng(1)
+    batch = random_fields_batch(fields, 4096, rng)
+    dbatch = to_device_batch(batch)
+    with torch.no_grad():
+        fo, fe, fl = emb(dbatch)
+        inputs, B = emb._gather_inputs(dbatch)
+        _, _, _, fm_fused = emb._launch_forward(inputs, B, want_fm=True)
+    ofo, ofe, ofl = O.embedding_forward(fields, params, batch, 16)
+    assert np.array_equal(npy(fe)[:, :26], ofe[:, :26])      # gathers bit-exact
+    assert_close(npy(fe), ofe, what="fe")
+    assert_close(npy(fo), ofo, what="fo")
+    assert fl.data_ptr() == fe.data_ptr()                    # aliased view, no second write
+    assert_close(npy(fm_fused), O.fm_forward(ofe), what="fused fm")
+
+
+def test_fm_vs_golden_and_known_answers():
+    from deepfm_amd.models.layers.fm import FMInteraction
+    g = load("fm")
+    fm = FMInteraction()
+    assert len(list(fm.parameters())) == 0                   # tests/test_layers.py:75-77
+    x = torch.from_numpy(g["x"]).cuda().requires_grad_()
+    out = fm(x)
+    assert out.shape == (64, 1)
+    assert_close(npy(out), g["out"], what="fm")
+    (out * torch.from_numpy(g["upstream"]).cuda()).sum().backward()
+    assert_close(npy(x.grad), g["d_x"], what="fm d_x")
+    assert float(fm(torch.from_numpy(g["known_x"]).cuda())[0, 0]) == 67.0   # notes/deepfm.md:72-90
+    assert np.allclose(npy(fm(torch.from_numpy(g["single_x"]).cuda())), 0.0, atol=1e-5)
+    assert_close(npy(out), O.fm_pairwise(g["x"]), what="pairwise")          # tests/test_layers.py:79-92
+
+
+@pytest.mark.parametrize("shape", [(3, 5, 6), (130, 39, 32), (7, 2, 1), (1, 1, 4)])
+def test_fm_odd_shapes(shape):
+    from deepfm_amd.models.layers.fm import FMInteraction
+    rng = np.random.default_rng(shape[0])
+    x = rng.standard_normal(shape).astype(np.float32)
+    g = rng.standard_normal((shape[0], 1)).astype(np.float32)
+    t = torch.from_numpy(x).cuda().requires_grad_()
+    out = FMInteraction()(t)
+    (out * torch.from_numpy(g).cuda()).sum().backward()
+    assert_close(npy(out), O.fm_forward(x), what="fm")
+    assert_close(npy(t.grad), O.fm_backward(x, g), what="fm bwd")

@@ -1,0 +1,206 @@
+"""GPU parity: whole-model logits/gradients (DeepFM here; xDeepFM / AttentionDeepFM in their
+own files) and the row-sparse training step, against golden vectors and the oracle."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ctr_oracle as O
+from tests.helpers import (assert_close, cfg_of, fields_of, group, load, load_params, npy,
+                           random_fields_batch, schema_from_fields, to_device_batch)
+from tools_shared import criteo_fields
+
+pytestmark = pytest.mark.gpu
+
+
+def _config(c):
+    from deepfm_amd.config import ExperimentConfig
+    cfg = ExperimentConfig()
+    cfg.feature.fm_embed_dim = c["fm_dim"]
+    cfg.dnn.hidden_units = list(c["hidden_units"])
+    cfg.dnn.dropout = 0.0
+    if c["kind"] == "xdeepfm":
+        cfg.cin.layer_sizes, cfg.cin.split_half = list(c["cin_sizes"]), c["cin_split"]
+    if c["kind"] == "attention_deepfm":
+        cfg.attention.num_heads, cfg.attention.attention_dim = c["heads"], c["A"]
+        cfg.attention.num_layers, cfg.attention.use_residual = c["layers"], c["residual"]
+    return cfg
+
+
+def check_model_case(case):
+    from deepfm_amd.models import create_model
+    g = load(case)
+    c = cfg_of(g)
+    model = create_model(c["kind"], schema_from_fields(fields_of(g)), _config(c))
+    want_p = group(g, "param/")
+    assert sorted(model.state_dict().keys()) == sorted(want_p.keys())      # drop-in state_dict
+    load_params(model, want_p)
+    model.embedding.strict_indices = True
+    batch = to_device_batch(group(g, "batch/"))
+    model.eval()
+    with torch.no_grad():
+        logits = model(batch)
+        assert logits.shape == g["logits_eval"].shape
+        assert_close(npy(logits), g["logits_eval"], what="eval logits")
+        p = npy(model.predict(batch))
+        assert (p >= 0).all() and (p <= 1).all()                           # tests/test_models.py:36-41
+    model.train()
+    logits = model(batch)
+    assert_close(npy(logits), g["logits_train"], what="train logits")
+    loss = torch.nn.functional.binary_cross_entropy_with_logits(
+        logits.squeeze(-1), torch.from_numpy(g["labels"]).cuda())
+    assert abs(float(loss) - float(g["loss"])) < 1e-5
+    loss.backward()
+    want_g = group(g, "grad/")
+    for k, prm in model.named_parameters():
+        assert prm.grad is not None, k
+        pre_bn_bias = k.startswith("dnn.mlp.") and k.endswith(".bias") and int(k.split(".")[2]) % 4 == 0
+        floor = 1e-6 if pre_bn_bias else (2e-6 if k.endswith("W_k.bias") else 0.0)
+        assert_close(npy(prm.grad), want_g[k], what=k, floor=floor)
+    assert float(model.get_l2_reg_loss()) > 0                              # tests/test_models.py:43-46
+
+
+@pytest.mark.parametrize("case", ["model_deepfm", "model_deepfm_movielens"])
+def test_deepfm_vs_golden(case):
+    check_model_case(case)
+
+
+def test_registry():
+    """tests/test_models.py:98-112"""
+    from deepfm_amd.config import ExperimentConfig
+    from deepfm_amd.models import MODEL_REGISTRY, create_model
+    assert "deepfm" in MODEL_REGISTRY
+    with pytest.raises(ValueError):
+        create_model("nope", schema_from_fields(criteo_fields(10, 16)), ExperimentConfig())
+
+
+# ------------------------------------------------------------------ row-sparse mode
+
+def test_rowgrad_equals_dense_reference_gradients():
+    from deepfm_amd.models.layers.embedding import FeatureEmbedding
+    g = load("emb_criteo_d16")
+    fields = fields_of(g)
+    emb = load_params(FeatureEmbedding(schema_from_fields(fields), 16), group(g, "param/"))
+    emb.set_grad_mode("rowsparse")
+    fo, fe, fl = emb(to_device_batch(group(g, "batch/")))
+    assert_close(npy(fe), g["out/field_embeddings"], what="fe")
+    up = {k: torch.from_numpy(g["upstream/" + k]).cuda() for k in ("first_order", "field_embeddings", "flat_embeddings")}
+    ((fo * up["first_order"]).sum() + (fe * up["field_embeddings"]).sum() + (fl * up["flat_embeddings"]).sum()).backward()
+    rs = emb.rowsparse
+    assert rs.has_grad and rs.chunks == 1
+    want = group(g, "grad/")
+    num = npy(rs.num_uniq)[0]
+    batch = group(g, "batch/")
+    g_fe_total = g["upstream/field_embeddings"] + g["upstream/flat_embeddings"].reshape(g["upstream/field_embeddings"].shape)
+    for s, f in enumerate(fields[:26]):
+        n = int(num[s])
+        rows = npy(rs.uniq_rows)[0, s, :n]
+        assert (np.diff(rows) > 0).all() and (rows > 0).all()
+        dense2 = np.zeros_like(want[f"second_order_embeddings.{f['name']}.weight"])
+        dense1 = np.zeros_like(want[f"first_order_embeddings.{f['name']}.weight"])
+        dense2[rows] = npy(rs.row_g2)[0, s, :n]
+        dense1[rows, 0] = npy(rs.row_g1)[0, s, :n]
+        assert_close(dense2, want[f"second_order_embeddings.{f['name']}.weight"], what=f["name"])
+        assert_close(dense1, want[f"first_order_embeddings.{f['name']}.weight"], what=f["name"])
+        # bit-exact against the oracle's ordered reduction (same fp32 addition order)
+        u, r2, r1 = O.rowsparse_from_batch(batch[f["name"]], g_fe_total[:, s, :], g["upstream/first_order"][:, 0])
+        assert np.array_equal(u, rows) and np.array_equal(r2, npy(rs.row_g2)[0, s, :n])
+        assert np.array_equal(r1, npy(rs.row_g1)[0, s, :n])
+    for k, p in emb.named_parameters():       # DENSE-field Linears still get autograd gradients
+        if ".I" in k:
+            assert_close(npy(p.grad), want[k], what=k)
+
+
+def _small_deepfm(V=300, seed=0):
+    from deepfm_amd.config import ExperimentConfig
+    from deepfm_amd.models import create_model
+    fields = criteo_fields(V, 16)
+    cfg = ExperimentConfig()
+    cfg.dnn.hidden_units, cfg.dnn.dropout = [64, 32], 0.0
+    torch.manual_seed(seed)
+    model = create_model("deepfm", schema_from_fields(fields), cfg).cuda().train()
+    model.embedding.set_grad_mode("rowsparse")
+    return fields, cfg, model
+
+
+def _pool(fields, n, B, rng):
+    ids = np.stack([np.stack([random_fields_batch([f], B, rng, 0.05)[f["name"]] for f in fields[:26]]) for _ in range(n)])
+    dense = rng.random((n, 13, B)).astype(np.float32)
+    labels = (rng.random((n, B)) < 0.25).astype(np.float32)
+    return ids, dense, labels
+
+
+def _oracle_state(model):
+    params = {k: npy(v).copy() for k, v in model.state_dict().items() if not k.endswith("num_batches_tracked")}
+    state = {}
+    for k, v in params.items():
+        if "running_" not in k:
+            state["m/" + k], state["v/" + k] = np.zeros_like(v), np.zeros_like(v)
+    return params, state
+
+
+@pytest.mark.parametrize("B", [512, 6000])      # 6000 -> two sorted chunks merged by ownership
+def test_rowsparse_train_steps_vs_oracle(B):
+    from deepfm_amd.training.rowsparse import RowSparseAdam
+    from deepfm_amd.training.step import RowSparseTrainStep
+    fields, cfg, model = _small_deepfm()
+    hp = dict(lr=1e-3, l2=1e-5, max_grad_norm=1.0)
+    params, state = _oracle_state(model)
+    opt = RowSparseAdam(model, lr=hp["lr"], l2=hp["l2"], max_grad_norm=hp["max_grad_norm"])
+    step = RowSparseTrainStep(model, opt, B, use_graph=False)
+    rng = np.random.default_rng(3)
+    ids, dense, labels = _pool(fields, 3, B, rng)
+    ocfg = dict(fm_dim=16, hidden_units=cfg.dnn.hidden_units)
+    for i in range(3):
+        step.load_batch(torch.from_numpy(ids[i]).cuda(), torch.from_numpy(dense[i]).cuda(), torch.from_numpy(labels[i]).cuda())
+        step.run()
+        batch = {f["name"]: ids[i, j] for j, f in enumerate(fields[:26])}
+        batch.update({f["name"]: dense[i, j] for j, f in enumerate(fields[26:])})
+        oloss = O.deepfm_train_step_rowsparse(fields, params, state, batch, labels[i], ocfg, hp, i + 1, exact_order=(B <= 512))
+        gl2 = float(model.get_l2_reg_loss())
+        assert abs(float(step.loss) - gl2 - float(oloss)) < 2e-5 + 1e-4 * abs(float(oloss)), (i, float(step.loss), float(oloss))
+    got = {k: npy(v) for k, v in model.state_dict().items()}
+    for k, want in params.items():
+        if "running_" in k:
+            assert_close(got[k], want, rtol=1e-3, what=k)
+            continue
+        if k.startswith("dnn.mlp.") and k.endswith(".bias") and int(k.split(".")[2]) % 4 == 0:
+            continue        # zero-gradient parameter: Adam amplifies rounding noise to +-lr
+        # Adam divides by sqrt(v): elements with |g| ~ eps are ill-conditioned -> absolute floor of lr/10
+        assert_close(got[k], want, rtol=1e-4, atol_scale=0.0, floor=1e-4, what=k)
+
+
+def test_graph_replay_is_bitwise_equal_to_eager_and_deterministic():
+    from deepfm_amd.training.rowsparse import RowSparseAdam
+    from deepfm_amd.training.step import RowSparseTrainStep
+    B = 1024
+    results = []
+    rng = np.random.default_rng(9)
+    fields = criteo_fields(300, 16)
+    ids, dense, labels = _pool(fields, 4, B, rng)
+    for use_graph in (False, True, True):
+        _, _, model = _small_deepfm(seed=4)
+        opt = RowSparseAdam(model, lr=1e-3, l2=1e-5, max_grad_norm=1.0)
+        step = RowSparseTrainStep(model, opt, B, use_graph=use_graph)
+        start = copy.deepcopy(model.state_dict())
+        step.load_batch(torch.from_numpy(ids[0]).cuda(), torch.from_numpy(dense[0]).cuda(), torch.from_numpy(labels[0]).cuda())
+        step.capture()
+        # capture's warm-up iterations trained on batch 0: rewind model + optimizer state
+        model.load_state_dict(start)
+        for t in opt.exp_avg + opt.exp_avg_sq:
+            t.zero_()
+        opt.step_count.zero_()
+        if opt.dense_opt is not None:
+            for st in opt.dense_opt.state.values():
+                for v in st.values():
+                    if torch.is_tensor(v):
+                        v.zero_()
+        for i in range(4):
+            step.load_batch(torch.from_numpy(ids[i]).cuda(), torch.from_numpy(dense[i]).cuda(), torch.from_numpy(labels[i]).cuda())
+            step.run()
+        torch.cuda.synchronize()
+        results.append({k: npy(v).copy() for k, v in model.state_dict().items()})
+    for k in results[0]:
+        assert np.array_equal(results[1][k], results[2][k]), f"graph replay not deterministic: {k}"
+        assert np.array_equal(results[0][k], results[1][k]), f"graph != eager: {k}"
