@@ -321,7 +321,7 @@ class FeatureEmbedding(nn.Module):
                 fo, fe = _RowSparseFn.apply(self, inputs, self._anchor, *self.non_table_parameters())
             else:
                 fo, fe, _, _ = self._launch_forward(inputs, B)
-            return fo, fe, fe.view(B, -1)
+            return fo, fe, fe.view(B, fe.shape[1] * fe.shape[2])
         params = list(self.parameters())
         if torch.is_grad_enabled() and any(p.requires_grad for p in params):
             outs = _DenseGradFn.apply(self, inputs, *params)
@@ -329,7 +329,7 @@ class FeatureEmbedding(nn.Module):
             fo, fe, flat, _ = self._launch_forward(inputs, B)
             outs = (fo, fe) if flat is None else (fo, fe, flat)
         if len(outs) == 2:            # uniform plan: flat_embeddings is the same bytes reshaped
-            return outs[0], outs[1], outs[1].view(B, -1)
+            return outs[0], outs[1], outs[1].view(B, outs[1].shape[1] * outs[1].shape[2])
         return outs
 
 

@@ -137,5 +137,6 @@ def test_fm_odd_shapes(shape):
     t = torch.from_numpy(x).cuda().requires_grad_()
     out = FMInteraction()(t)
     (out * torch.from_numpy(g).cuda()).sum().backward()
-    assert_close(npy(out), O.fm_forward(x), what="fm")
-    assert_close(npy(t.grad), O.fm_backward(x, g), what="fm bwd")
+    # a single field gives exactly 0 in exact arithmetic: absolute floor for that case
+    assert_close(npy(out), O.fm_forward(x), what="fm", floor=1e-6)
+    assert_close(npy(t.grad), O.fm_backward(x, g), what="fm bwd", floor=1e-6)
