@@ -58,9 +58,13 @@ SIGNATURES = {
     "dfm_embedding_backward_dense_fields": (_I, [_P, C.POINTER(_P), _L, _P, _P, _P, C.POINTER(FieldGrad), _P]),
     "dfm_rowplan_build": (_I, [C.POINTER(_P), C.POINTER(C.c_int32), _I, _L, _P, _P, _P, _P, _P, _P]),
     "dfm_rowgrad_build": (_I, [C.POINTER(C.c_int32), _I, _I, _I, _L, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "dfm_rowadam_merge": (_I, [C.POINTER(Table), _I, _I, _I, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P]),
-    "dfm_rowadam_workspace_bytes": (_SZ, [_I, _I]),
+    "dfm_rowadam_num_partials": (_L, [_I, _I, _I]),
+    "dfm_rowadam_merge": (_I, [C.POINTER(Table), _I, _I, _I, _P, _P, _P, _P, _P, _F, _F, _P, _P]),
     "dfm_rowadam_apply": (_I, [C.POINTER(Table), _I, _I, _I, _P, _P, _P, _P, _P, _P, _F, _F, _F, _F, _P, _P]),
+    "dfm_dense_num_partials": (_L, [_L]),
+    "dfm_dense_grad_prepare": (_I, [_P, _P, _L, _L, _F, _P, _P]),
+    "dfm_grad_norm_finalize": (_I, [_P, _L, _F, _P, _P, _P]),
+    "dfm_dense_adam": (_I, [_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _P, _P]),
     "dfm_fm_forward": (_I, [_P, _L, _I, _I, _P, _P]),
     "dfm_fm_backward": (_I, [_P, _P, _L, _I, _I, _P, _P]),
 }

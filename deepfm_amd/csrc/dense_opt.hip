@@ -1,0 +1,117 @@
+// Dense-parameter tail of the training step on ONE flat fp32 buffer (DENSE-field Linears,
+// DNN, heads, CIN, attention weights): L2 term, global gradient norm, clip and Adam —
+// reference trainer.py:224-237 (get_l2_reg_loss base.py:78-83, clip_grad_norm_, Adam).
+//   prepare : g[i] += 2*l2*p[i] for i < n_l2 (the embedding parameters);  partial |g|^2
+//   finalize: total = sum(partials) in fixed order;  clip = min(1, max_norm/(sqrt(total)+1e-6))
+//   adam    : torch.optim.Adam update with g*clip
+#include "common.h"
+
+using namespace dfm;
+
+namespace {
+constexpr int kPrepBlock = 256;
+constexpr int kPrepPerThread = 16;  // elements per thread (4 x float4)
+inline int64_t prep_blocks(int64_t n) {
+  const int64_t per_block = static_cast<int64_t>(kPrepBlock) * kPrepPerThread;
+  return (n + per_block - 1) / per_block;
+}
+}  // namespace
+
+__global__ __launch_bounds__(kPrepBlock) void dense_prepare_kernel(
+    float* __restrict__ g, const float* __restrict__ p, int64_t n, int64_t n_l2, float l2,
+    float* __restrict__ partial) {
+  const int64_t base = (static_cast<int64_t>(blockIdx.x) * kPrepBlock + threadIdx.x) * kPrepPerThread;
+  float sq = 0.f;
+  const float k = 2.f * l2;
+#pragma unroll 4
+  for (int j = 0; j < kPrepPerThread; ++j) {
+    const int64_t i = base + j;
+    if (i < n) {
+      float gi = g[i];
+      if (i < n_l2) { gi = fmaf(k, p[i], gi); g[i] = gi; }
+      sq = fmaf(gi, gi, sq);
+    }
+  }
+  __shared__ float wsum[kPrepBlock / kWave];
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) sq += __shfl_xor(sq, m, kWave);
+  if (lane_id() == 0) wsum[threadIdx.x >> 6] = sq;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+}
+
+__global__ __launch_bounds__(1024) void norm_finalize_kernel(const float* __restrict__ partial, int n,
+                                                             float max_norm, float* __restrict__ sq_out,
+                                                             float* __restrict__ clip_out) {
+  __shared__ float wsum[16];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n; i += 1024) acc += partial[i];
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, kWave);
+  if (lane_id() == 0) wsum[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float tot = 0.f;
+    for (int i = 0; i < 16; ++i) tot += wsum[i];
+    sq_out[0] = tot;
+    if (clip_out) {
+      float c = 1.f;
+      if (max_norm > 0.f) c = fminf(1.f, max_norm / (sqrtf(tot) + 1e-6f));
+      clip_out[0] = c;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void dense_adam_kernel(float* __restrict__ p, float* __restrict__ m,
+                                                         float* __restrict__ v, const float* __restrict__ g,
+                                                         int64_t n, const float* __restrict__ clip_coef,
+                                                         float lr, float b1, float b2, float eps,
+                                                         const int32_t* __restrict__ step_ptr) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float clip = clip_coef ? clip_coef[0] : 1.f;
+  const float step = static_cast<float>(step_ptr[0]);
+  const float step_size = lr / (1.f - powf(b1, step));
+  const float inv_bc2_sqrt = 1.f / sqrtf(1.f - powf(b2, step));
+  const float gi = g[i] * clip;
+  const float mi = fmaf(b1, m[i], (1.f - b1) * gi);
+  const float vi = fmaf(b2, v[i], (1.f - b2) * gi * gi);
+  m[i] = mi;
+  v[i] = vi;
+  p[i] -= step_size * (mi / (sqrtf(vi) * inv_bc2_sqrt + eps));
+}
+
+extern "C" int64_t dfm_dense_num_partials(int64_t n) { return n > 0 ? prep_blocks(n) : 0; }
+
+extern "C" int dfm_dense_grad_prepare(float* d_g, const float* d_p, int64_t n, int64_t n_l2, float l2,
+                                      float* d_partials, dfm_stream_t stream) {
+  DFM_REQUIRE(n >= 0 && n_l2 >= 0 && n_l2 <= n, "bad sizes");
+  if (n == 0) return DFM_OK;
+  DFM_REQUIRE(d_g && d_p && d_partials, "null argument");
+  hipLaunchKernelGGL(dense_prepare_kernel, dim3(static_cast<unsigned>(prep_blocks(n))), dim3(kPrepBlock), 0,
+                     as_stream(stream), d_g, d_p, n, n_l2, l2, d_partials);
+  DFM_LAUNCH_CHECK();
+  return DFM_OK;
+}
+
+extern "C" int dfm_grad_norm_finalize(const float* d_partials, int64_t num_partials, float max_norm,
+                                      float* d_sq_norm, float* d_clip_coef, dfm_stream_t stream) {
+  DFM_REQUIRE(d_partials && d_sq_norm, "null argument");
+  DFM_REQUIRE(num_partials >= 0 && num_partials < (int64_t(1) << 31), "bad partial count");
+  hipLaunchKernelGGL(norm_finalize_kernel, dim3(1), dim3(1024), 0, as_stream(stream), d_partials,
+                     static_cast<int>(num_partials), max_norm, d_sq_norm, d_clip_coef);
+  DFM_LAUNCH_CHECK();
+  return DFM_OK;
+}
+
+extern "C" int dfm_dense_adam(float* d_p, float* d_m, float* d_v, const float* d_g, int64_t n,
+                              const float* d_clip_coef, float lr, float beta1, float beta2, float eps,
+                              const int32_t* d_step, dfm_stream_t stream) {
+  DFM_REQUIRE(n >= 0, "bad size");
+  if (n == 0) return DFM_OK;
+  DFM_REQUIRE(d_p && d_m && d_v && d_g && d_step, "null argument");
+  hipLaunchKernelGGL(dense_adam_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0,
+                     as_stream(stream), d_p, d_m, d_v, d_g, n, d_clip_coef, lr, beta1, beta2, eps, d_step);
+  DFM_LAUNCH_CHECK();
+  return DFM_OK;
+}

@@ -13,6 +13,7 @@
 //     per (sample, field).  Correctness path for MovieLens-shaped schemas.
 #include "common.h"
 
+#include <cstdlib>
 #include <vector>
 
 using namespace dfm;
@@ -34,15 +35,39 @@ struct dfm_embedding_plan {
 // ======================================================================================
 // uniform fused gather
 // ======================================================================================
-template <int D, int W>
+// Per-call slot tables travel BY VALUE in the kernel-argument segment: a wave's slot index
+// depends only on its wave id, so the slot (pointers + vocab) is one scalar load issued at
+// kernel entry — the dependent chain is kernarg -> ids -> rows, nothing else.
+struct SparseSlot {
+  const int64_t* ids;
+  const float* w2;
+  const float* w1;
+  int32_t vocab;
+  int32_t field;
+};
+struct DenseSlot {
+  const float* x;
+  const float* w2;
+  const float* b2;
+  const float* w1;
+  const float* b1;
+  int32_t field;
+  int32_t pad;
+};
+constexpr int kMaxSparseSlots = 64, kMaxDenseSlots = 32;
+struct UniformArgs {
+  SparseSlot sp[kMaxSparseSlots];
+  DenseSlot de[kMaxDenseSlots];
+};
+
+template <int D, int W, bool HAS_SPARSE, bool HAS_DENSE>
 __global__ __launch_bounds__(W * 64) void emb_fwd_uniform(
-    const dfm_field* __restrict__ fields, const int32_t* __restrict__ sparse_list, int ns,
-    const int32_t* __restrict__ dense_list, int nd, PtrTable in, int64_t B, int F,
-    float* __restrict__ first_order, float* __restrict__ fe, float* __restrict__ fm_out,
-    int32_t* error_flag) {
+    UniformArgs args, int ns, int nd, int64_t B, int F, float* __restrict__ first_order,
+    float* __restrict__ fe, float* __restrict__ fm_out, int32_t* error_flag) {
   constexpr int LPR = D / 4;        // lanes per row (16 B each)
   constexpr int SPW = kWave / LPR;  // samples per wave == samples per block
-  constexpr int U = 4;              // fields in flight per wave
+  constexpr int US = HAS_SPARSE ? 4 : 0;  // sparse slots in flight per wave
+  constexpr int UD = HAS_DENSE ? 2 : 0;   // dense slots in flight per wave
   const int lane = lane_id();
   const int wave = wave_id_uniform();
   const int s = lane / LPR, q = lane % LPR;
@@ -53,62 +78,87 @@ __global__ __launch_bounds__(W * 64) void emb_fwd_uniform(
   float4 S = make_float4(0.f, 0.f, 0.f, 0.f);   // sum_f e
   float4 SQ = make_float4(0.f, 0.f, 0.f, 0.f);  // sum_f e^2
   float fo = 0.f;
+  bool bad = false;
 
-  // ---- SPARSE fields: id line -> row gather -------------------------------------------
-  for (int i0 = wave; i0 < ns; i0 += W * U) {
-    int f[U];
-    bool ok[U];
-    int64_t id[U];
+  // One straight-line block per iteration: every slot, then every id / dense value, then
+  // every row, then the arithmetic, and only then the (predicated) stores — so no branch
+  // sits between a load and its first use and the waits stay counted, not vmcnt(0).
+  // Slots past the end are clamped to slot 0 (a duplicate, cache-hitting load) and masked.
+  const int sp_iters = HAS_SPARSE ? (ns + W * 4 - 1) / (W * 4) : 0;
+  const int de_iters = HAS_DENSE ? (nd + W * 2 - 1) / (W * 2) : 0;
+  const int iters = sp_iters > de_iters ? sp_iters : de_iters;
+  for (int it = 0; it < iters; ++it) {
+    bool oks[US + 1], okd[UD + 1];
+    SparseSlot sl[US + 1];
+    DenseSlot dl[UD + 1];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int i = i0 + u * W;
-      ok[u] = i < ns;
-      f[u] = sparse_list[ok[u] ? i : ns - 1];
-      id[u] = static_cast<const int64_t*>(in.p[f[u]])[bc];
-    }
-    float4 row[U];
-    float w1v[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const dfm_field& fd = fields[f[u]];
-      id[u] = checked_id(id[u], fd.vocab, error_flag);
-      row[u] = ld4(fd.w2 + id[u] * D + q * 4);
-      w1v[u] = (q == 0) ? fd.w1[id[u]] : 0.f;
+    for (int u = 0; u < US; ++u) {
+      const int i = wave + (it * US + u) * W;
+      oks[u] = i < ns;
+      sl[u] = args.sp[oks[u] ? i : 0];
     }
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (ok[u]) {
-        const float4 e = row[u];
-        if (live) st4(fe + (b * F + f[u]) * D + q * 4, e);
-        S.x += e.x; S.y += e.y; S.z += e.z; S.w += e.w;
-        SQ.x = fmaf(e.x, e.x, SQ.x); SQ.y = fmaf(e.y, e.y, SQ.y);
-        SQ.z = fmaf(e.z, e.z, SQ.z); SQ.w = fmaf(e.w, e.w, SQ.w);
-        fo += w1v[u];
-      }
+    for (int u = 0; u < UD; ++u) {
+      const int i = wave + (it * UD + u) * W;
+      okd[u] = i < nd;
+      dl[u] = args.de[okd[u] ? i : 0];
     }
+    int64_t id[US + 1];
+    float x[UD + 1];
+#pragma unroll
+    for (int u = 0; u < US; ++u) id[u] = sl[u].ids[bc];
+#pragma unroll
+    for (int u = 0; u < UD; ++u) x[u] = dl[u].x[bc];
+    float4 dw[UD + 1], db[UD + 1];
+    float dw1[UD + 1], db1[UD + 1];
+#pragma unroll
+    for (int u = 0; u < UD; ++u) {
+      dw[u] = ld4(dl[u].w2 + q * 4);
+      db[u] = ld4(dl[u].b2 + q * 4);
+      dw1[u] = dl[u].w1[0];
+      db1[u] = dl[u].b1[0];
+    }
+    float4 row[US + 1];
+    float w1v[US + 1];
+#pragma unroll
+    for (int u = 0; u < US; ++u) {
+      const bool oob = static_cast<uint64_t>(id[u]) >= static_cast<uint64_t>(sl[u].vocab);
+      bad |= oob && oks[u];
+      id[u] = oob ? 0 : id[u];
+      row[u] = ld4(sl[u].w2 + id[u] * D + q * 4);
+      w1v[u] = sl[u].w1[id[u]];              // same address on the row's lanes: one request
+    }
+    float4 ed[UD + 1];
+#pragma unroll
+    for (int u = 0; u < UD; ++u) {
+      const float m = okd[u] ? 1.f : 0.f;
+      float4 e;
+      e.x = fmaf(x[u], dw[u].x, db[u].x); e.y = fmaf(x[u], dw[u].y, db[u].y);
+      e.z = fmaf(x[u], dw[u].z, db[u].z); e.w = fmaf(x[u], dw[u].w, db[u].w);
+      ed[u] = e;
+      S.x = fmaf(m, e.x, S.x); S.y = fmaf(m, e.y, S.y); S.z = fmaf(m, e.z, S.z); S.w = fmaf(m, e.w, S.w);
+      SQ.x = fmaf(m * e.x, e.x, SQ.x); SQ.y = fmaf(m * e.y, e.y, SQ.y);
+      SQ.z = fmaf(m * e.z, e.z, SQ.z); SQ.w = fmaf(m * e.w, e.w, SQ.w);
+      fo = fmaf(m, fmaf(x[u], dw1[u], db1[u]), fo);
+    }
+#pragma unroll
+    for (int u = 0; u < US; ++u) {
+      const float m = oks[u] ? 1.f : 0.f;
+      const float4 e = row[u];
+      S.x = fmaf(m, e.x, S.x); S.y = fmaf(m, e.y, S.y); S.z = fmaf(m, e.z, S.z); S.w = fmaf(m, e.w, S.w);
+      SQ.x = fmaf(m * e.x, e.x, SQ.x); SQ.y = fmaf(m * e.y, e.y, SQ.y);
+      SQ.z = fmaf(m * e.z, e.z, SQ.z); SQ.w = fmaf(m * e.w, e.w, SQ.w);
+      fo = fmaf(m, w1v[u], fo);
+    }
+#pragma unroll
+    for (int u = 0; u < UD; ++u)
+      if (live && okd[u]) st4(fe + (b * F + dl[u].field) * D + q * 4, ed[u]);
+#pragma unroll
+    for (int u = 0; u < US; ++u)
+      if (live && oks[u]) st4(fe + (b * F + sl[u].field) * D + q * 4, row[u]);
   }
-  // ---- DENSE fields: x * W + b  (Linear(1,D), Linear(1,1)) ------------------------------
-  for (int i0 = wave; i0 < nd; i0 += W * U) {
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int i = i0 + u * W;
-      if (i < nd) {
-        const int f = dense_list[i];
-        const dfm_field& fd = fields[f];
-        const float x = static_cast<const float*>(in.p[f])[bc];
-        const float4 w = ld4(fd.w2 + q * 4);
-        const float4 bb = ld4(fd.b2 + q * 4);
-        float4 e;
-        e.x = fmaf(x, w.x, bb.x); e.y = fmaf(x, w.y, bb.y);
-        e.z = fmaf(x, w.z, bb.z); e.w = fmaf(x, w.w, bb.w);
-        if (live) st4(fe + (b * F + f) * D + q * 4, e);
-        S.x += e.x; S.y += e.y; S.z += e.z; S.w += e.w;
-        SQ.x = fmaf(e.x, e.x, SQ.x); SQ.y = fmaf(e.y, e.y, SQ.y);
-        SQ.z = fmaf(e.z, e.z, SQ.z); SQ.w = fmaf(e.w, e.w, SQ.w);
-        if (q == 0) fo += fmaf(x, fd.w1[0], fd.b1[0]);
-      }
-    }
-  }
+  if (bad && error_flag) atomicOr(error_flag, 1);
+  if (q != 0) fo = 0.f;  // every lane of a row loaded the same first-order value: count it once
   // ---- fixed-order reduction over the block's waves --------------------------------------
   __shared__ float red[W][9][kWave];
   red[wave][0][lane] = S.x;  red[wave][1][lane] = S.y;  red[wave][2][lane] = S.z;
@@ -380,6 +430,7 @@ extern "C" int dfm_embedding_plan_create(const dfm_field* fields, int num_fields
     if (fd.kind == DFM_SEQUENCE || fd.proj || fd.dim != fm_dim) uniform = false;
   }
   plan->total_dim = off;
+  if (plan->h_sparse.size() > (size_t)kMaxSparseSlots || plan->h_dense.size() > (size_t)kMaxDenseSlots) uniform = false;
   plan->uniform = uniform ? 1 : 0;
   auto upload = [](const void* src, size_t bytes, void** dst) -> hipError_t {
     if (bytes == 0) { *dst = nullptr; return hipSuccess; }
@@ -425,16 +476,49 @@ static int fill_ptrs(const dfm_embedding_plan* plan, const void* const* inputs, 
   return DFM_OK;
 }
 
+static int gather_waves() {
+  static int w = [] {
+    const char* e = getenv("DFM_GATHER_WAVES");
+    const int v = e ? atoi(e) : 8;
+    return (v == 4 || v == 8 || v == 16) ? v : 8;
+  }();
+  return w;
+}
+
 template <int D>
 static int launch_uniform(const dfm_embedding_plan* plan, const PtrTable& in, int64_t B,
                           float* fo, float* fe, float* fm_out, int32_t* err, hipStream_t st) {
-  constexpr int W = 8;
   constexpr int SPW = kWave / (D / 4);
-  const int64_t blocks = (B + SPW - 1) / SPW;
-  hipLaunchKernelGGL((emb_fwd_uniform<D, W>), dim3(static_cast<unsigned>(blocks)), dim3(W * 64), 0, st,
-                     plan->d_fields, plan->d_sparse, static_cast<int>(plan->h_sparse.size()),
-                     plan->d_dense, static_cast<int>(plan->h_dense.size()), in, B, plan->num_fields,
-                     fo, fe, fm_out, err);
+  UniformArgs args;
+  const int ns = static_cast<int>(plan->h_sparse.size()), nd = static_cast<int>(plan->h_dense.size());
+  for (int i = 0; i < ns; ++i) {
+    const int f = plan->h_sparse[i];
+    const dfm_field& fd = plan->h_fields[f];
+    args.sp[i] = SparseSlot{static_cast<const int64_t*>(in.p[f]), fd.w2, fd.w1, fd.vocab, f};
+  }
+  for (int i = 0; i < nd; ++i) {
+    const int f = plan->h_dense[i];
+    const dfm_field& fd = plan->h_fields[f];
+    args.de[i] = DenseSlot{static_cast<const float*>(in.p[f]), fd.w2, fd.b2, fd.w1, fd.b1, f, 0};
+  }
+  const dim3 grid(static_cast<unsigned>((B + SPW - 1) / SPW));
+  const int F = plan->num_fields;
+#define DFM_GATHER_LAUNCH(WV, HS, HD)                                                              \
+  hipLaunchKernelGGL((emb_fwd_uniform<D, WV, HS, HD>), grid, dim3(WV * 64), 0, st, args, ns, nd, B, \
+                     F, fo, fe, fm_out, err)
+#define DFM_GATHER_PICK(WV)                                    \
+  do {                                                         \
+    if (ns > 0 && nd > 0) DFM_GATHER_LAUNCH(WV, true, true);   \
+    else if (ns > 0) DFM_GATHER_LAUNCH(WV, true, false);       \
+    else DFM_GATHER_LAUNCH(WV, false, true);                   \
+  } while (0)
+  switch (gather_waves()) {
+    case 4: DFM_GATHER_PICK(4); break;
+    case 16: DFM_GATHER_PICK(16); break;
+    default: DFM_GATHER_PICK(8);
+  }
+#undef DFM_GATHER_PICK
+#undef DFM_GATHER_LAUNCH
   DFM_LAUNCH_CHECK();
   return DFM_OK;
 }
@@ -508,7 +592,7 @@ static int launch_dense_fields(const dfm_embedding_plan* plan, const PtrTable& i
 extern "C" int dfm_embedding_backward_dense(const dfm_embedding_plan* plan, const void* const* inputs,
                                  int64_t batch, const float* d_g_first, const float* d_g_field,
                                  const float* d_g_flat, const dfm_field_grad* grads,
-                                 void* d_workspace, dfm_stream_t stream) {
+                                 const void* d_workspace, dfm_stream_t stream) {
   DFM_REQUIRE(plan && inputs && d_g_first && d_g_field && grads, "null argument");
   DFM_REQUIRE(plan->uniform || d_g_flat, "general plan needs d_g_flat");
   if (batch == 0) return DFM_OK;

@@ -85,22 +85,6 @@ __global__ __launch_bounds__(256) void rowadam_merge_kernel(
   if (threadIdx.x == 0) partial[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
 }
 
-__global__ __launch_bounds__(1024) void reduce_partials(const float* __restrict__ partial, int n,
-                                                        float* __restrict__ out) {
-  __shared__ float wsum[16];
-  float acc = 0.f;
-  for (int i = threadIdx.x; i < n; i += 1024) acc += partial[i];
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, kWave);
-  if (lane_id() == 0) wsum[threadIdx.x >> 6] = acc;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    float tot = 0.f;
-    for (int i = 0; i < 16; ++i) tot += wsum[i];
-    out[0] = tot;
-  }
-}
-
 __device__ __forceinline__ void adam1(float& w, float& m, float& v, float g, float b1, float b2,
                                       float step_size, float inv_bc2_sqrt, float eps) {
   m = fmaf(b1, m, (1.f - b1) * g);
@@ -168,29 +152,26 @@ static inline int64_t merge_blocks(int S, int D, int L) {
 
 extern "C" {
 
-size_t dfm_rowadam_workspace_bytes(int num_sparse, int num_lists) {
-  // one partial per merge block; D/4 <= 64 lanes per row bounds the block count
-  return sizeof(float) * static_cast<size_t>(merge_blocks(num_sparse, 256, num_lists));
+int64_t dfm_rowadam_num_partials(int num_sparse, int dim, int num_lists) {
+  return merge_blocks(num_sparse, dim, num_lists);  // one |g|^2 partial per merge block
 }
 
 int dfm_rowadam_merge(const dfm_table* tables, int num_sparse, int dim, int num_lists,
                       const int32_t* d_uniq_rows, const int32_t* d_num_uniq, float* d_row_g2,
                       float* d_row_g1, int32_t* d_owner_flag, float grad_scale, float l2,
-                      float* d_sq_norm, void* d_workspace, dfm_stream_t stream) {
-  DFM_REQUIRE(tables && d_uniq_rows && d_num_uniq && d_row_g2 && d_row_g1 && d_owner_flag && d_sq_norm &&
-              d_workspace, "null argument");
+                      float* d_partials, dfm_stream_t stream) {
+  DFM_REQUIRE(tables && d_uniq_rows && d_num_uniq && d_row_g2 && d_row_g1 && d_owner_flag && d_partials,
+              "null argument");
   DFM_REQUIRE(num_sparse > 0 && num_sparse <= DFM_MAX_FIELDS && num_lists > 0, "bad sizes");
   DFM_REQUIRE(dim > 0 && dim % 4 == 0 && dim <= 256, "dim must be a multiple of 4 and <= 256");
   TableArgs ta;
   if (int rc = fill_tables(tables, num_sparse, &ta, false)) return rc;
   const int64_t blocks = merge_blocks(num_sparse, dim, num_lists);
   hipStream_t st = as_stream(stream);
-  float* partial = static_cast<float*>(d_workspace);
+  float* partial = d_partials;
   hipLaunchKernelGGL(rowadam_merge_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, st, ta,
                      num_sparse, dim, num_lists, d_uniq_rows, d_num_uniq, d_row_g2, d_row_g1,
                      d_owner_flag, grad_scale, l2, partial);
-  DFM_LAUNCH_CHECK();
-  hipLaunchKernelGGL(reduce_partials, dim3(1), dim3(1024), 0, st, partial, static_cast<int>(blocks), d_sq_norm);
   DFM_LAUNCH_CHECK();
   return DFM_OK;
 }

@@ -9,8 +9,10 @@ tables are updated only on the rows the (global) batch touched:
     clip  = min(1, max_norm / (||all grads|| + 1e-6))            (trainer.py:232-235)
     Adam(w_row, m_row, v_row, clip * g_row)                      (trainer.py:67-70,237)
 
-All other parameters (DENSE-field Linears, DNN, heads, CIN, attention) take a dense
-Adam step through ``torch.optim.Adam(capturable=True)`` on one flat gradient buffer.
+All other parameters (DENSE-field Linears, DNN, heads, CIN, attention) live in ONE flat
+buffer (each ``nn.Parameter`` becomes a view of it) and take a dense Adam step from one
+kernel; the L2 term of the embedding's dense parameters is added to their gradient there
+(``g += 2*l2*p``), so the training loss passed to ``backward`` is the plain BCE.
 This is NOT trajectory-identical to the reference's dense Adam (untouched rows do not
 move); DESIGN.md states the delta.  Everything runs on the current stream with no host
 synchronisation, so a whole step can be captured in a HIP graph.
@@ -60,20 +62,30 @@ class RowSparseAdam:
         self.sq_norm = torch.zeros(1, dtype=torch.float32, device=dev)
         self.clip_coef = torch.ones(1, dtype=torch.float32, device=dev)
 
-        # dense parameters: one flat gradient buffer, .grad are views into it
+        # dense parameters: ONE flat parameter buffer and ONE flat gradient buffer; every
+        # parameter / .grad becomes a view (embedding parameters first: they take the L2 term)
         table_ids = {id(p) for p in tables}
-        self.dense_params = [p for p in model.parameters() if id(p) not in table_ids and p.requires_grad]
+        emb_dense = [p for p in emb.non_table_parameters() if p.requires_grad]
+        emb_ids = {id(p) for p in emb_dense}
+        others = [p for p in model.parameters()
+                  if id(p) not in table_ids and id(p) not in emb_ids and p.requires_grad]
+        self.dense_params = emb_dense + others
+        self.n_l2 = sum(p.numel() for p in emb_dense)
         total = sum(p.numel() for p in self.dense_params)
+        self.flat_param = torch.empty(total, dtype=torch.float32, device=dev)
         self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_m = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_v = torch.zeros(total, dtype=torch.float32, device=dev)
         off = 0
         for p in self.dense_params:
-            p.grad = self.flat_grad[off:off + p.numel()].view_as(p)
-            off += p.numel()
-        self.dense_opt = torch.optim.Adam(self.dense_params, lr=lr, betas=betas, eps=eps, capturable=True,
-                                          foreach=True) if self.dense_params else None
+            n = p.numel()
+            self.flat_param[off:off + n].copy_(p.data.reshape(-1))
+            p.data = self.flat_param[off:off + n].view_as(p)
+            p.grad = self.flat_grad[off:off + n].view_as(p)
+            off += n
         self._owner = None
         self._gathered = None
-        self._ws = None
+        self._partials = None
         self._cur = None
 
     # ------------------------------------------------------------------ helpers
@@ -113,35 +125,41 @@ class RowSparseAdam:
 
     @torch.no_grad()
     def apply(self) -> None:
-        """Merge lists, clip, row-wise Adam on the tables, dense Adam on everything else."""
+        """Merge lists, L2 + global norm + clip, row-wise Adam on the tables, Adam on the flat
+        dense buffer: five kernel launches, no host synchronisation."""
         lib = _lib.load()
         stream = _lib.stream_handle()
         grad_scale = 1.0 / self.world
         uniq, num, g2, g1, lists = self._cur
-        if self.world > 1:
-            self.flat_grad.mul_(grad_scale)          # mean over ranks (loss is a per-rank mean)
+        n_dense = self.flat_param.numel()
+        np_sparse = lib.dfm_rowadam_num_partials(self.num_sparse, self.dim, lists)
+        np_dense = lib.dfm_dense_num_partials(n_dense)
         if self._owner is None or self._owner.shape != uniq.shape:
             self._owner = torch.empty_like(uniq)
-            self._ws = torch.empty(lib.dfm_rowadam_workspace_bytes(self.num_sparse, lists) // 4,
-                                   dtype=torch.float32, device=self.device)
+            self._partials = torch.zeros(np_sparse + np_dense, dtype=torch.float32, device=self.device)
+        if self.world > 1:
+            self.flat_grad.mul_(grad_scale)          # mean over ranks (loss is a per-rank mean)
         tabs = self._table_struct()
         self.step_count.add_(1)
         _lib.check(lib.dfm_rowadam_merge(tabs, self.num_sparse, self.dim, lists, uniq.data_ptr(),
                                          num.data_ptr(), g2.data_ptr(), g1.data_ptr(),
                                          self._owner.data_ptr(), grad_scale, self.l2,
-                                         self.sq_norm.data_ptr(), self._ws.data_ptr(), stream))
-        clip_ptr = None
-        if self.max_grad_norm is not None:
-            total_sq = self.sq_norm + self.flat_grad.pow(2).sum()
-            torch.clamp(self.max_grad_norm / (total_sq.sqrt() + 1e-6), max=1.0, out=self.clip_coef)
-            self.flat_grad.mul_(self.clip_coef)
-            clip_ptr = self.clip_coef.data_ptr()
+                                         self._partials.data_ptr(), stream))
+        _lib.check(lib.dfm_dense_grad_prepare(self.flat_grad.data_ptr(), self.flat_param.data_ptr(), n_dense,
+                                              self.n_l2, self.l2,
+                                              self._partials.data_ptr() + 4 * np_sparse, stream))
+        _lib.check(lib.dfm_grad_norm_finalize(self._partials.data_ptr(), np_sparse + np_dense,
+                                              self.max_grad_norm or 0.0, self.sq_norm.data_ptr(),
+                                              self.clip_coef.data_ptr(), stream))
         _lib.check(lib.dfm_rowadam_apply(tabs, self.num_sparse, self.dim, lists, uniq.data_ptr(),
                                          num.data_ptr(), g2.data_ptr(), g1.data_ptr(),
-                                         self._owner.data_ptr(), clip_ptr, self.lr, self.betas[0],
-                                         self.betas[1], self.eps, self.step_count.data_ptr(), stream))
-        if self.dense_opt is not None:
-            self.dense_opt.step()
+                                         self._owner.data_ptr(), self.clip_coef.data_ptr(), self.lr,
+                                         self.betas[0], self.betas[1], self.eps,
+                                         self.step_count.data_ptr(), stream))
+        _lib.check(lib.dfm_dense_adam(self.flat_param.data_ptr(), self.flat_m.data_ptr(),
+                                      self.flat_v.data_ptr(), self.flat_grad.data_ptr(), n_dense,
+                                      self.clip_coef.data_ptr(), self.lr, self.betas[0], self.betas[1],
+                                      self.eps, self.step_count.data_ptr(), stream))
         self.emb.rowsparse.has_grad = False
 
     def step(self) -> None:

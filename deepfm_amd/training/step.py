@@ -6,7 +6,7 @@ tables in row-sparse mode (``RowSparseAdam``).  Layout of one step on the stream
 
     [eager]  fused embedding gather (``dfm_embedding_forward``)  <- optionally bracketed by
              HIP events so bench.py can time exactly this kernel in the timed region
-    [graph A] row plan, interaction layers + DNN forward, loss, backward, row gradients
+    [graph A] row plan (side stream), interaction layers + DNN forward, loss, backward, row gradients
     [eager]  data-parallel exchange (RCCL all-reduce / all-gather), world_size > 1 only
     [graph B] merge + clip + row-wise Adam + dense Adam
 
@@ -25,8 +25,7 @@ from deepfm_amd.training.rowsparse import RowSparseAdam
 
 
 class RowSparseTrainStep:
-    def __init__(self, model, optimizer: RowSparseAdam, batch_size: int, use_graph: bool = True,
-                 add_l2_term: bool = True) -> None:
+    def __init__(self, model, optimizer: RowSparseAdam, batch_size: int, use_graph: bool = True) -> None:
         self.model, self.opt, self.B = model, optimizer, batch_size
         self.emb = model.embedding
         if self.emb.grad_mode != "rowsparse":
@@ -50,8 +49,8 @@ class RowSparseTrainStep:
         self.fo = torch.empty(batch_size, 1, dtype=torch.float32, device=dev)
         self.fe = torch.empty(batch_size, F, D, dtype=torch.float32, device=dev)
         self.loss = torch.zeros((), dtype=torch.float32, device=dev)
-        self.add_l2_term = add_l2_term
         self.use_graph = use_graph
+        self.side = torch.cuda.Stream(device=dev)   # row plan (needs only the ids) overlaps fwd/bwd
         self.graph_a: Optional[torch.cuda.CUDAGraph] = None
         self.graph_b: Optional[torch.cuda.CUDAGraph] = None
         self.dense_grads = {id(p): p.grad for p in self.emb.non_table_parameters() if p.grad is not None}
@@ -71,15 +70,18 @@ class RowSparseTrainStep:
 
     def _body_a(self) -> None:
         self.opt.zero_grad()
-        self.emb.build_rowplan(self.inputs, self.B)
+        cur = torch.cuda.current_stream()
+        self.side.wait_stream(cur)
+        with torch.cuda.stream(self.side):
+            self.emb.build_rowplan(self.inputs, self.B)
         fo = self.fo.detach().requires_grad_()
         fe = self.fe.detach().requires_grad_()
         logits = self.model._forward_components(fo, fe, fe.view(self.B, -1))
+        # plain BCE: the L2 term (base.py:78-83) is applied as g += 2*l2*p by the optimizer
         loss = Fnn.binary_cross_entropy_with_logits(logits.view(-1), self.labels)
-        if self.add_l2_term:
-            loss = loss + self.model.get_l2_reg_loss()
         loss.backward()
         self.loss.copy_(loss.detach())
+        cur.wait_stream(self.side)
         self.emb.backward_rowsparse(self.inputs, fo.grad, fe.grad, self.dense_grads)
 
     def _body_b(self) -> None:

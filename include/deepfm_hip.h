@@ -104,11 +104,12 @@ int dfm_embedding_forward(const dfm_embedding_plan* plan, const void* const* inp
  * semantics (nn.Embedding(sparse=False), embedding.py:35-40).  Gradients are ADDED
  * into the buffers of `grads` (caller zero-fills them); row 0 receives none.
  * d_g_flat may be NULL for a uniform plan whose flat view aliases field_emb (the
- * caller has already summed both into d_g_field). */
+ * caller has already summed both into d_g_field).  d_flat_saved: the forward's
+ * flat_embeddings, needed only when the plan has projections (else NULL). */
 int dfm_embedding_backward_dense(const dfm_embedding_plan* plan, const void* const* inputs,
                                  int64_t batch, const float* d_g_first, const float* d_g_field,
                                  const float* d_g_flat, const dfm_field_grad* grads,
-                                 void* d_workspace, dfm_stream_t stream);
+                                 const void* d_flat_saved, dfm_stream_t stream);
 
 /* Gradients of the DENSE fields' Linear parameters only (deterministic tree
  * reduction over the batch); used by the row-sparse mode together with
@@ -149,20 +150,39 @@ int dfm_rowgrad_build(const int32_t* field_of_sparse, int num_sparse, int num_fi
  * adds the other lists' gradients in list order (bit-identical on every replica),
  * then:  g = grad_scale * sum + 2*l2*w ;  g *= clip ;  Adam(w, m, v, g)
  * (reference trainer.py:224-237 restricted to the rows the batch touched — DESIGN.md).
- * Pass A (dfm_rowadam_merge) writes the merged gradients in place and the squared
- * norm of g into d_sq_norm[0]; pass B (dfm_rowadam_apply) reads *d_clip_coef. */
+ * Pass A (dfm_rowadam_merge) writes the merged gradients in place and one partial sum of
+ * |g|^2 per block into d_partials[0 .. dfm_rowadam_num_partials); pass B
+ * (dfm_rowadam_apply) reads *d_clip_coef (NULL = 1). */
 typedef struct dfm_table { float* w2; float* m2; float* v2; float* w1; float* m1; float* v1; } dfm_table;
 
+int64_t dfm_rowadam_num_partials(int num_sparse, int dim, int num_lists);
 int dfm_rowadam_merge(const dfm_table* tables, int num_sparse, int dim, int num_lists,
                       const int32_t* d_uniq_rows, const int32_t* d_num_uniq, float* d_row_g2,
                       float* d_row_g1, int32_t* d_owner_flag, float grad_scale, float l2,
-                      float* d_sq_norm, void* d_workspace, dfm_stream_t stream);
-size_t dfm_rowadam_workspace_bytes(int num_sparse, int num_lists);
+                      float* d_partials, dfm_stream_t stream);
 int dfm_rowadam_apply(const dfm_table* tables, int num_sparse, int dim, int num_lists,
                       const int32_t* d_uniq_rows, const int32_t* d_num_uniq, const float* d_row_g2,
                       const float* d_row_g1, const int32_t* d_owner_flag, const float* d_clip_coef,
                       float lr, float beta1, float beta2, float eps, const int32_t* d_step,
                       dfm_stream_t stream);
+
+/* ---------------------------------------------------------------------------------
+ * Dense parameters on one flat fp32 buffer: L2 term, gradient norm, clip, Adam
+ * (reference base.py:78-83, trainer.py:224-237)
+ * ------------------------------------------------------------------------------- */
+/* g[i] += 2*l2*p[i] for i < n_l2 (the embedding parameters come first in the buffer);
+ * one partial sum of |g|^2 per block into d_partials[0 .. dfm_dense_num_partials(n)). */
+int64_t dfm_dense_num_partials(int64_t n);
+int dfm_dense_grad_prepare(float* d_g, const float* d_p, int64_t n, int64_t n_l2, float l2,
+                           float* d_partials, dfm_stream_t stream);
+/* *d_sq_norm = sum(partials) in a fixed order; *d_clip_coef = min(1, max_norm/(sqrt+1e-6))
+ * (clip_grad_norm_, trainer.py:232-235; max_norm <= 0 disables clipping: coef 1). */
+int dfm_grad_norm_finalize(const float* d_partials, int64_t num_partials, float max_norm,
+                           float* d_sq_norm, float* d_clip_coef, dfm_stream_t stream);
+/* torch.optim.Adam (trainer.py:67-70) on flat buffers with g scaled by *d_clip_coef. */
+int dfm_dense_adam(float* d_p, float* d_m, float* d_v, const float* d_g, int64_t n,
+                   const float* d_clip_coef, float lr, float beta1, float beta2, float eps,
+                   const int32_t* d_step, dfm_stream_t stream);
 
 /* ---------------------------------------------------------------------------------
  * FMInteraction  (reference deepfm/models/layers/fm.py:18-23)
