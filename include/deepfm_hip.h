@@ -193,6 +193,51 @@ int dfm_fm_forward(const float* d_field_emb, int64_t batch, int num_fields, int 
 int dfm_fm_backward(const float* d_field_emb, const float* d_g_out, int64_t batch, int num_fields,
                     int dim, float* d_g_field, dfm_stream_t stream);
 
+/* ---------------------------------------------------------------------------------
+ * CIN  (reference deepfm/models/layers/cin.py:26-105)
+ *   per layer i:  Z[b,h*F+f,d] = hidden_i[b,h,d] * x0[b,f,d]          (cin.py:84-87, never stored)
+ *                 Y_i = relu(W_i Z + bias_i)  (B, C_i, D)              (cin.py:90-91)
+ *                 split [direct | next] along channels, direct first   (cin.py:93-96)
+ *                 out[:, col_i : col_i+direct_i] = sum_d Y_i[:, :direct_i, :]  (cin.py:102-105)
+ *   weights[i] = conv_layers.<i>.weight (C_i, H_i*F[, 1]),  biases[i] = conv_layers.<i>.bias (C_i)
+ *   layer_sizes / split_half as in CIN.__init__ (cin.py:41-64).
+ * d_saved receives the post-ReLU Y_i of every layer (dfm_cin_saved_bytes) for the backward.
+ * ------------------------------------------------------------------------------- */
+int dfm_cin_output_dim(const int32_t* layer_sizes, int num_layers, int split_half);
+size_t dfm_cin_saved_bytes(const int32_t* layer_sizes, int num_layers, int split_half, int64_t batch,
+                           int num_fields, int dim);
+size_t dfm_cin_backward_workspace_bytes(const int32_t* layer_sizes, int num_layers, int split_half,
+                                        int64_t batch, int num_fields, int dim);
+int dfm_cin_forward(const float* d_x0, int64_t batch, int num_fields, int dim,
+                    const float* const* weights, const float* const* biases,
+                    const int32_t* layer_sizes, int num_layers, int split_half, float* d_out,
+                    float* d_saved, dfm_stream_t stream);
+/* d_g_x0 (B,F,D) is overwritten; weight / bias gradients are ADDED into g_weights[i] / g_biases[i]. */
+int dfm_cin_backward(const float* d_x0, int64_t batch, int num_fields, int dim,
+                     const float* const* weights, const int32_t* layer_sizes, int num_layers,
+                     int split_half, const float* d_saved, const float* d_g_out, float* d_g_x0,
+                     float* const* g_weights, float* const* g_biases, void* d_workspace,
+                     dfm_stream_t stream);
+
+/* ---------------------------------------------------------------------------------
+ * Field self-attention block  (reference deepfm/models/layers/attention.py:67-120)
+ *   one _AttentionBlock per call; MultiHeadSelfAttention.forward (attention.py:52-64) calls it
+ *   once per layer.  params[] (device pointers), PyTorch layouts:
+ *     0 W_q.weight (A,D) 1 W_q.bias (A) 2 W_k.weight 3 W_k.bias 4 W_v.weight 5 W_v.bias
+ *     6 W_out.weight (D,A) 7 W_out.bias (D) 8 layer_norm.weight (D) 9 layer_norm.bias (D)
+ *   (8, 9 only when use_residual).  x, out, g_out, g_x are (B, F, D).
+ * The backward recomputes the forward per sample; parameter gradients are ADDED into
+ * g_params[] (same order/shapes as params[]); d_g_x is overwritten.
+ * ------------------------------------------------------------------------------- */
+int dfm_attention_forward(const float* d_x, int64_t batch, int num_fields, int embed_dim,
+                          int attention_dim, int num_heads, int use_residual,
+                          const float* const* params, float* d_out, dfm_stream_t stream);
+size_t dfm_attention_backward_workspace_bytes(int64_t batch, int embed_dim, int attention_dim);
+int dfm_attention_backward(const float* d_x, const float* d_g_out, int64_t batch, int num_fields,
+                           int embed_dim, int attention_dim, int num_heads, int use_residual,
+                           const float* const* params, float* d_g_x, float* const* g_params,
+                           void* d_workspace, dfm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

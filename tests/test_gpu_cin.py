@@ -1,0 +1,75 @@
+"""GPU parity: CIN kernels (through the C ABI) against reference golden vectors and the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ctr_oracle as O
+from tests.helpers import assert_close, cin_full_params, group, load, npy
+from tests.test_gpu_models_step import check_model_case
+
+pytestmark = pytest.mark.gpu
+
+CASES = ["cin_small_split", "cin_small_nosplit", "cin_single_layer", "cin_odd_split", "cin_criteo_full"]
+
+
+def _module(g, params):
+    from deepfm_amd.models.layers.cin import CIN
+    F, D = g["x"].shape[1:]
+    cin = CIN(F, D, [int(s) for s in g["layer_sizes"]], bool(g["split_half"]))
+    assert cin.direct_sizes == list(g["direct_sizes"]) and cin.next_sizes == list(g["next_sizes"])
+    assert cin.output_dim == int(g["output_dim"])
+    cin.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+    return cin.cuda()
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_cin_vs_golden(case):
+    g = load(case)
+    params = cin_full_params() if bool(g["hashed"]) else group(g, "param/")
+    cin = _module(g, params)
+    x = torch.from_numpy(g["x"]).cuda().requires_grad_()
+    out = cin(x)
+    assert out.shape == g["out"].shape
+    assert_close(npy(out), g["out"], what="cin out")
+    (out * torch.from_numpy(g["upstream"]).cuda()).sum().backward()
+    assert_close(npy(x.grad), g["d_x"], what="cin d_x")
+    for k, p in cin.named_parameters():
+        assert p.grad is not None, k
+        if bool(g["hashed"]):
+            want = g["grad_sample/" + k]
+            got = npy(p.grad).reshape(-1)
+            got = got[::97] if k.endswith("weight") else got
+        else:
+            want, got = g["grad/" + k], npy(p.grad)
+        assert_close(got, want, what=k)
+
+
+def test_cin_reference_shape_tests():
+    """tests/test_layers.py:143-168"""
+    from deepfm_amd.models.layers.cin import CIN
+    x = torch.randn(4, 3, 16, device="cuda")
+    assert CIN(3, 16, [64, 64], split_half=False).cuda()(x).shape == (4, 128)
+    split = CIN(3, 16, [64, 64], split_half=True).cuda()
+    assert split.output_dim == 32 + 64 and split(x).shape == (4, 96)
+
+
+def test_cin_cfg3_batch_vs_oracle():
+    """BASELINE.json config 3 layer sizes at a batch the oracle finishes in seconds."""
+    rng = np.random.default_rng(7)
+    params = cin_full_params()
+    g = load("cin_criteo_full")
+    cin = _module(g, params)
+    x = (rng.standard_normal((192, 39, 16)) * 0.7).astype(np.float32)
+    up = rng.standard_normal((192, 256)).astype(np.float32)
+    t = torch.from_numpy(x).cuda().requires_grad_()
+    out = cin(t)
+    (out * torch.from_numpy(up).cuda()).sum().backward()
+    assert_close(npy(out), O.cin_forward(x, params, [128, 128, 128], True), what="out")
+    d_x, grads = O.cin_backward(x, params, [128, 128, 128], True, up)
+    assert_close(npy(t.grad), d_x, what="d_x")
+    for k, p in cin.named_parameters():
+        assert_close(npy(p.grad), grads[k], what=k)
+
+
+def test_xdeepfm_vs_golden():
+    check_model_case("model_xdeepfm")

@@ -56,7 +56,10 @@ def check_model_case(case):
     for k, prm in model.named_parameters():
         assert prm.grad is not None, k
         pre_bn_bias = k.startswith("dnn.mlp.") and k.endswith(".bias") and int(k.split(".")[2]) % 4 == 0
-        floor = 1e-6 if pre_bn_bias else (2e-6 if k.endswith("W_k.bias") else 0.0)
+        # identically-zero gradients (reference value is rounding noise): a Linear bias in front of
+        # train-mode BatchNorm, the softmax-invariant W_k.bias, and the last LayerNorm bias of the
+        # attention stack (a per-feature constant into Linear -> BatchNorm)
+        floor = 1e-6 if (pre_bn_bias or k.endswith("layer_norm.bias")) else (2e-6 if k.endswith("W_k.bias") else 0.0)
         assert_close(npy(prm.grad), want_g[k], what=k, floor=floor)
     assert float(model.get_l2_reg_loss()) > 0                              # tests/test_models.py:43-46
 
