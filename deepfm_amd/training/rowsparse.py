@@ -31,6 +31,7 @@ import torch
 import torch.distributed as dist
 
 from deepfm_amd import _lib
+from deepfm_amd.training import exchange
 from deepfm_amd.models.layers.embedding import FeatureEmbedding
 
 
@@ -45,7 +46,7 @@ class RowSparseAdam:
         self.lr, self.betas, self.eps, self.l2 = lr, betas, eps, l2
         self.max_grad_norm = max_grad_norm
         self.group = process_group
-        self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        self.world = exchange.world_size(process_group)
 
         tables = emb.table_parameters()
         if not tables:
@@ -111,16 +112,14 @@ class RowSparseAdam:
         rs = self.emb.rowsparse
         if rs is None or not rs.has_grad:
             raise RuntimeError("RowSparseAdam: no row gradients (run a backward pass first)")
+        local = (rs.uniq_rows, rs.num_uniq, rs.row_g2, rs.row_g1)
         if self.world == 1:
-            self._cur = (rs.uniq_rows, rs.num_uniq, rs.row_g2, rs.row_g1, rs.chunks)
+            self._cur = local + (rs.chunks,)
             return
-        dist.all_reduce(self.flat_grad, group=self.group)
+        exchange.allreduce_flat(self.flat_grad, self.group)
         if self._gathered is None or self._gathered[0].shape[0] != self.world * rs.chunks:
-            def like(t):
-                return torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-            self._gathered = tuple(like(t) for t in (rs.uniq_rows, rs.num_uniq, rs.row_g2, rs.row_g1))
-        for out, src in zip(self._gathered, (rs.uniq_rows, rs.num_uniq, rs.row_g2, rs.row_g1)):
-            dist.all_gather_into_tensor(out, src, group=self.group)
+            self._gathered = exchange.alloc_gathered(local, self.world)
+        exchange.allgather_row_lists(local, self._gathered, self.group)
         self._cur = self._gathered + (self.world * rs.chunks,)
 
     @torch.no_grad()

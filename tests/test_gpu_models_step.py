@@ -202,3 +202,55 @@ def test_graph_replay_is_bitwise_equal_to_eager_and_deterministic():
     for k in results[0]:
         assert np.array_equal(results[1][k], results[2][k]), f"graph replay not deterministic: {k}"
         assert np.array_equal(results[0][k], results[1][k]), f"graph != eager: {k}"
+
+
+def test_merge_of_two_simulated_ranks_vs_oracle():
+    """The data-parallel merge kernel with L = 2 lists: two half batches reduced separately (as
+    two ranks would), stacked rank-major like all_gather_into_tensor, merged + clipped + Adam'd
+    on the GPU, against the oracle's reduction of the whole batch (grad mean over 2 ranks)."""
+    from deepfm_amd.training.rowsparse import RowSparseAdam
+    fields, cfg, model = _small_deepfm(V=200, seed=2)
+    emb = model.embedding
+    opt = RowSparseAdam(model, lr=1e-2, l2=0.0, max_grad_norm=0.5)
+    Bh, F, D = 700, 39, 16
+    rng = np.random.default_rng(21)
+    ids = np.stack([random_fields_batch([f], 2 * Bh, rng, 0.05)[f["name"]] for f in fields[:26]])   # (26, 2Bh)
+    dense = rng.random((13, 2 * Bh)).astype(np.float32)
+    g_fe = rng.standard_normal((2 * Bh, F, D)).astype(np.float32)
+    g_fo = rng.standard_normal((2 * Bh, 1)).astype(np.float32)
+    w_before = {k: npy(v).copy() for k, v in emb.state_dict().items()}
+    parts = []
+    for r in range(2):
+        sl = slice(r * Bh, (r + 1) * Bh)
+        inputs = [torch.from_numpy(np.ascontiguousarray(ids[s, sl])).cuda() for s in range(26)] + \
+                 [torch.from_numpy(np.ascontiguousarray(dense[j, sl])).cuda() for j in range(13)]
+        emb._ensure_plan(inputs[0].device)
+        rs = emb.build_rowplan(inputs, Bh)
+        emb.backward_rowsparse(inputs, torch.from_numpy(g_fo[sl]).cuda(), torch.from_numpy(g_fe[sl]).cuda(), {})
+        parts.append([t.clone() for t in (rs.uniq_rows, rs.num_uniq, rs.row_g2, rs.row_g1)])
+    gathered = [torch.cat([parts[0][i], parts[1][i]], dim=0) for i in range(4)]
+    opt.world = 2
+    opt._cur = tuple(gathered) + (2,)
+    opt.flat_grad.zero_()
+    opt.apply()
+    torch.cuda.synchronize()
+    # oracle: whole batch, mean over the two ranks
+    rows, sq = {}, 0.0
+    for s, f in enumerate(fields[:26]):
+        u, a2, a1 = O.rowsparse_reduce_fast(ids[s], g_fe[:, s, :], g_fo[:, 0])
+        a2, a1 = (0.5 * a2).astype(np.float32), (0.5 * a1).astype(np.float32)
+        rows[f["name"]] = (u, a2, a1)
+        sq += float((a2.astype(np.float64) ** 2).sum() + (a1.astype(np.float64) ** 2).sum())
+    assert abs(float(opt.sq_norm) - sq) < 1e-4 * sq
+    coef = O.clip_coef(sq, 0.5)
+    assert abs(float(opt.clip_coef) - float(coef)) < 1e-5
+    got = {k: npy(v) for k, v in emb.state_dict().items()}
+    for name, (u, a2, a1) in rows.items():
+        for key, g in ((f"second_order_embeddings.{name}.weight", a2), (f"first_order_embeddings.{name}.weight", a1[:, None])):
+            w = w_before[key].copy()
+            wu, m, v = w[u], np.zeros_like(w[u]), np.zeros_like(w[u])
+            O.adam_update(wu, m, v, g * coef, 1, 1e-2)
+            w[u] = wu
+            assert_close(got[key], w, rtol=1e-4, atol_scale=0.0, floor=2e-5, what=key)
+            untouched = np.setdiff1d(np.arange(w.shape[0]), u)
+            assert np.array_equal(got[key][untouched], w_before[key][untouched])   # only touched rows move
