@@ -1,0 +1,109 @@
+"""CPU: the C-ABI library loads and exports every declared symbol; host-side mirror logic
+(schema / config / module construction / state_dict keys / fail-loud behaviour).  No compute."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import cfg_of, fields_of, group, load, schema_from_fields
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_header_symbol():
+    from deepfm_amd import _lib
+    header = open(os.path.join(ROOT, "include", "deepfm_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(dfm_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    lib = _lib.load()
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in deepfm_hip.h but not exported"
+    assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
+    assert lib.dfm_abi_version() == 1
+
+
+def test_cin_layout_helpers_match_reference_bookkeeping():
+    from deepfm_amd import _lib
+    lib = _lib.load()
+    for sizes, split, want in (([64, 64], 0, 128), ([64, 64], 1, 96), ([128, 128, 128], 1, 256), ([5, 7, 3], 1, 2 + 3 + 3)):
+        arr = (ctypes.c_int32 * len(sizes))(*sizes)
+        assert lib.dfm_cin_output_dim(arr, len(sizes), split) == want
+
+
+def test_schema_and_config_mirror():
+    from deepfm_amd.config import ExperimentConfig, _parse_value
+    from deepfm_amd.data.schema import DatasetSchema, FeatureType, FieldSchema
+    f = FieldSchema("a", FeatureType.SPARSE)
+    assert (f.vocabulary_size, f.embedding_dim, f.group, f.max_length, f.combiner) == (0, 8, "", 1, "mean")
+    s = DatasetSchema(fields={"a": FieldSchema("a", FeatureType.SPARSE, 10, 16),
+                              "b": FieldSchema("b", FeatureType.DENSE, embedding_dim=4),
+                              "c": FieldSchema("c", FeatureType.SEQUENCE, 5, 16, max_length=3)})
+    assert s.num_fields == 3 and s.total_embedding_dim == 36          # tests/test_schema.py:70-73
+    assert [x.name for x in s.sparse_fields] == ["a"] and [x.name for x in s.dense_fields] == ["b"]
+    assert [x.name for x in s.sequence_fields] == ["c"]
+    c = ExperimentConfig()
+    assert c.feature.fm_embed_dim == 16 and c.cin.layer_sizes == [128, 128] and c.attention.attention_dim == 64
+    assert c.training.batch_size == 4096 and c.feature.embedding_l2_reg == 1e-5
+    assert _parse_value("true") is True and _parse_value("3") == 3 and _parse_value("[1,2]") == [1, 2]
+
+
+def test_load_config_yaml_and_overrides(tmp_path):
+    from deepfm_amd.config import load_config
+    p = tmp_path / "c.yaml"
+    p.write_text("model_name: xdeepfm\ncin:\n  layer_sizes: [64]\ntraining:\n  lr: 0.01\n")
+    cfg = load_config(p, ["training.batch_size=2048", "cin.split_half=false"])
+    assert cfg.model_name == "xdeepfm" and cfg.cin.layer_sizes == [64] and cfg.cin.split_half is False
+    assert cfg.training.batch_size == 2048 and cfg.training.lr == 0.01
+    p.write_text("nope: 1\n")
+    with pytest.raises(ValueError):
+        load_config(p)
+
+
+@pytest.mark.parametrize("case", ["model_deepfm", "model_xdeepfm", "model_attention_deepfm", "model_deepfm_movielens"])
+def test_models_expose_reference_state_dict_keys_and_shapes(case):
+    from deepfm_amd.models import create_model
+    from tests.test_gpu_models_step import _config
+    g = load(case)
+    c = cfg_of(g)
+    model = create_model(c["kind"], schema_from_fields(fields_of(g)), _config(c))
+    want = group(g, "param/")
+    sd = model.state_dict()
+    assert sorted(sd) == sorted(want)
+    for k, v in sd.items():
+        assert tuple(v.shape) == tuple(want[k].shape), k
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in want.items()})   # checkpoint round trip
+
+
+def test_same_seed_same_initial_weights_and_padding_row_zero():
+    from deepfm_amd.models.layers.embedding import FeatureEmbedding
+    g = load("emb_layers_test_schema")
+    schema = schema_from_fields(fields_of(g))
+    torch.manual_seed(3)
+    a = FeatureEmbedding(schema, 16)
+    torch.manual_seed(3)
+    b = FeatureEmbedding(schema, 16)
+    for (k, x), (_, y) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert torch.equal(x, y), k
+    for name in ("u", "i", "g"):
+        assert float(a.second_order_embeddings[name].weight[0].abs().sum()) == 0.0     # embedding.py:66-74
+
+
+def test_cpu_tensors_fail_loudly_no_fallback():
+    from deepfm_amd.models.layers.attention import MultiHeadSelfAttention
+    from deepfm_amd.models.layers.cin import CIN
+    from deepfm_amd.models.layers.fm import FMInteraction
+    x = torch.randn(2, 3, 8)
+    for layer in (FMInteraction(), CIN(3, 8, [4]), MultiHeadSelfAttention(8, 2, 8)):
+        with pytest.raises(RuntimeError, match="HIP device only"):
+            layer(x)
+    with pytest.raises(ValueError):
+        MultiHeadSelfAttention(8, num_heads=3, attention_dim=8)
+    from deepfm_amd.models.layers.dnn import DNN
+    with pytest.raises(ValueError):
+        DNN(4, [])
+    with pytest.raises(ValueError):
+        DNN(4, [2], activation="nope")
