@@ -68,7 +68,8 @@ SIGNATURES = {
     "dfm_cin_output_dim": (_I, [C.POINTER(C.c_int32), _I, _I]),
     "dfm_cin_saved_bytes": (_SZ, [C.POINTER(C.c_int32), _I, _I, _L, _I, _I]),
     "dfm_cin_backward_workspace_bytes": (_SZ, [C.POINTER(C.c_int32), _I, _I, _L, _I, _I]),
-    "dfm_cin_forward": (_I, [_P, _L, _I, _I, C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_int32), _I, _I, _P, _P, _P]),
+    "dfm_cin_forward_workspace_bytes": (_SZ, [C.POINTER(C.c_int32), _I, _I, _I, _I]),
+    "dfm_cin_forward": (_I, [_P, _L, _I, _I, C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_int32), _I, _I, _P, _P, _P, _P]),
     "dfm_cin_backward": (_I, [_P, _L, _I, _I, C.POINTER(_P), C.POINTER(C.c_int32), _I, _I, _P, _P, _P,
                               C.POINTER(_P), C.POINTER(_P), _P, _P]),
     "dfm_attention_forward": (_I, [_P, _L, _I, _I, _I, _I, _I, C.POINTER(_P), _P, _P]),

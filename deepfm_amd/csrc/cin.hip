@@ -3,6 +3,7 @@
 // and the MFMA kernels (cin_mfma.hip) for the shapes those support.
 #include "common.h"
 
+#include <cstdlib>
 #include <vector>
 
 using namespace dfm;
@@ -18,9 +19,66 @@ int cin_simple_backward_layer(const float* x0, const float* hidden, int64_t hidd
                               int out_stride, int out_col, const float* d_next, float* dY,
                               float* d_hidden_out, float* d_x0, int layer0, float* dW, float* db,
                               float* partial, hipStream_t st);
+typedef __bf16 bf16_t;
+constexpr int kCinMaxLayers = 8;
+struct CinMfmaLayer {
+  const bf16_t* w_hi;
+  const bf16_t* w_lo;
+  const float* bias;
+  float* Y;
+  int C, H, HP, MB, direct, next_off, next_count, out_col;
+};
+struct CinMfmaArgs {
+  const float* x0;
+  float* out;
+  int64_t B;
+  int F, L, out_dim, hid_rows;
+  CinMfmaLayer layer[kCinMaxLayers];
+};
+struct CinBwdLayer {
+  const bf16_t* wt_hi;
+  const bf16_t* wt_lo;
+  const float* Y;
+  const float* hidden;
+  int64_t hidden_stride;
+  float* dY;
+  int C, H, HQ, KS, direct, next_off, next_count, out_col;
+};
+struct CinBwdArgs {
+  const float* x0;
+  const float* g_out;
+  float* g_x0;
+  int64_t B;
+  int F, L, out_dim, dh_rows;
+  CinBwdLayer layer[kCinMaxLayers];
+};
+size_t cin_bwd_packed_wt_elems(int H, int F, int C);
+int cin_bwd_pack_wt(const float* W, int C, int H, int F, bf16_t* hi, bf16_t* lo, hipStream_t st);
+int cin_mfma_dgrad(const CinBwdArgs& args, int D, bool split, hipStream_t st);
+size_t cin_mfma_wgrad_workspace_bytes(int64_t B, int C, int H, int F);
+int cin_mfma_wgrad(const float* dY, const float* x0, const float* hidden, int64_t hidden_stride, int64_t B,
+                   int F, int H, int C, float* dW, void* workspace, bool split, hipStream_t st);
+int cin_bias_grad_launch(const float* dY, int64_t B, int C, int D, float* db, hipStream_t st);
+bool cin_mfma_supported(int F, int D, const int* C, const int* H, int L);
+size_t cin_mfma_packed_elems(int H, int F, int C);
+int cin_mfma_pack(const float* W, int C, int H, int F, bf16_t* hi, bf16_t* lo, hipStream_t st);
+int cin_mfma_forward(const CinMfmaArgs& args, int D, bool split, hipStream_t st);
 }  // namespace dfm
 
 namespace {
+// DFM_CIN_MODE: "split" (default: bf16 x 3, parity grade), "bf16" (plain bf16 MFMA, throughput
+// mode with its own tolerance), "fp32" (general exact kernels only)
+int cin_mode() {
+  static int mode = [] {
+    const char* e = getenv("DFM_CIN_MODE");
+    if (!e) return 0;
+    if (!strcmp(e, "bf16")) return 1;
+    if (!strcmp(e, "fp32")) return 2;
+    return 0;
+  }();
+  return mode;
+}
+
 struct Layout {
   int L = 0, F = 0, D = 0, out_dim = 0;
   std::vector<int> C, H, direct, next_off, out_col;
@@ -78,6 +136,28 @@ extern "C" size_t dfm_cin_saved_bytes(const int32_t* layer_sizes, int num_layers
   return sizeof(float) * static_cast<size_t>(lo.saved_floats);
 }
 
+static size_t packed_total_elems(const Layout& lo) {
+  size_t total = 0;
+  for (int i = 0; i < lo.L; ++i) total += cin_mfma_packed_elems(lo.H[i], lo.F, lo.C[i]);
+  return total;
+}
+
+extern "C" size_t dfm_cin_forward_workspace_bytes(const int32_t* layer_sizes, int num_layers, int split_half,
+                                                  int num_fields, int dim) {
+  Layout lo;
+  if (make_layout(layer_sizes, num_layers, split_half, num_fields, dim, 1, &lo)) return 0;
+  return 2 * sizeof(bf16_t) * packed_total_elems(lo) + 256;   // hi + lo fragment images
+}
+
+static size_t packed_wt_total(const Layout& lo) {
+  size_t total = 0;
+  for (int i = 0; i < lo.L; ++i) total += ((cin_bwd_packed_wt_elems(lo.H[i], lo.F, lo.C[i]) + 63) / 64) * 64;
+  return total;
+}
+static bool mfma_bwd_ok(const Layout& lo) {
+  return cin_mode() != 2 && lo.D == 16 && cin_mfma_supported(lo.F, lo.D, lo.C.data(), lo.H.data(), lo.L);
+}
+
 extern "C" size_t dfm_cin_backward_workspace_bytes(const int32_t* layer_sizes, int num_layers,
                                                    int split_half, int64_t batch, int num_fields,
                                                    int dim) {
@@ -86,22 +166,59 @@ extern "C" size_t dfm_cin_backward_workspace_bytes(const int32_t* layer_sizes, i
   const int64_t dy = batch * lo.max_C * dim;           // dY of the current layer
   const int64_t dh = batch * lo.max_H * dim;           // d hidden, two buffers (ping-pong)
   const int64_t part = kWgradSlices * lo.max_CK;       // weight-gradient partials
-  return sizeof(float) * static_cast<size_t>(dy + 2 * dh + part);
+  size_t simple = sizeof(float) * static_cast<size_t>(dy + 2 * dh + part);
+  // matrix-core path: dY of every layer + W^T fragments (hi, lo) + the largest wgrad workspace
+  size_t wg = 0;
+  for (int i = 0; i < lo.L; ++i) {
+    const size_t w = cin_mfma_wgrad_workspace_bytes(batch, lo.C[i], lo.H[i], num_fields);
+    wg = w > wg ? w : wg;
+  }
+  size_t mfma = sizeof(float) * static_cast<size_t>(lo.saved_floats) + 2 * sizeof(bf16_t) * packed_wt_total(lo) + wg + 1024;
+  return simple > mfma ? simple : mfma;
 }
 
 extern "C" int dfm_cin_forward(const float* d_x0, int64_t batch, int num_fields, int dim,
                                const float* const* weights, const float* const* biases,
                                const int32_t* layer_sizes, int num_layers, int split_half,
-                               float* d_out, float* d_saved, dfm_stream_t stream) {
-  DFM_REQUIRE(d_x0 && weights && biases && d_out && d_saved, "null argument");
+                               float* d_out, float* d_saved, void* d_workspace, dfm_stream_t stream) {
+  DFM_REQUIRE(d_x0 && weights && biases && d_out, "null argument");
   Layout lo;
   if (int rc = make_layout(layer_sizes, num_layers, split_half, num_fields, dim, batch, &lo)) return rc;
   if (batch == 0) return DFM_OK;
   hipStream_t st = as_stream(stream);
+  for (int i = 0; i < lo.L; ++i) DFM_REQUIRE(weights[i] && biases[i], "layer %d: null parameter", i);
+
+  if (cin_mode() != 2 && d_workspace && cin_mfma_supported(num_fields, dim, lo.C.data(), lo.H.data(), lo.L)) {
+    // matrix-core path: repack the weights (they change every step), then one fused launch
+    CinMfmaArgs args;
+    memset(&args, 0, sizeof(args));
+    args.x0 = d_x0; args.out = d_out; args.B = batch; args.F = num_fields; args.L = lo.L;
+    args.out_dim = lo.out_dim;
+    bf16_t* hi = static_cast<bf16_t*>(d_workspace);
+    bf16_t* lop = hi + ((packed_total_elems(lo) + 63) / 64) * 64;
+    size_t off = 0;
+    int hid_rows = 2;
+    for (int i = 0; i < lo.L; ++i) {
+      CinMfmaLayer& ly = args.layer[i];
+      ly.w_hi = hi + off; ly.w_lo = lop + off; ly.bias = biases[i];
+      ly.Y = d_saved ? d_saved + lo.y_off[i] : nullptr;
+      ly.C = lo.C[i]; ly.H = lo.H[i]; ly.HP = (lo.H[i] + 1) / 2; ly.MB = (lo.C[i] + 31) / 32;
+      ly.direct = lo.direct[i]; ly.next_off = lo.next_off[i];
+      ly.next_count = i < lo.L - 1 ? lo.H[i + 1] : 0;
+      ly.out_col = lo.out_col[i];
+      if (int rc = cin_mfma_pack(weights[i], lo.C[i], lo.H[i], num_fields, hi + off, lop + off, st)) return rc;
+      off += cin_mfma_packed_elems(lo.H[i], num_fields, lo.C[i]);
+      hid_rows = 2 * ly.HP > hid_rows ? 2 * ly.HP : hid_rows;
+    }
+    const int fg8 = ((num_fields + 7) / 8) * 8;
+    args.hid_rows = hid_rows > fg8 ? hid_rows : fg8;
+    return cin_mfma_forward(args, dim, cin_mode() == 0, st);
+  }
+
+  DFM_REQUIRE(d_saved, "the general CIN kernels need the d_saved buffer");
   const float* hidden = d_x0;
   int64_t hstride = static_cast<int64_t>(num_fields) * dim;
   for (int i = 0; i < lo.L; ++i) {
-    DFM_REQUIRE(weights[i] && biases[i], "layer %d: null parameter", i);
     float* Y = d_saved + lo.y_off[i];
     if (int rc = cin_simple_forward_layer(d_x0, hidden, hstride, weights[i], biases[i], batch, num_fields,
                                           lo.H[i], lo.C[i], dim, lo.direct[i], Y, d_out, lo.out_dim,
@@ -124,6 +241,47 @@ extern "C" int dfm_cin_backward(const float* d_x0, int64_t batch, int num_fields
   if (int rc = make_layout(layer_sizes, num_layers, split_half, num_fields, dim, batch, &lo)) return rc;
   if (batch == 0) return DFM_OK;
   hipStream_t st = as_stream(stream);
+  for (int i = 0; i < lo.L; ++i) DFM_REQUIRE(weights[i] && g_weights[i] && g_biases[i], "layer %d: null parameter", i);
+  if (mfma_bwd_ok(lo)) {
+    const bool split = cin_mode() == 0;
+    float* dY_all = static_cast<float*>(d_workspace);
+    bf16_t* hi = reinterpret_cast<bf16_t*>(dY_all + lo.saved_floats);
+    bf16_t* lop = hi + packed_wt_total(lo);
+    unsigned char* wg_ws = reinterpret_cast<unsigned char*>(lop + packed_wt_total(lo));
+    wg_ws += (256 - (reinterpret_cast<uintptr_t>(wg_ws) & 255)) & 255;
+    CinBwdArgs args;
+    memset(&args, 0, sizeof(args));
+    args.x0 = d_x0; args.g_out = d_g_out; args.g_x0 = d_g_x0; args.B = batch; args.F = num_fields;
+    args.L = lo.L; args.out_dim = lo.out_dim;
+    size_t off = 0;
+    int dh_rows = 4;
+    for (int i = 0; i < lo.L; ++i) {
+      CinBwdLayer& ly = args.layer[i];
+      ly.wt_hi = hi + off; ly.wt_lo = lop + off;
+      ly.Y = d_saved + lo.y_off[i];
+      ly.hidden = i == 0 ? d_x0 : d_saved + lo.y_off[i - 1] + static_cast<int64_t>(lo.next_off[i - 1]) * dim;
+      ly.hidden_stride = i == 0 ? static_cast<int64_t>(num_fields) * dim : static_cast<int64_t>(lo.C[i - 1]) * dim;
+      ly.dY = dY_all + lo.y_off[i];
+      ly.C = lo.C[i]; ly.H = lo.H[i]; ly.HQ = (lo.H[i] + 3) / 4; ly.KS = (lo.C[i] + 15) / 16;
+      ly.direct = lo.direct[i]; ly.next_off = lo.next_off[i];
+      ly.next_count = i < lo.L - 1 ? lo.H[i + 1] : 0;
+      ly.out_col = lo.out_col[i];
+      if (int rc = cin_bwd_pack_wt(weights[i], lo.C[i], lo.H[i], num_fields, hi + off, lop + off, st)) return rc;
+      off += ((cin_bwd_packed_wt_elems(lo.H[i], num_fields, lo.C[i]) + 63) / 64) * 64;
+      dh_rows = 4 * ly.HQ > dh_rows ? 4 * ly.HQ : dh_rows;
+    }
+    const int fg8 = ((num_fields + 7) / 8) * 8;
+    args.dh_rows = dh_rows > fg8 ? dh_rows : fg8;
+    if (int rc = cin_mfma_dgrad(args, dim, split, st)) return rc;
+    for (int i = 0; i < lo.L; ++i) {
+      const CinBwdLayer& ly = args.layer[i];
+      if (int rc = cin_mfma_wgrad(ly.dY, d_x0, ly.hidden, ly.hidden_stride, batch, num_fields, lo.H[i], lo.C[i],
+                                  g_weights[i], wg_ws, split, st))
+        return rc;
+      if (int rc = cin_bias_grad_launch(ly.dY, batch, lo.C[i], dim, g_biases[i], st)) return rc;
+    }
+    return DFM_OK;
+  }
   float* ws = static_cast<float*>(d_workspace);
   float* dY = ws;
   float* dh[2] = {dY + batch * lo.max_C * dim, dY + batch * lo.max_C * dim + batch * lo.max_H * dim};

@@ -1,0 +1,280 @@
+// CIN forward on the gfx950 matrix cores: the WHOLE layer stack in one launch.
+// Reference: deepfm/models/layers/cin.py:66-105.
+//
+// GEMM view of one layer:  Y[c, n] = relu(bias[c] + sum_k W[c,k] Z[k,n]),
+// k = (h, f), n = (b, d), Z[(h,f),(b,d)] = hidden[b,h,d] * x0[b,f,d].  Every column n depends only
+// on column n of hidden and x0, so a wave that owns 32 columns (two samples at D = 16) can run all
+// layers back to back: the "next" half of its accumulator tile IS the hidden input of the following
+// layer (handed over through a wave-private LDS image), and Z — 398-654 MB per layer in the
+// reference — is generated in registers, one 16-deep k-step at a time, as the MFMA B operand.
+//
+// Mapping onto v_mfma_f32_32x32x16_bf16 (D = A*B + C, A: 32 rows x 16 k, B: 16 k x 32 cols):
+//   * rows   = output channels c, up to four 32-row blocks (C <= 128) -> 64 accumulator VGPRs;
+//   * cols   = the wave's 32 (b,d) columns;
+//   * k-step = one field group fg (8 consecutive f) for TWO hidden rows: lane half 0 takes hidden
+//     row 2*hp, half 1 takes row 2*hp+1, so a lane's 8 B-operand values are
+//     hidden[h][n] * x0[fg*8 + j][n]: one LDS scalar times 8 registers of the lane's x0 column.
+//   * A operand: W repacked by cin_pack_weights into exactly the fragment order
+//     [k-step][row block][lane][8 bf16] — one 16-B load per lane per MFMA, staged through LDS once
+//     per workgroup (4 waves share a slab), double buffered.
+// Numerics: bf16 x 3 split — W = Wh + Wl, Z = Zh + Zl, acc += Wh*Zh + Wh*Zl + Wl*Zh (fp32
+// accumulate) — which holds the 1e-4 logit bar (plain bf16 is 4e-3, the split
+// 7e-6); SPLIT = false is the plain-bf16 throughput mode (own tolerance, never used for parity).
+#include "common.h"
+
+using namespace dfm;
+
+namespace dfm {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kCinMaxLayers = 8;
+constexpr int kCinWaves = 4;          // waves per workgroup (share the weight slabs)
+constexpr int kCinCols = 32;          // columns per wave
+
+struct CinMfmaLayer {
+  const __bf16* w_hi;   // packed (HP*FG, MB, 64, 8)
+  const __bf16* w_lo;
+  const float* bias;    // (C)
+  float* Y;             // (B, C, D) post-ReLU activations for the backward, or null
+  int C, H, HP, MB, direct, next_off, next_count, out_col;
+};
+struct CinMfmaArgs {
+  const float* x0;
+  float* out;
+  int64_t B;
+  int F, L, out_dim, hid_rows;  // hid_rows: rows of the per-wave hidden image in LDS
+  CinMfmaLayer layer[kCinMaxLayers];
+};
+
+// ---- weight packing -----------------------------------------------------------------
+// W (C, H*F) fp32 -> hi/lo bf16 fragments [ks = hp*FG+fg][mb][lane = hf*32+r][j]:
+//   value = W[c = mb*32+r][h = 2*hp+hf][f = fg*8+j]  (0 outside C/H/F)
+__global__ __launch_bounds__(256) void cin_pack_weights(const float* __restrict__ W, int C, int H, int F,
+                                                        int HP, int FG, int MB,
+                                                        __bf16* __restrict__ hi, __bf16* __restrict__ lo) {
+  const int64_t t = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  const int64_t total = static_cast<int64_t>(HP) * FG * MB * 64 * 8;
+  if (t >= total) return;
+  const int j = t & 7;
+  const int lane = (t >> 3) & 63;
+  const int64_t rest = t >> 9;
+  const int mb = static_cast<int>(rest % MB);
+  const int ks = static_cast<int>(rest / MB);
+  const int hp = ks / FG, fg = ks % FG;
+  const int c = mb * 32 + (lane & 31), h = 2 * hp + (lane >> 5), f = fg * 8 + j;
+  float v = 0.f;
+  if (c < C && h < H && f < F) v = W[static_cast<int64_t>(c) * H * F + h * F + f];
+  const __bf16 vh = static_cast<__bf16>(v);
+  hi[t] = vh;
+  lo[t] = static_cast<__bf16>(v - static_cast<float>(vh));
+}
+
+// ---- the fused forward ----------------------------------------------------------------
+template <int D, int FG, bool SPLIT>
+__global__ __launch_bounds__(kCinWaves * 64, 2) void cin_fwd_mfma(CinMfmaArgs args) {
+  static_assert(kCinCols % D == 0, "a 32-column tile must hold whole samples");
+  constexpr int SPT = kCinCols / D;                       // samples per tile
+  constexpr int SLAB = 4 /*MB max*/ * 64 * 16;            // bytes of one hi (or lo) slab
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  // [2 buffers][hi, lo][MB*64 lanes][16 B]  then per-wave hidden images
+  unsigned char* wbuf = lds_raw;
+  float* hid_all = reinterpret_cast<float*>(lds_raw + 2 * 2 * SLAB);
+  const int lane = lane_id();
+  const int wave = wave_id_uniform();
+  const int tid = threadIdx.x;
+  float* hid = hid_all + static_cast<size_t>(wave) * args.hid_rows * kCinCols;
+  const int n = lane & 31, hf = lane >> 5;
+  const int64_t col0 = (static_cast<int64_t>(blockIdx.x) * kCinWaves + wave) * kCinCols;
+  const int64_t ncols = args.B * D;
+  const int64_t col = col0 + n;
+  const bool live = col < ncols;
+  const int64_t b = live ? col / D : 0;
+  const int d = static_cast<int>(col % D);
+  const int F = args.F;
+
+  // the lane's x0 column in registers (zero beyond F / beyond the batch)
+  float x0r[FG * 8];
+#pragma unroll
+  for (int f = 0; f < FG * 8; ++f)
+    x0r[f] = (live && f < F) ? args.x0[(b * F + f) * D + d] : 0.f;
+  // layer 0: hidden = x0 (wave-private LDS image, both lane halves write the same values)
+  for (int r = 0; r < args.hid_rows; ++r) {
+    if (hf == (r & 1)) hid[r * kCinCols + n] = 0.f;
+  }
+#pragma unroll
+  for (int f = 0; f < FG * 8; ++f)
+    if (hf == 0 && f < args.hid_rows) hid[f * kCinCols + n] = x0r[f];
+
+  for (int li = 0; li < args.L; ++li) {
+    const CinMfmaLayer ly = args.layer[li];
+    const int MB = ly.MB;
+    f32x16 acc[4];
+    {
+      // accumulators start at the bias; rows of this lane: mb*32 + (r&3) + 8*(r>>2) + 4*hf
+      const float* brow = ly.bias + 4 * hf;
+      const int c_lim = ly.C - 4 * hf;          // row < C  <=>  (row - 4*hf) < c_lim
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rr = mb * 32 + (r & 3) + 8 * (r >> 2);   // compile-time
+          acc[mb][r] = rr < c_lim ? brow[rr] : 0.f;
+        }
+      }
+    }
+    const int ksteps = ly.HP * FG;
+    // stage slab 0
+    const int s_mb = tid >> 6, s_lane = tid & 63;
+    auto stage_load = [&](int ks, uint4& vh, uint4& vl) {
+      if (s_mb < MB) {
+        const int64_t e = (static_cast<int64_t>(ks) * MB + s_mb) * 64 + s_lane;
+        vh = reinterpret_cast<const uint4*>(ly.w_hi)[e];
+        if (SPLIT) vl = reinterpret_cast<const uint4*>(ly.w_lo)[e];
+      }
+    };
+    auto stage_store = [&](int buf, const uint4& vh, const uint4& vl) {
+      if (s_mb < MB) {
+        unsigned char* base = wbuf + buf * 2 * SLAB;
+        reinterpret_cast<uint4*>(base)[s_mb * 64 + s_lane] = vh;
+        if (SPLIT) reinterpret_cast<uint4*>(base + SLAB)[s_mb * 64 + s_lane] = vl;
+      }
+    };
+    // Weight pipeline: slab t is loaded global->registers during k-step t-2, written to LDS at
+    // the start of k-step t-1 (the load had a whole k-step to land), made visible by the
+    // barrier that ends k-step t-1, read during k-step t.  Two LDS buffers, one register set.
+    uint4 vh = {}, vl = {};
+    __syncthreads();                       // previous layer's readers are done with both buffers / hid
+    stage_load(0, vh, vl);
+    stage_store(0, vh, vl);
+    if (ksteps > 1) stage_load(1, vh, vl);
+    __syncthreads();
+    int ks = 0;
+    for (int hp = 0; hp < ly.HP; ++hp) {
+      const float hv = hid[(2 * hp + hf) * kCinCols + n];
+#pragma unroll
+      for (int fg = 0; fg < FG; ++fg, ++ks) {
+        const int cur = ks & 1;
+        if (ks + 1 < ksteps) stage_store(cur ^ 1, vh, vl);   // slab ks+1 (loaded one step ago)
+        if (ks + 2 < ksteps) stage_load(ks + 2, vh, vl);
+        // B operand: Z values of this k-step for the lane's column
+        float z[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) z[j] = hv * x0r[fg * 8 + j];
+        bf16x8 bh, bl;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          bh[j] = static_cast<__bf16>(z[j]);
+          if (SPLIT) bl[j] = static_cast<__bf16>(z[j] - static_cast<float>(bh[j]));
+        }
+        const unsigned char* base = wbuf + cur * 2 * SLAB;
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+          if (mb < MB) {
+            const bf16x8 ah = reinterpret_cast<const bf16x8*>(base)[mb * 64 + lane];
+            acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[mb], 0, 0, 0);
+            if (SPLIT) {
+              const bf16x8 al = reinterpret_cast<const bf16x8*>(base + SLAB)[mb * 64 + lane];
+              acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[mb], 0, 0, 0);
+              acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[mb], 0, 0, 0);
+            }
+          }
+        }
+        __syncthreads();
+      }
+    }
+    // ---- epilogue: ReLU, sum-pool of the direct channels, hand the next channels over ------
+    const bool last = li == args.L - 1;
+    // the hidden image is rewritten below: every row of the next layer's (padded) image
+    if (!last) {
+      const int rows_next = 2 * args.layer[li + 1].HP;
+      for (int r = ly.next_count; r < rows_next; ++r)
+        if (hf == (r & 1)) hid[r * kCinCols + n] = 0.f;
+    }
+    {
+      // per-lane bases so that every row below is a compile-time offset from them
+      float* ybase = ly.Y ? ly.Y + (b * ly.C + 4 * hf) * D + d : nullptr;
+      float* obase = args.out + b * args.out_dim + ly.out_col + 4 * hf;
+      float* hbase = hid + (4 * hf - ly.next_off) * kCinCols + n;
+      const int c_lim = ly.C - 4 * hf, d_lim = ly.direct - 4 * hf;
+      const int n_lo = ly.next_off - 4 * hf, n_hi = n_lo + (last ? 0 : ly.next_count);
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rr = mb * 32 + (r & 3) + 8 * (r >> 2);   // compile-time; row = rr + 4*hf
+          const float y = fmaxf(acc[mb][r], 0.f);
+          if (ybase && live && rr < c_lim) ybase[rr * D] = y;
+          if (rr >= n_lo && rr < n_hi) hbase[rr * kCinCols] = y;
+          // sum-pool over the D columns of each sample (D consecutive lanes; xor partners share
+          // the lane half, hence the row, so the branch is taken pairwise)
+          if (rr < d_lim) {
+            float sum = live ? y : 0.f;
+#pragma unroll
+            for (int m = 1; m < D; m <<= 1) sum += __shfl_xor(sum, m, kWave);
+            if (live && d == 0) obase[rr] = sum;
+          }
+        }
+      }
+    }
+    (void)SPT;
+  }
+}
+
+// ---- host side ---------------------------------------------------------------------------
+bool cin_mfma_supported(int F, int D, const int* C, const int* H, int L) {
+  if (D != 16 && D != 8 && D != 32) return false;
+  if (F > 40 || L > kCinMaxLayers) return false;
+  for (int i = 0; i < L; ++i)
+    if (C[i] > 128 || H[i] > 128) return false;
+  return true;
+}
+
+size_t cin_mfma_packed_elems(int H, int F, int C) {
+  const int HP = (H + 1) / 2, FG = (F + 7) / 8, MB = (C + 31) / 32;
+  return static_cast<size_t>(HP) * FG * MB * 64 * 8;
+}
+
+int cin_mfma_pack(const float* W, int C, int H, int F, __bf16* hi, __bf16* lo, hipStream_t st) {
+  const int HP = (H + 1) / 2, FG = (F + 7) / 8, MB = (C + 31) / 32;
+  const size_t total = cin_mfma_packed_elems(H, F, C);
+  hipLaunchKernelGGL(cin_pack_weights, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, st, W, C,
+                     H, F, HP, FG, MB, hi, lo);
+  DFM_LAUNCH_CHECK();
+  return DFM_OK;
+}
+
+template <int D, int FG>
+static int launch_fwd(const CinMfmaArgs& args, bool split, hipStream_t st) {
+  const int64_t ncols = args.B * D;
+  const int64_t blocks = (ncols + kCinWaves * kCinCols - 1) / (kCinWaves * kCinCols);
+  const size_t lds = 2 * 2 * (4 * 64 * 16) + sizeof(float) * kCinWaves * args.hid_rows * kCinCols;
+  DFM_REQUIRE(lds <= 160 * 1024, "CIN MFMA kernel needs %zu bytes of LDS", lds);
+  if (split) {
+    DFM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(cin_fwd_mfma<D, FG, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    hipLaunchKernelGGL((cin_fwd_mfma<D, FG, true>), dim3(static_cast<unsigned>(blocks)), dim3(kCinWaves * 64),
+                       lds, st, args);
+  } else {
+    DFM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(cin_fwd_mfma<D, FG, false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    hipLaunchKernelGGL((cin_fwd_mfma<D, FG, false>), dim3(static_cast<unsigned>(blocks)), dim3(kCinWaves * 64),
+                       lds, st, args);
+  }
+  DFM_LAUNCH_CHECK();
+  return DFM_OK;
+}
+
+int cin_mfma_forward(const CinMfmaArgs& args, int D, bool split, hipStream_t st) {
+  const int FG = (args.F + 7) / 8;
+#define DFM_CIN_CASE(DD, GG) \
+  if (D == DD && FG == GG) return launch_fwd<DD, GG>(args, split, st);
+  DFM_CIN_CASE(16, 1) DFM_CIN_CASE(16, 2) DFM_CIN_CASE(16, 3) DFM_CIN_CASE(16, 4) DFM_CIN_CASE(16, 5)
+  DFM_CIN_CASE(8, 1) DFM_CIN_CASE(8, 2) DFM_CIN_CASE(8, 3) DFM_CIN_CASE(8, 4) DFM_CIN_CASE(8, 5)
+  DFM_CIN_CASE(32, 1) DFM_CIN_CASE(32, 2) DFM_CIN_CASE(32, 3) DFM_CIN_CASE(32, 4) DFM_CIN_CASE(32, 5)
+#undef DFM_CIN_CASE
+  return fail(DFM_ERR_UNSUPPORTED, "no MFMA CIN kernel for D=%d, F=%d", D, args.F);
+}
+
+}  // namespace dfm

@@ -185,6 +185,12 @@ int cin_simple_forward_layer(const float* x0, const float* hidden, int64_t hidde
   return DFM_OK;
 }
 
+int cin_bias_grad_launch(const float* dY, int64_t B, int C, int D, float* db, hipStream_t st) {
+  hipLaunchKernelGGL(cin_bias_grad, dim3(C), dim3(kThreads), 0, st, dY, B, C, D, db);
+  DFM_LAUNCH_CHECK();
+  return DFM_OK;
+}
+
 int cin_simple_backward_layer(const float* x0, const float* hidden, int64_t hidden_stride,
                               const float* W, const float* Y, int64_t B, int F, int H, int C, int D,
                               int direct, int next_off, int next_count, const float* g_out,

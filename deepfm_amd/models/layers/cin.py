@@ -73,8 +73,10 @@ class _CINFn(torch.autograd.Function):
         out = torch.empty(B, module.output_dim, dtype=torch.float32, device=x0.device)
         saved = torch.empty(max(lib.dfm_cin_saved_bytes(sizes, L, split, B, F, D) // 4, 1),
                             dtype=torch.float32, device=x0.device)
+        ws = torch.empty(max(lib.dfm_cin_forward_workspace_bytes(sizes, L, split, F, D), 16), dtype=torch.uint8,
+                         device=x0.device)
         _lib.check(lib.dfm_cin_forward(x0.data_ptr(), B, F, D, _ptrs(weights), _ptrs(biases), sizes, L, split,
-                                       out.data_ptr(), saved.data_ptr(), _lib.stream_handle()))
+                                       out.data_ptr(), saved.data_ptr(), ws.data_ptr(), _lib.stream_handle()))
         ctx.module = module
         ctx.save_for_backward(x0, saved, *weights)
         return out

@@ -201,17 +201,24 @@ int dfm_fm_backward(const float* d_field_emb, const float* d_g_out, int64_t batc
  *                 out[:, col_i : col_i+direct_i] = sum_d Y_i[:, :direct_i, :]  (cin.py:102-105)
  *   weights[i] = conv_layers.<i>.weight (C_i, H_i*F[, 1]),  biases[i] = conv_layers.<i>.bias (C_i)
  *   layer_sizes / split_half as in CIN.__init__ (cin.py:41-64).
- * d_saved receives the post-ReLU Y_i of every layer (dfm_cin_saved_bytes) for the backward.
+ * d_saved receives the post-ReLU Y_i of every layer (dfm_cin_saved_bytes) for the backward
+ * (may be NULL for inference on the matrix-core path).  d_workspace
+ * (dfm_cin_forward_workspace_bytes) holds the bf16 hi/lo weight fragments of the MFMA path
+ * (F <= 40, D in {8,16,32}, layer sizes <= 128); without it, or for other shapes, the general
+ * fp32 kernels run.  Environment DFM_CIN_MODE = split (default, bf16 x 3: parity grade) |
+ * bf16 (plain bf16 MFMA, throughput mode) | fp32 (general kernels only).
  * ------------------------------------------------------------------------------- */
 int dfm_cin_output_dim(const int32_t* layer_sizes, int num_layers, int split_half);
 size_t dfm_cin_saved_bytes(const int32_t* layer_sizes, int num_layers, int split_half, int64_t batch,
                            int num_fields, int dim);
+size_t dfm_cin_forward_workspace_bytes(const int32_t* layer_sizes, int num_layers, int split_half,
+                                       int num_fields, int dim);
 size_t dfm_cin_backward_workspace_bytes(const int32_t* layer_sizes, int num_layers, int split_half,
                                         int64_t batch, int num_fields, int dim);
 int dfm_cin_forward(const float* d_x0, int64_t batch, int num_fields, int dim,
                     const float* const* weights, const float* const* biases,
                     const int32_t* layer_sizes, int num_layers, int split_half, float* d_out,
-                    float* d_saved, dfm_stream_t stream);
+                    float* d_saved, void* d_workspace, dfm_stream_t stream);
 /* d_g_x0 (B,F,D) is overwritten; weight / bias gradients are ADDED into g_weights[i] / g_biases[i]. */
 int dfm_cin_backward(const float* d_x0, int64_t batch, int num_fields, int dim,
                      const float* const* weights, const int32_t* layer_sizes, int num_layers,

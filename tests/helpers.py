@@ -112,3 +112,17 @@ def random_fields_batch(fields, B, rng, zero_frac=0.01):
             x = rng.random(B).astype(np.float32)
         batch[f["name"]] = x
     return batch
+
+
+def assert_close_mostly(got, want, max_bad_frac: float, rtol: float = RTOL, atol_scale: float = 1e-5, what: str = ""):
+    """assert_close that tolerates a bounded fraction of outliers.  Used only where a ReLU kink
+    makes the gradient discontinuous: an activation within rounding distance of 0 may land on the
+    other side of the kink in fp32-vs-split-bf16 arithmetic, which flips one (sample, d) column of
+    the CIN gradients.  Everything else must still meet the normal bar."""
+    got = np.asarray(got, dtype=np.float64)
+    want = np.asarray(want, dtype=np.float64)
+    assert got.shape == want.shape, f"{what}: shape {got.shape} vs {want.shape}"
+    scale = max(float(np.abs(want).max()) if want.size else 0.0, 1e-30)
+    bad = np.abs(got - want) > rtol * np.abs(want) + atol_scale * scale
+    frac = bad.mean() if bad.size else 0.0
+    assert frac <= max_bad_frac, f"{what}: {bad.sum()} / {bad.size} elements ({frac:.2e}) out of tolerance"
