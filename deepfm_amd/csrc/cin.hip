@@ -58,7 +58,8 @@ int cin_mfma_dgrad(const CinBwdArgs& args, int D, bool split, hipStream_t st);
 size_t cin_mfma_wgrad_workspace_bytes(int64_t B, int C, int H, int F);
 int cin_mfma_wgrad(const float* dY, const float* x0, const float* hidden, int64_t hidden_stride, int64_t B,
                    int F, int H, int C, float* dW, void* workspace, bool split, hipStream_t st);
-int cin_bias_grad_launch(const float* dY, int64_t B, int C, int D, float* db, hipStream_t st);
+size_t cin_bias_grad_workspace_bytes(int C);
+int cin_bias_grad_launch(const float* dY, int64_t B, int C, int D, float* db, float* partial, hipStream_t st);
 bool cin_mfma_supported(int F, int D, const int* C, const int* H, int L);
 size_t cin_mfma_packed_elems(int H, int F, int C);
 int cin_mfma_pack(const float* W, int C, int H, int F, bf16_t* hi, bf16_t* lo, hipStream_t st);
@@ -165,7 +166,8 @@ extern "C" size_t dfm_cin_backward_workspace_bytes(const int32_t* layer_sizes, i
   if (make_layout(layer_sizes, num_layers, split_half, num_fields, dim, batch, &lo)) return 0;
   const int64_t dy = batch * lo.max_C * dim;           // dY of the current layer
   const int64_t dh = batch * lo.max_H * dim;           // d hidden, two buffers (ping-pong)
-  const int64_t part = kWgradSlices * lo.max_CK;       // weight-gradient partials
+  int64_t part = kWgradSlices * lo.max_CK;             // weight-gradient partials (reused for bias partials)
+  if (part < 256 * static_cast<int64_t>(lo.max_C)) part = 256 * static_cast<int64_t>(lo.max_C);
   size_t simple = sizeof(float) * static_cast<size_t>(dy + 2 * dh + part);
   // matrix-core path: dY of every layer + W^T fragments (hi, lo) + the largest wgrad workspace
   size_t wg = 0;
@@ -278,14 +280,15 @@ extern "C" int dfm_cin_backward(const float* d_x0, int64_t batch, int num_fields
       if (int rc = cin_mfma_wgrad(ly.dY, d_x0, ly.hidden, ly.hidden_stride, batch, num_fields, lo.H[i], lo.C[i],
                                   g_weights[i], wg_ws, split, st))
         return rc;
-      if (int rc = cin_bias_grad_launch(ly.dY, batch, lo.C[i], dim, g_biases[i], st)) return rc;
+      // wgrad's slabs are consumed (stream order): its workspace doubles as the bias partials
+      if (int rc = cin_bias_grad_launch(ly.dY, batch, lo.C[i], dim, g_biases[i], reinterpret_cast<float*>(wg_ws), st)) return rc;
     }
     return DFM_OK;
   }
   float* ws = static_cast<float*>(d_workspace);
   float* dY = ws;
   float* dh[2] = {dY + batch * lo.max_C * dim, dY + batch * lo.max_C * dim + batch * lo.max_H * dim};
-  float* partial = dh[1] + batch * lo.max_H * dim;
+  float* partial = dh[1] + batch * lo.max_H * dim;   // >= max(slices*C*K, 256*C) floats
   DFM_HIP_TRY(hipMemsetAsync(d_g_x0, 0, sizeof(float) * batch * num_fields * dim, st));
   const float* d_next = nullptr;
   for (int i = lo.L - 1; i >= 0; --i) {

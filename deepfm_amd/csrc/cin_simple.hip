@@ -149,22 +149,36 @@ __global__ __launch_bounds__(kThreads) void cin_wgrad_reduce(const float* __rest
   dW[o] += acc;
 }
 
-// db[c] = sum_{b,d} dY[b,c,d]; grid = C, fixed-order tree
-__global__ __launch_bounds__(kThreads) void cin_bias_grad(const float* __restrict__ dY, int64_t B,
-                                                          int C, int D, float* __restrict__ db) {
-  const int c = blockIdx.x;
-  float acc = 0.f;
-  for (int64_t i = threadIdx.x; i < B * D; i += kThreads) {
-    const int64_t b = i / D;
-    const int d = static_cast<int>(i % D);
-    acc += dY[(b * C + c) * D + d];
+// db[c] = sum_{b,d} dY[b,c,d].  Stage 1: each workgroup sweeps a batch slice with fully
+// coalesced reads (a sample's (C, D) block is contiguous) and leaves C partial sums; stage 2
+// adds the slices in a fixed order.  Dynamic LDS = C*D floats.
+__global__ __launch_bounds__(kThreads) void cin_bias_partial(const float* __restrict__ dY, int64_t B,
+                                                             int C, int D, int slices,
+                                                             float* __restrict__ partial) {
+  extern __shared__ float tmp[];
+  const int CD = C * D;
+  const int64_t per = (B + slices - 1) / slices;
+  const int64_t b0 = blockIdx.x * per, b1 = b0 + per < B ? b0 + per : B;
+  for (int e = threadIdx.x; e < CD; e += kThreads) {
+    float acc = 0.f;
+    for (int64_t b = b0; b < b1; ++b) acc += dY[b * CD + e];
+    tmp[e] = acc;
   }
-  __shared__ float wsum[kThreads / kWave];
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, kWave);
-  if (lane_id() == 0) wsum[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) db[c] += (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+  for (int c = threadIdx.x; c < C; c += kThreads) {
+    float acc = 0.f;
+    for (int d = 0; d < D; ++d) acc += tmp[c * D + d];
+    partial[static_cast<int64_t>(blockIdx.x) * C + c] = acc;
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void cin_bias_reduce(const float* __restrict__ partial, int C,
+                                                            int slices, float* __restrict__ db) {
+  const int c = blockIdx.x * kThreads + threadIdx.x;
+  if (c >= C) return;
+  float acc = 0.f;
+  for (int s = 0; s < slices; ++s) acc += partial[static_cast<int64_t>(s) * C + c];
+  db[c] += acc;
 }
 
 namespace dfm {
@@ -185,8 +199,16 @@ int cin_simple_forward_layer(const float* x0, const float* hidden, int64_t hidde
   return DFM_OK;
 }
 
-int cin_bias_grad_launch(const float* dY, int64_t B, int C, int D, float* db, hipStream_t st) {
-  hipLaunchKernelGGL(cin_bias_grad, dim3(C), dim3(kThreads), 0, st, dY, B, C, D, db);
+constexpr int kBiasSlices = 256;
+size_t cin_bias_grad_workspace_bytes(int C) { return sizeof(float) * kBiasSlices * static_cast<size_t>(C); }
+
+int cin_bias_grad_launch(const float* dY, int64_t B, int C, int D, float* db, float* partial, hipStream_t st) {
+  const int slices = B < kBiasSlices ? static_cast<int>(B) : kBiasSlices;
+  hipLaunchKernelGGL(cin_bias_partial, dim3(slices), dim3(kThreads), sizeof(float) * C * D, st, dY, B, C, D,
+                     slices, partial);
+  DFM_LAUNCH_CHECK();
+  hipLaunchKernelGGL(cin_bias_reduce, dim3((C + kThreads - 1) / kThreads), dim3(kThreads), 0, st, partial, C,
+                     slices, db);
   DFM_LAUNCH_CHECK();
   return DFM_OK;
 }
@@ -214,8 +236,7 @@ int cin_simple_backward_layer(const float* x0, const float* hidden, int64_t hidd
   hipLaunchKernelGGL(cin_wgrad_reduce, dim3(static_cast<unsigned>((n + kThreads - 1) / kThreads)),
                      dim3(kThreads), 0, st, partial, n, slices, dW);
   DFM_LAUNCH_CHECK();
-  hipLaunchKernelGGL(cin_bias_grad, dim3(C), dim3(kThreads), 0, st, dY, B, C, D, db);
-  DFM_LAUNCH_CHECK();
-  return DFM_OK;
+  // the weight-gradient partials are consumed by now: reuse the buffer for the bias partials
+  return cin_bias_grad_launch(dY, B, C, D, db, partial, st);
 }
 }  // namespace dfm

@@ -26,6 +26,11 @@ struct dfm_embedding_plan {
   int max_dim = 0;
   std::vector<dfm_field> h_fields;
   std::vector<int32_t> h_sparse, h_dense, h_proj;
+  // device-resident slot tables of the uniform gather (DFM_GATHER_ARGS=device)
+  void* d_slots = nullptr;
+  void* h_shadow = nullptr;        // last uploaded contents
+  void* h_ring = nullptr;          // pinned staging ring
+  int ring_pos = 0;
   dfm_field* d_fields = nullptr;
   int32_t* d_sparse = nullptr;
   int32_t* d_dense = nullptr;
@@ -61,9 +66,9 @@ struct UniformArgs {
 };
 
 template <int D, int W, bool HAS_SPARSE, bool HAS_DENSE>
-__global__ __launch_bounds__(W * 64) void emb_fwd_uniform(
-    UniformArgs args, int ns, int nd, int64_t B, int F, float* __restrict__ first_order,
-    float* __restrict__ fe, float* __restrict__ fm_out, int32_t* error_flag) {
+__device__ __forceinline__ void emb_fwd_uniform_body(
+    const UniformArgs& args, int ns, int nd, int64_t B, int F, float* __restrict__ first_order,
+    float* __restrict__ fe, float* __restrict__ fm_out, int32_t* error_flag, int ablate = 0) {
   constexpr int LPR = D / 4;        // lanes per row (16 B each)
   constexpr int SPW = kWave / LPR;  // samples per wave == samples per block
   constexpr int US = HAS_SPARSE ? 4 : 0;  // sparse slots in flight per wave
@@ -85,7 +90,8 @@ __global__ __launch_bounds__(W * 64) void emb_fwd_uniform(
   // sits between a load and its first use and the waits stay counted, not vmcnt(0).
   // Slots past the end are clamped to slot 0 (a duplicate, cache-hitting load) and masked.
   const int sp_iters = HAS_SPARSE ? (ns + W * 4 - 1) / (W * 4) : 0;
-  const int de_iters = HAS_DENSE ? (nd + W * 2 - 1) / (W * 2) : 0;
+  const int de_iters = (HAS_DENSE && !(ablate & 2)) ? (nd + W * 2 - 1) / (W * 2) : 0;
+  if (ablate & 2) nd = 0;
   const int iters = sp_iters > de_iters ? sp_iters : de_iters;
   for (int it = 0; it < iters; ++it) {
     bool oks[US + 1], okd[UD + 1];
@@ -126,7 +132,7 @@ __global__ __launch_bounds__(W * 64) void emb_fwd_uniform(
       bad |= oob && oks[u];
       id[u] = oob ? 0 : id[u];
       row[u] = ld4(sl[u].w2 + id[u] * D + q * 4);
-      w1v[u] = sl[u].w1[id[u]];              // same address on the row's lanes: one request
+      w1v[u] = (ablate & 1) ? 0.f : sl[u].w1[id[u]];   // same address on the row's lanes: one request
     }
     float4 ed[UD + 1];
 #pragma unroll
@@ -158,6 +164,7 @@ __global__ __launch_bounds__(W * 64) void emb_fwd_uniform(
       if (live && oks[u]) st4(fe + (b * F + sl[u].field) * D + q * 4, row[u]);
   }
   if (bad && error_flag) atomicOr(error_flag, 1);
+  if (ablate & 4) return;
   if (q != 0) fo = 0.f;  // every lane of a row loaded the same first-order value: count it once
   // ---- fixed-order reduction over the block's waves --------------------------------------
   __shared__ float red[W][9][kWave];
@@ -183,6 +190,22 @@ __global__ __launch_bounds__(W * 64) void emb_fwd_uniform(
       if (fm_out) fm_out[b] = 0.5f * t;
     }
   }
+}
+
+// slot tables in the kernel-argument segment ...
+template <int D, int W, bool HAS_SPARSE, bool HAS_DENSE>
+__global__ __launch_bounds__(W * 64) void emb_fwd_uniform(
+    UniformArgs args, int ns, int nd, int64_t B, int F, float* __restrict__ first_order,
+    float* __restrict__ fe, float* __restrict__ fm_out, int32_t* error_flag, int ablate) {
+  emb_fwd_uniform_body<D, W, HAS_SPARSE, HAS_DENSE>(args, ns, nd, B, F, first_order, fe, fm_out, error_flag, ablate);
+}
+// ... or in device memory owned by the plan (refreshed only when a pointer changes)
+template <int D, int W, bool HAS_SPARSE, bool HAS_DENSE>
+__global__ __launch_bounds__(W * 64) void emb_fwd_uniform_mem(
+    const UniformArgs* __restrict__ args, int ns, int nd, int64_t B, int F,
+    float* __restrict__ first_order, float* __restrict__ fe, float* __restrict__ fm_out,
+    int32_t* error_flag, int ablate) {
+  emb_fwd_uniform_body<D, W, HAS_SPARSE, HAS_DENSE>(*args, ns, nd, B, F, first_order, fe, fm_out, error_flag, ablate);
 }
 
 // ======================================================================================
@@ -452,6 +475,9 @@ extern "C" int dfm_embedding_plan_create(const dfm_field* fields, int num_fields
 
 extern "C" int dfm_embedding_plan_destroy(dfm_embedding_plan* plan) {
   if (!plan) return DFM_OK;
+  (void)hipFree(plan->d_slots);
+  if (plan->h_ring) (void)hipHostFree(plan->h_ring);
+  free(plan->h_shadow);
   (void)hipFree(plan->d_fields);
   (void)hipFree(plan->d_sparse);
   (void)hipFree(plan->d_dense);
@@ -476,6 +502,17 @@ static int fill_ptrs(const dfm_embedding_plan* plan, const void* const* inputs, 
   return DFM_OK;
 }
 
+// timing-only ablation mask for tools/microbench_gather (0 in every product call)
+static int g_ablate = [] { const char* e = getenv("DFM_GATHER_ABLATE"); return e ? atoi(e) : 0; }();
+
+static bool gather_args_in_mem() {
+  static bool v = [] {
+    const char* e = getenv("DFM_GATHER_ARGS");
+    return e && !strcmp(e, "device");
+  }();
+  return v;
+}
+
 static int gather_waves() {
   static int w = [] {
     const char* e = getenv("DFM_GATHER_WAVES");
@@ -490,6 +527,7 @@ static int launch_uniform(const dfm_embedding_plan* plan, const PtrTable& in, in
                           float* fo, float* fe, float* fm_out, int32_t* err, hipStream_t st) {
   constexpr int SPW = kWave / (D / 4);
   UniformArgs args;
+  memset(&args, 0, sizeof(args));
   const int ns = static_cast<int>(plan->h_sparse.size()), nd = static_cast<int>(plan->h_dense.size());
   for (int i = 0; i < ns; ++i) {
     const int f = plan->h_sparse[i];
@@ -503,9 +541,33 @@ static int launch_uniform(const dfm_embedding_plan* plan, const PtrTable& in, in
   }
   const dim3 grid(static_cast<unsigned>((B + SPW - 1) / SPW));
   const int F = plan->num_fields;
-#define DFM_GATHER_LAUNCH(WV, HS, HD)                                                              \
-  hipLaunchKernelGGL((emb_fwd_uniform<D, WV, HS, HD>), grid, dim3(WV * 64), 0, st, args, ns, nd, B, \
-                     F, fo, fe, fm_out, err)
+  const UniformArgs* d_args = nullptr;
+  if (gather_args_in_mem()) {
+    constexpr int kRing = 8;
+    auto* mp = const_cast<dfm_embedding_plan*>(plan);
+    if (!mp->d_slots) {
+      DFM_HIP_TRY(hipMalloc(&mp->d_slots, sizeof(UniformArgs)));
+      DFM_HIP_TRY(hipHostMalloc(&mp->h_ring, sizeof(UniformArgs) * kRing, hipHostMallocDefault));
+      mp->h_shadow = calloc(1, sizeof(UniformArgs));
+    }
+    const size_t used = sizeof(SparseSlot) * kMaxSparseSlots + sizeof(DenseSlot) * nd;
+    if (memcmp(mp->h_shadow, &args, used) != 0) {     // a pointer changed: refresh the device copy
+      void* stage = static_cast<char*>(mp->h_ring) + sizeof(UniformArgs) * (mp->ring_pos++ % kRing);
+      memcpy(stage, &args, sizeof(UniformArgs));
+      memcpy(mp->h_shadow, &args, sizeof(UniformArgs));
+      DFM_HIP_TRY(hipMemcpyAsync(mp->d_slots, stage, sizeof(UniformArgs), hipMemcpyHostToDevice, st));
+    }
+    d_args = static_cast<const UniformArgs*>(mp->d_slots);
+  }
+#define DFM_GATHER_LAUNCH(WV, HS, HD)                                                                   \
+  do {                                                                                                  \
+    if (d_args)                                                                                         \
+      hipLaunchKernelGGL((emb_fwd_uniform_mem<D, WV, HS, HD>), grid, dim3(WV * 64), 0, st, d_args, ns,  \
+                         nd, B, F, fo, fe, fm_out, err, g_ablate);                                      \
+    else                                                                                                \
+      hipLaunchKernelGGL((emb_fwd_uniform<D, WV, HS, HD>), grid, dim3(WV * 64), 0, st, args, ns, nd, B, \
+                         F, fo, fe, fm_out, err, g_ablate);                                             \
+  } while (0)
 #define DFM_GATHER_PICK(WV)                                    \
   do {                                                         \
     if (ns > 0 && nd > 0) DFM_GATHER_LAUNCH(WV, true, true);   \

@@ -1,8 +1,12 @@
 """DNN tower (reference ``deepfm/models/layers/dnn.py:9-59``).
 
-Not one of the four hot-path layers (SURVEY.md §2 keeps it on ``torch.nn`` →
-rocBLAS/hipBLASLt); it is mirrored so the three models assemble with the reference's
-``dnn.mlp.<i>`` state_dict layout: ``[Linear, (BatchNorm1d), activation, Dropout] * n``.
+Not one of the four hot-path layers (SURVEY.md §2 keeps it on ``torch.nn``): same
+constructor, ``mlp`` ``nn.Sequential`` and ``dnn.mlp.<i>`` state_dict layout —
+``[Linear, (BatchNorm1d), activation, Dropout] * n``.  The Linear GEMMs always run on
+rocBLAS through torch.  On an MI355X, in training mode with BatchNorm + ReLU (the reference
+default), the BatchNorm -> ReLU -> Dropout chain between two GEMMs runs as the fused HIP
+kernels ``dfm_bn_relu_dropout_forward/backward`` (two launches each way
+instead of about a dozen); every other configuration uses the plain ``nn.Sequential``.
 """
 
 from __future__ import annotations
@@ -11,6 +15,71 @@ from typing import List
 
 import torch
 import torch.nn as nn
+
+from deepfm_amd import _lib
+
+
+def _grad_target(p: torch.Tensor):
+    """An existing, contiguous .grad buffer we may accumulate into directly (the row-sparse
+    optimizer makes every .grad a view of one flat buffer), else None."""
+    g = p.grad
+    return g if (g is not None and g.is_contiguous() and g.dtype == torch.float32) else None
+
+
+class _LinearBnReluDropoutFn(torch.autograd.Function):
+    """One DNN layer: Linear (rocBLAS) -> BatchNorm1d(train) -> ReLU -> Dropout (fused HIP).
+
+    Backward writes parameter gradients straight into existing ``.grad`` buffers
+    (``addmm_`` with beta = 1 for dW, ``+=`` inside the BN kernels) and returns ``None`` for
+    them, which removes one AccumulateGrad add + one zero-fill launch per parameter.  The
+    Linear bias in front of a training-mode BatchNorm has an identically-zero gradient (BN
+    subtracts the batch mean), so none is computed."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, bn: nn.BatchNorm1d, p: float, seed, salt: int):
+        lib = _lib.load()
+        z = torch.addmm(bias, x, weight.t())
+        M, N = z.shape
+        out = torch.empty_like(z)
+        stats = torch.empty(2, N, dtype=torch.float32, device=z.device)
+        ws = torch.empty(max(lib.dfm_bn_workspace_bytes(M, N) // 4, 1), dtype=torch.float32, device=z.device)
+        track = bn.track_running_stats and bn.running_mean is not None
+        _lib.check(lib.dfm_bn_relu_dropout_forward(
+            z.data_ptr(), M, N, gamma.data_ptr(), beta.data_ptr(),
+            bn.running_mean.data_ptr() if track else None, bn.running_var.data_ptr() if track else None,
+            bn.num_batches_tracked.data_ptr() if track else None, float(bn.momentum), float(bn.eps), float(p),
+            _lib.ptr(seed), salt, out.data_ptr(), stats.data_ptr(), ws.data_ptr(), _lib.stream_handle()))
+        ctx.save_for_backward(x, weight, z, gamma, beta, stats)
+        ctx.p, ctx.seed, ctx.salt = p, seed, salt
+        ctx.params = (weight, bias, gamma, beta)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        lib = _lib.load()
+        x, weight, z, gamma, beta, stats = ctx.saved_tensors
+        w_p, b_p, gamma_p, beta_p = ctx.params
+        M, N = z.shape
+        dz = torch.empty_like(z)
+        tg, tb = _grad_target(gamma_p), _grad_target(beta_p)
+        d_gamma = tg if tg is not None else torch.zeros_like(gamma)
+        d_beta = tb if tb is not None else torch.zeros_like(beta)
+        ws = torch.empty(max(lib.dfm_bn_workspace_bytes(M, N) // 4, 1), dtype=torch.float32, device=z.device)
+        _lib.check(lib.dfm_bn_relu_dropout_backward(
+            g_out.contiguous().data_ptr(), z.data_ptr(), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(), M, N,
+            float(ctx.p), _lib.ptr(ctx.seed), ctx.salt, dz.data_ptr(), d_gamma.data_ptr(), d_beta.data_ptr(),
+            ws.data_ptr(), _lib.stream_handle()))
+        tw = _grad_target(w_p)
+        if tw is not None:
+            tw.addmm_(dz.t(), x)                       # dW accumulated in place (beta = 1)
+            d_w = None
+        else:
+            d_w = dz.t() @ x
+        # d bias == 0 exactly (BatchNorm removes the batch mean): leave an existing buffer as is
+        d_b = None if _grad_target(b_p) is not None else torch.zeros_like(b_p)
+        d_x = dz @ weight if ctx.needs_input_grad[0] else None
+        return (d_x, d_w, d_b, None if tg is not None else d_gamma, None if tb is not None else d_beta,
+                None, None, None, None)
 
 
 class DNN(nn.Module):
@@ -35,6 +104,27 @@ class DNN(nn.Module):
             width = units
         self.mlp = nn.Sequential(*stack)
         self.output_dim = width
+        self.fused = True          # use the fused HIP BatchNorm/ReLU/Dropout kernels when eligible
+        self._fusable = use_batch_norm and activation.lower() == "relu"
+        self._n_layers = len(hidden_units)
+        self._seed = None
+
+    def _fused_ok(self, x: torch.Tensor) -> bool:
+        if not (self.fused and self._fusable and self.training and x.is_cuda and x.dtype == torch.float32
+                and x.dim() == 2 and x.shape[0] > 1):
+            return False
+        bn = self.mlp[1]
+        return bn.momentum is not None and bn.affine
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        return self.mlp(x)
+        if not self._fused_ok(x):
+            return self.mlp(x)
+        if self._seed is None or self._seed.device != x.device:
+            self._seed = torch.randint(1, 2 ** 40, (1,), dtype=torch.int64, device=x.device)
+        self._seed.add_(1)
+        h = x
+        for i in range(self._n_layers):
+            lin, bn, _, drop = (self.mlp[4 * i + j] for j in range(4))
+            h = _LinearBnReluDropoutFn.apply(h, lin.weight, lin.bias, bn.weight, bn.bias, bn, drop.p,
+                                             self._seed, i)
+        return h

@@ -104,15 +104,19 @@ class RowSparseTrainStep:
         torch.cuda.synchronize()
         self._gather()
         single = self.opt.world == 1
+        # thread_local capture mode: another thread (the RCCL watchdog polling its events under
+        # data parallelism) must not invalidate the capture
+        mode = dict(capture_error_mode="thread_local")
         self.graph_a = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph_a):
+        with torch.cuda.graph(self.graph_a, **mode):
             self._body_a()
             if single:
                 self._body_b()
         if not single:
             self.opt.exchange()
+            torch.cuda.synchronize()
             self.graph_b = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_b):
+            with torch.cuda.graph(self.graph_b, **mode):
                 self._body_b()
         torch.cuda.synchronize()
 

@@ -245,6 +245,28 @@ int dfm_attention_backward(const float* d_x, const float* d_g_out, int64_t batch
                            const float* const* params, float* d_g_x, float* const* g_params,
                            void* d_workspace, dfm_stream_t stream);
 
+/* ---------------------------------------------------------------------------------
+ * DNN tower glue (reference deepfm/models/layers/dnn.py:45-55): BatchNorm1d (training
+ * statistics) -> ReLU -> Dropout between the Linear GEMMs, two launches each way.
+ *   forward : out = dropout_p(relu(gamma * (z - mean) * rstd + beta)), z (batch, features);
+ *             saves mean / rstd (2, features); updates running_mean / running_var (unbiased,
+ *             momentum) and num_batches_tracked like nn.BatchNorm1d when they are non-NULL
+ *   backward: d z from d out (recomputes y and the dropout mask); ADDS d gamma / d beta
+ * Dropout keeps element i iff hash(*d_seed, salt, i) >= p * 2^32 (scale 1/(1-p)); the seed is
+ * read on the device, so forward and backward agree and a replayed graph gets fresh masks.
+ * ------------------------------------------------------------------------------- */
+size_t dfm_bn_workspace_bytes(int64_t batch, int features);
+int dfm_bn_relu_dropout_forward(const float* d_z, int64_t batch, int features, const float* d_gamma,
+                                const float* d_beta, float* d_running_mean, float* d_running_var,
+                                int64_t* d_num_batches, float momentum, float eps, float p_drop,
+                                const int64_t* d_seed, int salt, float* d_out, float* d_mean_rstd,
+                                void* d_workspace, dfm_stream_t stream);
+int dfm_bn_relu_dropout_backward(const float* d_g_out, const float* d_z, const float* d_mean_rstd,
+                                 const float* d_gamma, const float* d_beta, int64_t batch, int features,
+                                 float p_drop, const int64_t* d_seed, int salt, float* d_g_z,
+                                 float* d_g_gamma, float* d_g_beta, void* d_workspace,
+                                 dfm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,94 @@
+"""GPU: the fused BatchNorm -> ReLU -> Dropout kernels of the DNN tower against torch.nn
+(the reference's own modules, dnn.py:45-55) and the oracle."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ctr_oracle as O
+from tests.helpers import assert_close, npy
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(in_dim, hidden, dropout):
+    from deepfm_amd.models.layers.dnn import DNN
+    torch.manual_seed(0)
+    fused = DNN(in_dim, hidden, "relu", dropout, True).cuda().train()
+    plain = copy.deepcopy(fused)
+    plain.fused = False
+    with torch.no_grad():
+        for m in fused.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.uniform_(-0.3, 0.3)
+        plain.load_state_dict(fused.state_dict())
+    return fused, plain
+
+
+@pytest.mark.parametrize("shape", [(4096, 624, [256, 128, 64]), (37, 10, [7, 5]), (2, 3, [4])])
+def test_fused_matches_torch_modules(shape):
+    B, in_dim, hidden = shape
+    fused, plain = _pair(in_dim, hidden, 0.0)
+    x = torch.randn(B, in_dim, device="cuda") * 2 + 0.5
+    xa, xb = x.clone().requires_grad_(), x.clone().requires_grad_()
+    ya, yb = fused(xa), plain(xb)
+    rtol = 1e-2 if B < 8 else 1e-4        # a batch of 2 makes BatchNorm itself ill-conditioned
+    assert_close(npy(ya), npy(yb), rtol=rtol, what="output")
+    g = torch.randn_like(ya)
+    (ya * g).sum().backward()
+    (yb * g).sum().backward()
+    assert_close(npy(xa.grad), npy(xb.grad), rtol=rtol, what="d_x")
+    for (k, pa), (_, pb) in zip(fused.named_parameters(), plain.named_parameters()):
+        zero_grad = k.endswith(".bias") and int(k.split(".")[1]) % 4 == 0     # Linear bias before BN
+        assert pa.grad is not None, k
+        # (identically-zero gradient: both sides hold rounding noise that grows with the batch)
+        assert_close(npy(pa.grad), npy(pb.grad), rtol=rtol, what=k, floor=1e-3 if zero_grad else 0.0)
+    for (k, ba), (_, bb) in zip(fused.named_buffers(), plain.named_buffers()):
+        if k.endswith("num_batches_tracked"):
+            assert int(ba) == int(bb) == 1
+        else:
+            assert_close(npy(ba), npy(bb), rtol=rtol, what=k)        # running_mean / running_var
+
+
+def test_fused_large_column_mean():
+    """Column means far from zero (|mean| >> std): the shifted-sum variance must not cancel.
+    Compared with torch's BatchNorm on the SAME rocBLAS pre-activations."""
+    fused, plain = _pair(16, [8], 0.0)
+    x = torch.randn(512, 16, device="cuda") * 0.1 + 50.0
+    # (z - mean) itself cancels here (|mean|/std ~ 500): both sides carry ~1e-4 absolute noise
+    assert_close(npy(fused(x)), npy(plain(x)), rtol=5e-3, atol_scale=2e-4, what="large mean")
+    want = O.dnn_forward(npy(x), {k: npy(v) for k, v in plain.state_dict().items()}, 1, training=True)
+    assert_close(npy(fused(x)), want, rtol=5e-2, atol_scale=2e-3, what="oracle (ill-conditioned: loose)")
+
+
+def test_dropout_mask_consistent_and_fresh():
+    fused, _ = _pair(64, [128], 0.25)
+    x = torch.randn(2048, 64, device="cuda").requires_grad_()
+    y = fused(x)
+    keep = (npy(y) != 0)
+    relu_on = keep.mean()
+    assert 0.2 < relu_on < 0.55                      # ~half pass ReLU, 75 % of those are kept
+    g = torch.ones_like(y)
+    y.backward(g)
+    y2 = fused(x.detach())
+    assert (npy(y2) != 0).mean() > 0 and not np.array_equal(npy(y2) != 0, keep)   # new seed, new mask
+    fused.eval()
+    assert torch.isfinite(fused(x.detach())).all()   # eval falls back to nn.Sequential
+
+
+def test_direct_accumulation_into_existing_grad_buffers():
+    """With pre-existing .grad buffers (the row-sparse optimizer's flat views) the layer adds
+    its parameter gradients in place: two backward passes give exactly twice one pass."""
+    fused, plain = _pair(32, [16, 8], 0.0)
+    x = torch.randn(256, 32, device="cuda")
+    g = torch.randn(256, 8, device="cuda")
+    (plain(x) * g).sum().backward()
+    for p in fused.parameters():
+        p.grad = torch.zeros_like(p)
+    for _ in range(2):
+        (fused(x) * g).sum().backward()
+    for (k, pa), (_, pb) in zip(fused.named_parameters(), plain.named_parameters()):
+        zero_grad = k.endswith(".bias") and int(k.split(".")[1]) % 4 == 0
+        assert_close(npy(pa.grad), 2 * npy(pb.grad), rtol=1e-4, what=k, floor=1e-3 if zero_grad else 0.0)
