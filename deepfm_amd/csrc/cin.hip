@@ -33,6 +33,7 @@ struct CinMfmaArgs {
   float* out;
   int64_t B;
   int F, L, out_dim, hid_rows;
+  int ablate;
   CinMfmaLayer layer[kCinMaxLayers];
 };
 struct CinBwdLayer {
@@ -196,6 +197,7 @@ extern "C" int dfm_cin_forward(const float* d_x0, int64_t batch, int num_fields,
     memset(&args, 0, sizeof(args));
     args.x0 = d_x0; args.out = d_out; args.B = batch; args.F = num_fields; args.L = lo.L;
     args.out_dim = lo.out_dim;
+    { const char* e = getenv("DFM_CIN_ABLATE"); args.ablate = e ? atoi(e) : 0; }
     bf16_t* hi = static_cast<bf16_t*>(d_workspace);
     bf16_t* lop = hi + ((packed_total_elems(lo) + 63) / 64) * 64;
     size_t off = 0;

@@ -45,6 +45,7 @@ struct CinMfmaArgs {
   float* out;
   int64_t B;
   int F, L, out_dim, hid_rows;  // hid_rows: rows of the per-wave hidden image in LDS
+  int ablate;                   // timing-only switches (tools/time_layers.py): 1 no staging, 2 no B-gen, 4 no barrier
   CinMfmaLayer layer[kCinMaxLayers];
 };
 
@@ -156,17 +157,19 @@ __global__ __launch_bounds__(kCinWaves * 64, 2) void cin_fwd_mfma(CinMfmaArgs ar
 #pragma unroll
       for (int fg = 0; fg < FG; ++fg, ++ks) {
         const int cur = ks & 1;
-        if (ks + 1 < ksteps) stage_store(cur ^ 1, vh, vl);   // slab ks+1 (loaded one step ago)
-        if (ks + 2 < ksteps) stage_load(ks + 2, vh, vl);
+        if (!(args.ablate & 1)) {
+          if (ks + 1 < ksteps) stage_store(cur ^ 1, vh, vl);   // slab ks+1 (loaded one step ago)
+          if (ks + 2 < ksteps) stage_load(ks + 2, vh, vl);
+        }
         // B operand: Z values of this k-step for the lane's column
         float z[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) z[j] = hv * x0r[fg * 8 + j];
+        for (int j = 0; j < 8; ++j) z[j] = (args.ablate & 2) ? x0r[j] : hv * x0r[fg * 8 + j];
         bf16x8 bh, bl;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           bh[j] = static_cast<__bf16>(z[j]);
-          if (SPLIT) bl[j] = static_cast<__bf16>(z[j] - static_cast<float>(bh[j]));
+          if (SPLIT) bl[j] = (args.ablate & 2) ? bh[j] : static_cast<__bf16>(z[j] - static_cast<float>(bh[j]));
         }
         const unsigned char* base = wbuf + cur * 2 * SLAB;
 #pragma unroll
@@ -181,7 +184,7 @@ __global__ __launch_bounds__(kCinWaves * 64, 2) void cin_fwd_mfma(CinMfmaArgs ar
             }
           }
         }
-        __syncthreads();
+        if (!(args.ablate & 4)) __syncthreads();
       }
     }
     // ---- epilogue: ReLU, sum-pool of the direct channels, hand the next channels over ------

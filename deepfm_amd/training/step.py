@@ -18,9 +18,9 @@ from __future__ import annotations
 from typing import List, Optional
 
 import torch
-import torch.nn.functional as Fnn
 
 from deepfm_amd.data.schema import FeatureType
+from deepfm_amd.training.losses import bce_with_logits_mean
 from deepfm_amd.training.rowsparse import RowSparseAdam
 
 
@@ -78,7 +78,7 @@ class RowSparseTrainStep:
         fe = self.fe.detach().requires_grad_()
         logits = self.model._forward_components(fo, fe, fe.view(self.B, -1))
         # plain BCE: the L2 term (base.py:78-83) is applied as g += 2*l2*p by the optimizer
-        loss = Fnn.binary_cross_entropy_with_logits(logits.view(-1), self.labels)
+        loss = bce_with_logits_mean(logits.view(-1), self.labels)
         loss.backward()
         self.loss.copy_(loss.detach())
         cur.wait_stream(self.side)

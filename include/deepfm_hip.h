@@ -267,6 +267,14 @@ int dfm_bn_relu_dropout_backward(const float* d_g_out, const float* d_z, const f
                                  float* d_g_gamma, float* d_g_beta, void* d_workspace,
                                  dfm_stream_t stream);
 
+/* ---------------------------------------------------------------------------------
+ * BCEWithLogitsLoss, mean reduction (reference deepfm/training/trainer.py:59, 221):
+ * *d_loss = mean(max(z,0) - z*y + log1p(exp(-|z|)));  d_g_logits = (sigmoid(z) - y) / n.
+ * ------------------------------------------------------------------------------- */
+size_t dfm_bce_workspace_bytes(int64_t n);
+int dfm_bce_with_logits(const float* d_logits, const float* d_labels, int64_t n, float* d_loss,
+                        float* d_g_logits, void* d_workspace, dfm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -92,3 +92,22 @@ def test_direct_accumulation_into_existing_grad_buffers():
     for (k, pa), (_, pb) in zip(fused.named_parameters(), plain.named_parameters()):
         zero_grad = k.endswith(".bias") and int(k.split(".")[1]) % 4 == 0
         assert_close(npy(pa.grad), 2 * npy(pb.grad), rtol=1e-4, what=k, floor=1e-3 if zero_grad else 0.0)
+
+
+def test_fused_bce_matches_torch_and_oracle():
+    from deepfm_amd.training.losses import bce_with_logits_mean
+    rng = np.random.default_rng(5)
+    z = (rng.standard_normal(4099) * 6).astype(np.float32)
+    z[:4] = [60.0, -60.0, 0.0, 1e-8]
+    y = (rng.random(4099) < 0.3).astype(np.float32)
+    zt = torch.from_numpy(z).cuda().requires_grad_()
+    loss = bce_with_logits_mean(zt.view(-1, 1), torch.from_numpy(y).cuda())
+    (loss * 3.0).backward()
+    zr = torch.from_numpy(z).cuda().requires_grad_()
+    ref = torch.nn.functional.binary_cross_entropy_with_logits(zr, torch.from_numpy(y).cuda())
+    (ref * 3.0).backward()
+    assert abs(float(loss) - float(ref)) < 1e-6 * max(1.0, abs(float(ref)))
+    assert_close(npy(zt.grad), npy(zr.grad), rtol=1e-5, what="dz")
+    oloss, odz = O.bce_with_logits(z, y)
+    assert abs(float(loss) - float(oloss)) < 1e-5
+    assert_close(npy(zt.grad), 3.0 * odz, rtol=1e-4, what="dz vs oracle")
