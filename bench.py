@@ -162,11 +162,29 @@ def main():
         elapsed = float(t.item())
     loss = float(step.loss.item())
 
+    # calibration, outside the timed region: the same event bracket around an EMPTY kernel
+    from deepfm_amd import _lib
+    lib = _lib.load()
+    empty_ms = []
+    for _ in range(30):
+        s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s0.record()
+        lib.dfm_debug_empty_launch(_lib.stream_handle())
+        s1.record()
+        empty_ms.append((s0, s1))
+    torch.cuda.synchronize()
+    empty_us = sum(a.elapsed_time(b) for a, b in empty_ms) / len(empty_ms) * 1e3
+
     gather_ms = [s.elapsed_time(e) for s, e in (step.gather_events or [])]
     gather_avg_s = (sum(gather_ms) / len(gather_ms)) * 1e-3 if gather_ms else float("nan")
     algo_bytes = gather_bytes_per_sample(n_sparse, n_dense, D) * B
     achieved = algo_bytes / gather_avg_s / 1e9
 
+    pmc = None
+    pmc_path = os.path.join(ROOT, "profiles", "r01_gather_pmc.json")
+    if os.path.exists(pmc_path) and B == 4096 and V == 1_000_000 and D == 16:
+        with open(pmc_path) as fh:
+            pmc = json.load(fh)
     if rank == 0:
         out = {
             "metric": "train samples/sec DeepFM Criteo-shape bs4096",
@@ -197,11 +215,13 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": pmc["traffic_bytes_per_launch"] if pmc else None,
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "avg_launch_us": gather_avg_s * 1e6,
                 "launches_timed": len(gather_ms),
                 "timer": "HIP events around each launch on the launch stream, inside the timed region",
+                "event_bracket_of_empty_kernel_us": empty_us,
+                "rocprof": pmc,
             },
         }
         if world == 1 and not args.no_cpu_baseline:

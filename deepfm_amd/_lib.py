@@ -49,6 +49,7 @@ SIGNATURES = {
     "dfm_abi_version": (_I, []),
     "dfm_last_error": (C.c_char_p, []),
     "dfm_device_info": (_I, [_P, _P, C.c_char_p, _I]),
+    "dfm_debug_empty_launch": (_I, [_P]),
     "dfm_embedding_plan_create": (_I, [C.POINTER(Field), _I, _I, C.POINTER(_P)]),
     "dfm_embedding_plan_destroy": (_I, [_P]),
     "dfm_embedding_plan_is_uniform": (_I, [_P]),

@@ -41,6 +41,8 @@ int dfm_abi_version(void);
 const char* dfm_last_error(void);
 /* CU count, wavefront size and gcnArchName of the current device. */
 int dfm_device_info(int* cu_count, int* wave_size, char* arch, int arch_len);
+/* Launches an empty kernel (timing calibration of event brackets in bench.py). */
+int dfm_debug_empty_launch(dfm_stream_t stream);
 
 /* ---------------------------------------------------------------------------------
  * FeatureEmbedding  (reference deepfm/models/layers/embedding.py:20-126)
