@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--dim", type=int, default=16)
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--unpacked", action="store_true", help="keep the tables as separate contiguous tensors")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
 
@@ -130,6 +131,8 @@ def main():
     with torch.device(dev):
         model = create_model("deepfm", schema_from_fields(fields), cfg)
     model.train()
+    if not args.unpacked:
+        model.embedding.pack_tables_()        # 256-B row records: [w2 | w1 m1 v1 | m2 | v2]
     model.embedding.set_grad_mode("rowsparse")
     hp = dict(lr=cfg.training.lr, l2=cfg.feature.embedding_l2_reg, max_grad_norm=cfg.training.gradient_clip_norm)
     opt = RowSparseAdam(model, lr=hp["lr"], l2=hp["l2"], max_grad_norm=hp["max_grad_norm"])
@@ -206,6 +209,7 @@ def main():
                 "global_batch": B * world,
                 "parallelism": f"dp{world}",
                 "hip_graph": not args.no_graph,
+                "table_layout": "separate tensors" if args.unpacked else "packed 256-B row records",
                 "final_loss": loss,
             },
             "roofline": {

@@ -26,7 +26,8 @@ c_int_p = C.c_void_p
 class Field(C.Structure):
     """struct dfm_field"""
     _fields_ = [("kind", C.c_int32), ("dim", C.c_int32), ("vocab", C.c_int32), ("max_len", C.c_int32),
-                ("combiner", C.c_int32), ("flat_offset", C.c_int32),
+                ("combiner", C.c_int32), ("flat_offset", C.c_int32), ("stride2", C.c_int32),
+                ("stride1", C.c_int32),
                 ("w2", C.c_void_p), ("b2", C.c_void_p), ("w1", C.c_void_p), ("b1", C.c_void_p),
                 ("proj", C.c_void_p)]
 
@@ -40,7 +41,8 @@ class FieldGrad(C.Structure):
 class Table(C.Structure):
     """struct dfm_table"""
     _fields_ = [("w2", C.c_void_p), ("m2", C.c_void_p), ("v2", C.c_void_p),
-                ("w1", C.c_void_p), ("m1", C.c_void_p), ("v1", C.c_void_p)]
+                ("w1", C.c_void_p), ("m1", C.c_void_p), ("v1", C.c_void_p),
+                ("stride2", C.c_int32), ("stride1", C.c_int32)]
 
 
 # name -> (restype, argtypes); must list every symbol of include/deepfm_hip.h

@@ -49,6 +49,8 @@ struct SparseSlot {
   const float* w1;
   int32_t vocab;
   int32_t field;
+  int32_t stride2;  // floats between rows of w2 / w1 (packed row records: the record size)
+  int32_t stride1;
 };
 struct DenseSlot {
   const float* x;
@@ -59,7 +61,7 @@ struct DenseSlot {
   int32_t field;
   int32_t pad;
 };
-constexpr int kMaxSparseSlots = 64, kMaxDenseSlots = 32;
+constexpr int kMaxSparseSlots = 48, kMaxDenseSlots = 32;   // 48*40 + 32*48 B of kernel arguments
 struct UniformArgs {
   SparseSlot sp[kMaxSparseSlots];
   DenseSlot de[kMaxDenseSlots];
@@ -131,8 +133,8 @@ __device__ __forceinline__ void emb_fwd_uniform_body(
       const bool oob = static_cast<uint64_t>(id[u]) >= static_cast<uint64_t>(sl[u].vocab);
       bad |= oob && oks[u];
       id[u] = oob ? 0 : id[u];
-      row[u] = ld4(sl[u].w2 + id[u] * D + q * 4);
-      w1v[u] = (ablate & 1) ? 0.f : sl[u].w1[id[u]];   // same address on the row's lanes: one request
+      row[u] = ld4(sl[u].w2 + id[u] * sl[u].stride2 + q * 4);
+      w1v[u] = (ablate & 1) ? 0.f : sl[u].w1[id[u] * sl[u].stride1];   // same address on the row's lanes: one request
     }
     float4 ed[UD + 1];
 #pragma unroll
@@ -248,9 +250,9 @@ __global__ void emb_fwd_general(const dfm_field* __restrict__ fields, PtrTable i
   float fo;
   if (fd.kind == DFM_SPARSE) {
     const int64_t id = checked_id(static_cast<const int64_t*>(in.p[f])[b], fd.vocab, error_flag);
-    const float* row = fd.w2 + id * d;
+    const float* row = fd.w2 + id * fd.stride2;
     for (int j = 0; j < d; ++j) flat_row[j] = row[j];
-    fo = fd.w1[id];
+    fo = fd.w1[id * fd.stride1];
   } else if (fd.kind == DFM_DENSE) {
     const float x = static_cast<const float*>(in.p[f])[b];
     for (int j = 0; j < d; ++j) flat_row[j] = fmaf(x, fd.w2[j], fd.b2[j]);
@@ -258,8 +260,8 @@ __global__ void emb_fwd_general(const dfm_field* __restrict__ fields, PtrTable i
   } else {
     const int64_t* ids = static_cast<const int64_t*>(in.p[f]) + b * fd.max_len;
     for (int j = 0; j < d; ++j)
-      flat_row[j] = bag_pool(fd.w2, d, j, ids, fd.max_len, fd.vocab, fd.combiner, error_flag);
-    fo = bag_pool(fd.w1, 1, 0, ids, fd.max_len, fd.vocab, fd.combiner, error_flag);
+      flat_row[j] = bag_pool(fd.w2, fd.stride2, j, ids, fd.max_len, fd.vocab, fd.combiner, error_flag);
+    fo = bag_pool(fd.w1, fd.stride1, 0, ids, fd.max_len, fd.vocab, fd.combiner, error_flag);
   }
   fo_parts[b * F + f] = fo;
   if (fd.proj) {
@@ -332,7 +334,7 @@ __global__ void emb_bwd_scatter(const dfm_field* __restrict__ fields, PtrTable i
   if (fd.combiner == DFM_MAX) {
     for (int j = 0; j <= d; ++j) {  // j == d: the (V,1) first-order table
       const float* table = j < d ? fd.w2 : fd.w1;
-      const int stride = j < d ? d : 1, col = j < d ? j : 0;
+      const int stride = j < d ? fd.stride2 : fd.stride1, col = j < d ? j : 0;
       int64_t best = 0;
       float bestv = 0.f;
       for (int l = 0; l < L; ++l) {
@@ -444,6 +446,12 @@ extern "C" int dfm_embedding_plan_create(const dfm_field* fields, int num_fields
       delete plan;
       return fail(DFM_ERR_INVALID, "field %d: inconsistent descriptor", f);
     }
+    if (fd.stride2 == 0) fd.stride2 = fd.dim;
+    if (fd.stride1 == 0) fd.stride1 = 1;
+    if (fd.kind != DFM_DENSE && (fd.stride2 < fd.dim || fd.stride1 < 1 || (uniform && fd.stride2 % 4 != 0))) {
+      delete plan;
+      return fail(DFM_ERR_INVALID, "field %d: bad row strides", f);
+    }
     fd.flat_offset = off;
     off += fd.dim;
     plan->max_dim = fd.dim > plan->max_dim ? fd.dim : plan->max_dim;
@@ -532,7 +540,7 @@ static int launch_uniform(const dfm_embedding_plan* plan, const PtrTable& in, in
   for (int i = 0; i < ns; ++i) {
     const int f = plan->h_sparse[i];
     const dfm_field& fd = plan->h_fields[f];
-    args.sp[i] = SparseSlot{static_cast<const int64_t*>(in.p[f]), fd.w2, fd.w1, fd.vocab, f};
+    args.sp[i] = SparseSlot{static_cast<const int64_t*>(in.p[f]), fd.w2, fd.w1, fd.vocab, f, fd.stride2, fd.stride1};
   }
   for (int i = 0; i < nd; ++i) {
     const int f = plan->h_dense[i];

@@ -63,14 +63,14 @@ __global__ __launch_bounds__(256) void rowadam_merge_kernel(
         }
       }
       const dfm_table tb = tabs.t[s];
-      const float4 w = ld4(tb.w2 + static_cast<int64_t>(row) * D + q * 4);
+      const float4 w = ld4(tb.w2 + static_cast<int64_t>(row) * tb.stride2 + q * 4);
       const float k = 2.f * l2;
       g.x = fmaf(k, w.x, grad_scale * g.x); g.y = fmaf(k, w.y, grad_scale * g.y);
       g.z = fmaf(k, w.z, grad_scale * g.z); g.w = fmaf(k, w.w, grad_scale * g.w);
       st4(row_g2 + (list * CH + u) * D + q * 4, g);
       sq = g.x * g.x + g.y * g.y + g.z * g.z + g.w * g.w;
       if (q == 0) {
-        g1 = fmaf(k, tb.w1[row], grad_scale * g1);
+        g1 = fmaf(k, tb.w1[static_cast<int64_t>(row) * tb.stride1], grad_scale * g1);
         row_g1[list * CH + u] = g1;
         sq = fmaf(g1, g1, sq);
       }
@@ -117,30 +117,35 @@ __global__ __launch_bounds__(256) void rowadam_apply_kernel(
   const float inv_bc2_sqrt = 1.f / sqrtf(bc2);
   const dfm_table tb = tabs.t[s];
   float4 g = ld4(row_g2 + (list * CH + u) * D + q * 4);
-  float4 w = ld4(tb.w2 + row * D + q * 4);
-  float4 m = ld4(tb.m2 + row * D + q * 4);
-  float4 v = ld4(tb.v2 + row * D + q * 4);
+  const int64_t o2 = row * tb.stride2 + q * 4, o1 = row * tb.stride1;
+  float4 w = ld4(tb.w2 + o2);
+  float4 m = ld4(tb.m2 + o2);
+  float4 v = ld4(tb.v2 + o2);
   adam1(w.x, m.x, v.x, g.x * clip, b1, b2, step_size, inv_bc2_sqrt, eps);
   adam1(w.y, m.y, v.y, g.y * clip, b1, b2, step_size, inv_bc2_sqrt, eps);
   adam1(w.z, m.z, v.z, g.z * clip, b1, b2, step_size, inv_bc2_sqrt, eps);
   adam1(w.w, m.w, v.w, g.w * clip, b1, b2, step_size, inv_bc2_sqrt, eps);
-  st4(tb.w2 + row * D + q * 4, w);
-  st4(tb.m2 + row * D + q * 4, m);
-  st4(tb.v2 + row * D + q * 4, v);
+  st4(tb.w2 + o2, w);
+  st4(tb.m2 + o2, m);
+  st4(tb.v2 + o2, v);
   if (q == 0) {
-    float w1 = tb.w1[row], m1 = tb.m1[row], v1 = tb.v1[row];
+    float w1 = tb.w1[o1], m1 = tb.m1[o1], v1 = tb.v1[o1];
     adam1(w1, m1, v1, row_g1[list * CH + u] * clip, b1, b2, step_size, inv_bc2_sqrt, eps);
-    tb.w1[row] = w1; tb.m1[row] = m1; tb.v1[row] = v1;
+    tb.w1[o1] = w1; tb.m1[o1] = m1; tb.v1[o1] = v1;
   }
 }
 
-static int fill_tables(const dfm_table* tables, int S, TableArgs* out, bool need_state) {
+static int fill_tables(const dfm_table* tables, int S, int D, TableArgs* out, bool need_state) {
   memset(out, 0, sizeof(*out));
   for (int s = 0; s < S; ++s) {
     DFM_REQUIRE(tables[s].w2 && tables[s].w1, "table %d: null weights", s);
     if (need_state)
       DFM_REQUIRE(tables[s].m2 && tables[s].v2 && tables[s].m1 && tables[s].v1, "table %d: null Adam state", s);
     out->t[s] = tables[s];
+    if (out->t[s].stride2 == 0) out->t[s].stride2 = D;
+    if (out->t[s].stride1 == 0) out->t[s].stride1 = 1;
+    DFM_REQUIRE(out->t[s].stride2 >= D && out->t[s].stride2 % 4 == 0 && out->t[s].stride1 >= 1,
+                "table %d: bad row strides", s);
   }
   return DFM_OK;
 }
@@ -165,7 +170,7 @@ int dfm_rowadam_merge(const dfm_table* tables, int num_sparse, int dim, int num_
   DFM_REQUIRE(num_sparse > 0 && num_sparse <= DFM_MAX_FIELDS && num_lists > 0, "bad sizes");
   DFM_REQUIRE(dim > 0 && dim % 4 == 0 && dim <= 256, "dim must be a multiple of 4 and <= 256");
   TableArgs ta;
-  if (int rc = fill_tables(tables, num_sparse, &ta, false)) return rc;
+  if (int rc = fill_tables(tables, num_sparse, dim, &ta, false)) return rc;
   const int64_t blocks = merge_blocks(num_sparse, dim, num_lists);
   hipStream_t st = as_stream(stream);
   float* partial = d_partials;
@@ -186,7 +191,7 @@ int dfm_rowadam_apply(const dfm_table* tables, int num_sparse, int dim, int num_
   DFM_REQUIRE(num_sparse > 0 && num_sparse <= DFM_MAX_FIELDS && num_lists > 0, "bad sizes");
   DFM_REQUIRE(dim > 0 && dim % 4 == 0 && dim <= 256, "dim must be a multiple of 4 and <= 256");
   TableArgs ta;
-  if (int rc = fill_tables(tables, num_sparse, &ta, true)) return rc;
+  if (int rc = fill_tables(tables, num_sparse, dim, &ta, true)) return rc;
   const int64_t blocks = merge_blocks(num_sparse, dim, num_lists);
   hipLaunchKernelGGL(rowadam_apply_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0,
                      as_stream(stream), ta, num_sparse, dim, num_lists, d_uniq_rows, d_num_uniq,

@@ -83,6 +83,7 @@ class FeatureEmbedding(nn.Module):
         self.grad_mode = "dense"
         self.strict_indices = os.environ.get("DEEPFM_AMD_STRICT_INDICES", "0") == "1"
         self.rowsparse: Optional[RowSparseBuffers] = None
+        self.packed: Dict[str, dict] = {}      # filled by pack_tables_()
         self._plan = None
         self._plan_key = None
         self._plan_uniform = False
@@ -131,6 +132,35 @@ class FeatureEmbedding(nn.Module):
                 out += [second.weight, first.weight]
         return out
 
+    def pack_tables_(self) -> "FeatureEmbedding":
+        """Re-home every SPARSE table in a packed row-record buffer on the current device.
+
+        One record per id, ``RS = roundup(3*d + 4, 32)`` floats (256 B at d = 16):
+        ``[w2 (d) | w1, m1, v1, pad | m2 (d) | v2 (d) | pad]``.  ``second_order_embeddings.<f>.weight``
+        and ``first_order_embeddings.<f>.weight`` become strided views of it (same shapes, same
+        values, same state_dict keys), so the forward's first-order scalar rides on the row's
+        128-B line and ``RowSparseAdam`` — which places its moments in the same records — touches
+        one contiguous record per row instead of six scattered locations.  MI355X-first layout:
+        4x the table bytes, paid from 288 GB of HBM.  Call after ``.to(device)`` (which
+        re-materialises parameters contiguously) and before creating the optimizer."""
+        self.packed = {}
+        for name, spec, second, first, _ in self._field_params():
+            if spec.feature_type is not FeatureType.SPARSE:
+                continue
+            d, V = spec.embedding_dim, spec.vocabulary_size
+            if d % 4:
+                raise NotImplementedError("packed row records need embedding_dim % 4 == 0")
+            rs = ((3 * d + 4 + 31) // 32) * 32
+            buf = torch.zeros(V, rs, dtype=torch.float32, device=second.weight.device)
+            buf[:, :d].copy_(second.weight.data)
+            buf[:, d:d + 1].copy_(first.weight.data)
+            second.weight.data = buf[:, :d]
+            first.weight.data = buf[:, d:d + 1]
+            self.packed[name] = dict(buffer=buf, m1=buf[:, d + 1:d + 2], v1=buf[:, d + 2:d + 3],
+                                     m2=buf[:, d + 4:2 * d + 4], v2=buf[:, 2 * d + 4:3 * d + 4])
+        self._drop_plan()
+        return self
+
     def non_table_parameters(self) -> List[nn.Parameter]:
         tables = {id(p) for p in self.table_parameters()}
         return [p for p in self.parameters() if id(p) not in tables]
@@ -153,7 +183,7 @@ class FeatureEmbedding(nn.Module):
     # ------------------------------------------------------------------ plan
     def _ensure_plan(self, device: torch.device):
         params = list(self.parameters())
-        key = (device, tuple(p.data_ptr() for p in params))
+        key = (device, tuple((p.data_ptr(), p.stride(0)) for p in params))
         if self._plan is not None and key == self._plan_key:
             return self._plan
         self._drop_plan()
@@ -165,8 +195,9 @@ class FeatureEmbedding(nn.Module):
         for i, (name, spec, second, first, proj) in enumerate(self._field_params()):
             for p in (second.weight, first.weight):
                 _lib.require_device(p, f"parameter of field {name!r}")
-                if p.dtype != torch.float32 or not p.is_contiguous():
-                    raise TypeError("embedding parameters must be contiguous float32")
+                # rows may be strided (packed row records), elements of a row are contiguous
+                if p.dtype != torch.float32 or p.dim() != 2 or (p.shape[1] > 1 and p.stride(1) != 1):
+                    raise TypeError("embedding parameters must be float32 with contiguous rows")
             fd = arr[i]
             fd.kind = _KIND[spec.feature_type]
             fd.dim = spec.embedding_dim
@@ -174,6 +205,8 @@ class FeatureEmbedding(nn.Module):
             fd.max_len = spec.max_length
             fd.combiner = _lib.COMBINER[spec.combiner] if spec.feature_type is FeatureType.SEQUENCE else 0
             fd.w2, fd.w1 = second.weight.data_ptr(), first.weight.data_ptr()
+            if spec.feature_type is not FeatureType.DENSE:
+                fd.stride2, fd.stride1 = second.weight.stride(0), first.weight.stride(0)
             if spec.feature_type is FeatureType.DENSE:
                 fd.b2, fd.b1 = second.bias.data_ptr(), first.bias.data_ptr()
             fd.proj = proj.weight.data_ptr() if proj is not None else None

@@ -31,6 +31,7 @@ import torch
 import torch.distributed as dist
 
 from deepfm_amd import _lib
+from deepfm_amd.data.schema import FeatureType
 from deepfm_amd.training import exchange
 from deepfm_amd.models.layers.embedding import FeatureEmbedding
 
@@ -56,8 +57,20 @@ class RowSparseAdam:
         self.device = dev
         self.num_sparse = len(tables) // 2
         self.dim = emb.fm_embed_dim
-        self.exp_avg = [torch.zeros_like(p) for p in tables]
-        self.exp_avg_sq = [torch.zeros_like(p) for p in tables]
+        # Adam moments: inside the packed row records when the embedding was packed
+        # (FeatureEmbedding.pack_tables_), else separate contiguous tensors
+        self.exp_avg, self.exp_avg_sq = [], []
+        sparse_names = [n for n, spec in model.schema.fields.items() if spec.feature_type is FeatureType.SPARSE]
+        for name, w2, w1 in zip(sparse_names, tables[0::2], tables[1::2]):
+            rec = emb.packed.get(name) if getattr(emb, "packed", None) else None
+            if rec is not None and rec["buffer"].data_ptr() == w2.data_ptr():
+                self.exp_avg += [rec["m2"], rec["m1"]]
+                self.exp_avg_sq += [rec["v2"], rec["v1"]]
+            else:
+                self.exp_avg += [torch.zeros_like(w2, memory_format=torch.contiguous_format),
+                                 torch.zeros_like(w1, memory_format=torch.contiguous_format)]
+                self.exp_avg_sq += [torch.zeros_like(w2, memory_format=torch.contiguous_format),
+                                    torch.zeros_like(w1, memory_format=torch.contiguous_format)]
         self._tables = tables
         self.step_count = torch.zeros(1, dtype=torch.int32, device=dev)
         self.sq_norm = torch.zeros(1, dtype=torch.float32, device=dev)
@@ -102,6 +115,12 @@ class RowSparseAdam:
             t.w2, t.w1 = self._tables[2 * s].data_ptr(), self._tables[2 * s + 1].data_ptr()
             t.m2, t.m1 = self.exp_avg[2 * s].data_ptr(), self.exp_avg[2 * s + 1].data_ptr()
             t.v2, t.v1 = self.exp_avg_sq[2 * s].data_ptr(), self.exp_avg_sq[2 * s + 1].data_ptr()
+            t.stride2, t.stride1 = self._tables[2 * s].stride(0), self._tables[2 * s + 1].stride(0)
+            for a, b in ((self.exp_avg[2 * s], t.stride2), (self.exp_avg_sq[2 * s], t.stride2),
+                         (self.exp_avg[2 * s + 1], t.stride1), (self.exp_avg_sq[2 * s + 1], t.stride1)):
+                if a.stride(0) != b:
+                    raise RuntimeError("Adam state and table row strides differ (re-create the optimizer after "
+                                       "pack_tables_() / .to())")
         return arr
 
     # ------------------------------------------------------------------ step

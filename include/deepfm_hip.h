@@ -61,6 +61,8 @@ typedef struct dfm_field {
   int32_t max_len;     /* SEQUENCE: ids per bag (L) */
   int32_t combiner;    /* SEQUENCE: dfm_combiner */
   int32_t flat_offset; /* column of this field inside flat_embeddings */
+  int32_t stride2;     /* floats between consecutive rows of w2 (0 = dim: contiguous) */
+  int32_t stride1;     /* floats between consecutive rows of w1 (0 = 1: contiguous) */
   const float* w2;
   const float* b2;
   const float* w1;
@@ -155,7 +157,15 @@ int dfm_rowgrad_build(const int32_t* field_of_sparse, int num_sparse, int num_fi
  * Pass A (dfm_rowadam_merge) writes the merged gradients in place and one partial sum of
  * |g|^2 per block into d_partials[0 .. dfm_rowadam_num_partials); pass B
  * (dfm_rowadam_apply) reads *d_clip_coef (NULL = 1). */
-typedef struct dfm_table { float* w2; float* m2; float* v2; float* w1; float* m1; float* v1; } dfm_table;
+typedef struct dfm_table {
+  float* w2; float* m2; float* v2;   /* (V, dim) weights and Adam moments, row stride `stride2` floats */
+  float* w1; float* m1; float* v1;   /* (V, 1) first-order ones, row stride `stride1` floats */
+  int32_t stride2;                   /* 0 = dim (contiguous tensors) */
+  int32_t stride1;                   /* 0 = 1 */
+} dfm_table;
+/* Packed row records (FeatureEmbedding.pack_tables_): all six arrays are views of one (V, RS)
+ * buffer — [w2 | w1 m1 v1 pad | m2 | v2 | pad], RS a multiple of 32 floats — so a row's forward
+ * reads hit one 128-B line and its Adam update touches one contiguous record. */
 
 int64_t dfm_rowadam_num_partials(int num_sparse, int dim, int num_lists);
 int dfm_rowadam_merge(const dfm_table* tables, int num_sparse, int dim, int num_lists,

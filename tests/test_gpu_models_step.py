@@ -254,3 +254,54 @@ def test_merge_of_two_simulated_ranks_vs_oracle():
             assert_close(got[key], w, rtol=1e-4, atol_scale=0.0, floor=2e-5, what=key)
             untouched = np.setdiff1d(np.arange(w.shape[0]), u)
             assert np.array_equal(got[key][untouched], w_before[key][untouched])   # only touched rows move
+
+
+def test_packed_row_records_are_bitwise_equivalent():
+    """FeatureEmbedding.pack_tables_(): same values, same state_dict, bit-identical forward and
+    bit-identical training steps as the separate-tensor layout (only addresses change)."""
+    from deepfm_amd.training.rowsparse import RowSparseAdam
+    from deepfm_amd.training.step import RowSparseTrainStep
+    B = 768
+    rng = np.random.default_rng(17)
+    fields = criteo_fields(300, 16)
+    ids, dense, labels = _pool(fields, 3, B, rng)
+    finals = []
+    for packed in (False, True):
+        _, _, model = _small_deepfm(seed=6)
+        before = {k: npy(v).copy() for k, v in model.state_dict().items()}
+        if packed:
+            model.embedding.pack_tables_()
+            after = {k: npy(v) for k, v in model.state_dict().items()}
+            assert sorted(before) == sorted(after)
+            for k in before:
+                assert np.array_equal(before[k], after[k]), k
+            w = model.embedding.second_order_embeddings["C1"].weight
+            assert w.shape == (300, 16) and w.stride(0) == 64
+        model.embedding.set_grad_mode("rowsparse")
+        opt = RowSparseAdam(model, lr=1e-3, l2=1e-5, max_grad_norm=1.0)
+        step = RowSparseTrainStep(model, opt, B, use_graph=False)
+        for i in range(3):
+            step.load_batch(torch.from_numpy(ids[i]).cuda(), torch.from_numpy(dense[i]).cuda(), torch.from_numpy(labels[i]).cuda())
+            step.run()
+        torch.cuda.synchronize()
+        finals.append({k: npy(v).copy() for k, v in model.state_dict().items()})
+        with torch.no_grad():   # dense-gradient mode also works on packed tables
+            pass
+    for k in finals[0]:
+        assert np.array_equal(finals[0][k], finals[1][k]), f"packed layout changed {k}"
+
+
+def test_packed_tables_dense_grad_mode_vs_golden():
+    from deepfm_amd.models.layers.embedding import FeatureEmbedding
+    g = load("emb_criteo_d16")
+    emb = load_params(FeatureEmbedding(schema_from_fields(fields_of(g)), 16), group(g, "param/"))
+    emb.pack_tables_()
+    emb.strict_indices = True
+    fo, fe, fl = emb(to_device_batch(group(g, "batch/")))
+    assert np.array_equal(npy(fe)[:, :26], g["out/field_embeddings"][:, :26])
+    assert_close(npy(fo), g["out/first_order"], what="fo")
+    up = {k: torch.from_numpy(g["upstream/" + k]).cuda() for k in ("first_order", "field_embeddings", "flat_embeddings")}
+    ((fo * up["first_order"]).sum() + (fe * up["field_embeddings"]).sum() + (fl * up["flat_embeddings"]).sum()).backward()
+    want = group(g, "grad/")
+    for k, p in emb.named_parameters():
+        assert_close(npy(p.grad), want[k], what=k)
