@@ -83,6 +83,8 @@ SIGNATURES = {
     "dfm_bn_relu_dropout_backward": (_I, [_P, _P, _P, _P, _P, _L, _I, _F, _P, _I, _P, _P, _P, _P, _P]),
     "dfm_bce_workspace_bytes": (_SZ, [_L]),
     "dfm_bce_with_logits": (_I, [_P, _P, _L, _P, _P, _P, _P]),
+    "dfm_gemm_workspace_bytes": (_SZ, [_I, _I, _I]),
+    "dfm_gemm_f32": (_I, [_P, _L, _I, _P, _L, _I, _P, _L, _I, _I, _I, _P, _I, _P, _P]),
     "dfm_fm_forward": (_I, [_P, _L, _I, _I, _P, _P]),
     "dfm_fm_backward": (_I, [_P, _P, _L, _I, _I, _P, _P]),
 }

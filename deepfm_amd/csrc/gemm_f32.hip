@@ -1,0 +1,232 @@
+// Exact-fp32 GEMM on the gfx950 matrix cores for the DNN tower's Linear layers
+// (reference dnn.py:45-47: nn.Linear forward/backward = aten::addmm / mm).
+//
+//   C[m,n] (+)= sum_k A(m,k) * B(n,k) (+ bias[n])
+// Each operand is "K-contiguous" (element (r,k) at base[r*ld + k]) or "K-strided" (element (r,k)
+// at base[k*ld + r]); the three GEMMs of a Linear layer are then this one kernel, no transposes:
+//   forward  z  = x W^T + b : A = x  (KC),  B = W (KC)
+//   d input  dx = dz W      : A = dz (KC),  B = W (K-strided: element (k_in, n) at W[n*K + k_in])
+//   d weight dW += dz^T x   : A = dz (K-strided over the batch), B = x (K-strided), accumulate
+//
+// v_mfma_f32_32x32x2_f32: fp32 inputs, fp32 accumulate — bit-for-bit a k-ordered fmaf chain
+// (MI355X_MICROARCH.md, matrix cores), 64 FLOP/clk/SIMD = the fp32 vector peak, so nothing is
+// rounded to bf16 and the 1e-4 parity bar is untouched.  The shapes are small (batch 4096 x
+// <= 1024), so the tile is small too: a workgroup of 4 waves owns a 64 x 64 output tile (one
+// 32 x 32 MFMA tile per wave) — 1024 waves for the 4096 x 256 layer — and stages 64 x 32 slices
+// of A and B through LDS (coalesced 16-byte global loads in either layout, padded rows so the
+// per-lane fragment reads are conflict-free), double buffered.  Small outputs with a long
+// reduction (dW: reduce over the batch) are split over workgroup rows into slabs that are added
+// in a fixed order.
+#include "common.h"
+
+using namespace dfm;
+
+namespace {
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 64, BN = 64, BK = 32;
+constexpr int LDS_STRIDE = BK + 1;               // padded row: bank = (row + k) % 32
+constexpr int kThreads = 256;
+
+// Stage a (64 rows x 32 k) slice of an operand into LDS as [row][k] (stride 33).
+//   KC:      global element (r, k) at base[r*ld + k]  -> float4 along k
+//   strided: global element (r, k) at base[k*ld + r]  -> float4 along r
+// FAST (chosen on the host): every 16-byte piece is either entirely inside the operand or
+// entirely outside (leading dimension and base 16-byte aligned, the vectorised extent a
+// multiple of 4), so the load is branch-free: clamp the address, load, select zero.  Otherwise
+// the guarded element-wise path runs (ragged shapes; correctness only).
+template <bool KC, bool FAST>
+__device__ __forceinline__ void load_slice(const float* __restrict__ base, int64_t ld, int r0, int rows, int k0,
+                                           int kend, float4 (&v)[2], bool (&okv)[2]) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int p = tid + i * kThreads;             // 512 float4 pieces per slice
+    int r, k;
+    if (KC) { r = r0 + (p >> 3); k = k0 + (p & 7) * 4; }        // 8 pieces per row, along k
+    else    { k = k0 + (p >> 4); r = r0 + (p & 15) * 4; }       // 16 pieces per k, along r
+    const int64_t off = KC ? static_cast<int64_t>(r) * ld + k : static_cast<int64_t>(k) * ld + r;
+    if (FAST) {
+      // the zero-select is applied at the LDS store: consuming the value here would make the
+      // compiler wait for this load before the MFMAs of the current slice
+      okv[i] = r < rows && k < kend;
+      v[i] = ld4(base + (okv[i] ? off : 0));
+    } else {
+      float e[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool ok = KC ? (r < rows && k + j < kend) : (k < kend && r + j < rows);
+        e[j] = ok ? base[off + (KC ? j : j)] : 0.f;
+      }
+      v[i] = make_float4(e[0], e[1], e[2], e[3]);
+      okv[i] = true;
+    }
+  }
+}
+
+template <bool KC>
+__device__ __forceinline__ void store_slice(float* __restrict__ lds, const float4 (&vin)[2], const bool (&okv)[2]) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int p = tid + i * kThreads;
+    float4 v[2];
+    v[i] = okv[i] ? vin[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (KC) {
+      const int row = p >> 3, kq = (p & 7) * 4;
+      float* d = lds + row * LDS_STRIDE + kq;
+      d[0] = v[i].x; d[1] = v[i].y; d[2] = v[i].z; d[3] = v[i].w;
+    } else {
+      const int kk = p >> 4, rq = (p & 15) * 4;
+      float* d = lds + rq * LDS_STRIDE + kk;
+      d[0] = v[i].x; d[LDS_STRIDE] = v[i].y; d[2 * LDS_STRIDE] = v[i].z; d[3 * LDS_STRIDE] = v[i].w;
+    }
+  }
+}
+}  // namespace
+
+// grid (tiles_n, tiles_m, splits)
+template <bool A_KC, bool B_KC, bool A_FAST, bool B_FAST>
+__global__ __launch_bounds__(kThreads) void gemm_f32_kernel(
+    const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb, float* __restrict__ C,
+    int64_t ldc, int M, int N, int K, const float* __restrict__ bias, int accumulate, int k_per_split,
+    float* __restrict__ slabs) {
+  __shared__ float lds_a[2][BM * LDS_STRIDE];
+  __shared__ float lds_b[2][BN * LDS_STRIDE];
+  const int lane = lane_id(), wave = wave_id_uniform();
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;   // this wave's 32x32 tile inside the block tile
+  const int kb = blockIdx.z * k_per_split;
+  const int ke = kb + k_per_split < K ? kb + k_per_split : K;
+  f32x16 acc = {};
+  float4 va[2], vb[2];
+  bool oka[2], okb[2];
+  load_slice<A_KC, A_FAST>(A, lda, m0, M, kb, ke, va, oka);
+  load_slice<B_KC, B_FAST>(B, ldb, n0, N, kb, ke, vb, okb);
+  store_slice<A_KC>(lds_a[0], va, oka);
+  store_slice<B_KC>(lds_b[0], vb, okb);
+  if (kb + BK < ke) {
+    load_slice<A_KC, A_FAST>(A, lda, m0, M, kb + BK, ke, va, oka);
+    load_slice<B_KC, B_FAST>(B, ldb, n0, N, kb + BK, ke, vb, okb);
+  }
+  __syncthreads();
+  const int r = lane & 31, hf = lane >> 5;
+  int buf = 0;
+  for (int k0 = kb; k0 < ke; k0 += BK, buf ^= 1) {
+    // slice k0+BK (already in registers) -> the other LDS buffer; then fetch slice k0+2*BK
+    if (k0 + BK < ke) {
+      store_slice<A_KC>(lds_a[buf ^ 1], va, oka);
+      store_slice<B_KC>(lds_b[buf ^ 1], vb, okb);
+    }
+    if (k0 + 2 * BK < ke) {
+      load_slice<A_KC, A_FAST>(A, lda, m0, M, k0 + 2 * BK, ke, va, oka);
+      load_slice<B_KC, B_FAST>(B, ldb, n0, N, k0 + 2 * BK, ke, vb, okb);
+    }
+    const float* pa = lds_a[buf] + (wm + r) * LDS_STRIDE + hf;
+    const float* pb = lds_b[buf] + (wn + r) * LDS_STRIDE + hf;
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[kk], pb[kk], acc, 0, 0, 0);
+    __syncthreads();
+  }
+  // accumulator: col n = lane & 31, row m = (reg&3) + 8*(reg>>2) + 4*hf
+  const int n = n0 + wn + r;
+  if (n >= N) return;
+  if (slabs) {
+    float* sl = slabs + static_cast<int64_t>(blockIdx.z) * M * N;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int m = m0 + wm + (reg & 3) + 8 * (reg >> 2) + 4 * hf;
+      if (m < M) sl[static_cast<int64_t>(m) * N + n] = acc[reg];
+    }
+    return;
+  }
+  const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg) {
+    const int m = m0 + wm + (reg & 3) + 8 * (reg >> 2) + 4 * hf;
+    if (m < M) {
+      float* dst = C + static_cast<int64_t>(m) * ldc + n;
+      const float v = acc[reg] + bv;
+      *dst = accumulate ? *dst + v : v;
+    }
+  }
+}
+
+// C[m,n] = (accumulate ? C : 0) + bias[n] + sum_s slabs[s][m][n]   (fixed order)
+__global__ __launch_bounds__(256) void gemm_f32_reduce(const float* __restrict__ slabs, int splits, int M, int N,
+                                                       float* __restrict__ C, int64_t ldc,
+                                                       const float* __restrict__ bias, int accumulate) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (i >= static_cast<int64_t>(M) * N) return;
+  const int m = static_cast<int>(i / N), n = static_cast<int>(i % N);
+  // fixed summation order; loads issued 8 at a time so they overlap instead of chaining
+  float acc = 0.f;
+  int sp = 0;
+  for (; sp + 8 <= splits; sp += 8) {
+    float t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = slabs[static_cast<int64_t>(sp + u) * M * N + i];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += t[u];
+  }
+  for (; sp < splits; ++sp) acc += slabs[static_cast<int64_t>(sp) * M * N + i];
+  float* dst = C + static_cast<int64_t>(m) * ldc + n;
+  *dst = (accumulate ? *dst : 0.f) + (bias ? bias[n] : 0.f) + acc;
+}
+
+namespace {
+int pick_splits(int m, int n, int k) {
+  const int64_t tiles = static_cast<int64_t>((m + BM - 1) / BM) * ((n + BN - 1) / BN);
+  if (tiles >= 96 || k <= 8 * BK) return 1;      // only small outputs with a long reduction (dW)
+  int64_t s = (256 + tiles - 1) / tiles;         // aim for >= 256 workgroups (1024 waves)
+  const int64_t max_s = k / (4 * BK);            // at least 4 k-tiles per split
+  if (s > max_s) s = max_s;
+  return s < 1 ? 1 : static_cast<int>(s);
+}
+}  // namespace
+
+extern "C" size_t dfm_gemm_workspace_bytes(int m, int n, int k) {
+  const int s = pick_splits(m, n, k);
+  return s > 1 ? sizeof(float) * static_cast<size_t>(s) * m * n : 0;
+}
+
+extern "C" int dfm_gemm_f32(const float* d_a, int64_t lda, int a_k_contiguous, const float* d_b, int64_t ldb,
+                            int b_k_contiguous, float* d_c, int64_t ldc, int m, int n, int k,
+                            const float* d_bias, int accumulate, void* d_workspace, dfm_stream_t stream) {
+  DFM_REQUIRE(d_a && d_b && d_c, "null argument");
+  DFM_REQUIRE(m > 0 && n > 0 && k > 0, "bad shape");
+  int splits = d_workspace ? pick_splits(m, n, k) : 1;
+  int k_per_split = ((k + splits - 1) / splits + BK - 1) / BK * BK;
+  splits = (k + k_per_split - 1) / k_per_split;
+  float* slabs = splits > 1 ? static_cast<float*>(d_workspace) : nullptr;
+  const dim3 grid((n + BN - 1) / BN, (m + BM - 1) / BM, splits), block(kThreads);
+  hipStream_t st = as_stream(stream);
+  // branch-free tile loads need all-or-nothing 16-byte pieces (see load_slice)
+  auto fast = [](const float* p, int64_t ld, bool kc, int rows, int kdim) {
+    return (reinterpret_cast<uintptr_t>(p) & 15) == 0 && ld % 4 == 0 && (kc ? kdim % 4 == 0 : rows % 4 == 0);
+  };
+  const bool af = fast(d_a, lda, a_k_contiguous != 0, m, k), bf = fast(d_b, ldb, b_k_contiguous != 0, n, k);
+#define DFM_GEMM_LAUNCH(AK, BK_, AF, BF)                                                                    \
+  hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_, AF, BF>), grid, block, 0, st, d_a, lda, d_b, ldb, d_c, ldc, m, \
+                     n, k, d_bias, accumulate, k_per_split, slabs)
+#define DFM_GEMM_FAST(AK, BK_)                         \
+  do {                                                 \
+    if (af && bf) DFM_GEMM_LAUNCH(AK, BK_, true, true); \
+    else DFM_GEMM_LAUNCH(AK, BK_, false, false);       \
+  } while (0)
+  if (a_k_contiguous && b_k_contiguous) DFM_GEMM_FAST(true, true);
+  else if (a_k_contiguous) DFM_GEMM_FAST(true, false);
+  else if (b_k_contiguous) DFM_GEMM_FAST(false, true);
+  else DFM_GEMM_FAST(false, false);
+#undef DFM_GEMM_FAST
+#undef DFM_GEMM_LAUNCH
+  DFM_LAUNCH_CHECK();
+  if (slabs) {
+    const int64_t total = static_cast<int64_t>(m) * n;
+    hipLaunchKernelGGL(gemm_f32_reduce, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, st, slabs,
+                       splits, m, n, d_c, ldc, d_bias, accumulate);
+    DFM_LAUNCH_CHECK();
+  }
+  return DFM_OK;
+}

@@ -2,8 +2,8 @@
 
 Not one of the four hot-path layers (SURVEY.md §2 keeps it on ``torch.nn``): same
 constructor, ``mlp`` ``nn.Sequential`` and ``dnn.mlp.<i>`` state_dict layout —
-``[Linear, (BatchNorm1d), activation, Dropout] * n``.  The Linear GEMMs always run on
-rocBLAS through torch.  On an MI355X, in training mode with BatchNorm + ReLU (the reference
+``[Linear, (BatchNorm1d), activation, Dropout] * n``.  The Linear GEMMs of the fused path run on the exact-fp32
+MFMA kernel ``dfm_gemm_f32`` (no transposes, no precision loss); the fallback path uses torch.  On an MI355X, in training mode with BatchNorm + ReLU (the reference
 default), the BatchNorm -> ReLU -> Dropout chain between two GEMMs runs as the fused HIP
 kernels ``dfm_bn_relu_dropout_forward/backward`` (two launches each way
 instead of about a dozen); every other configuration uses the plain ``nn.Sequential``.
@@ -17,6 +17,16 @@ import torch
 import torch.nn as nn
 
 from deepfm_amd import _lib
+
+
+def _gemm(a, lda, a_kc, b, ldb, b_kc, c, m, n, k, bias=None, accumulate=False):
+    """c (m, n) (+)= a(m, k) * b(n, k) (+ bias): exact fp32 on the matrix cores (csrc/gemm_f32.hip)."""
+    lib = _lib.load()
+    ws_bytes = lib.dfm_gemm_workspace_bytes(m, n, k)
+    ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=c.device) if ws_bytes else None
+    _lib.check(lib.dfm_gemm_f32(a.data_ptr(), lda, int(a_kc), b.data_ptr(), ldb, int(b_kc), c.data_ptr(),
+                                c.stride(0), m, n, k, _lib.ptr(bias), int(accumulate), _lib.ptr(ws),
+                                _lib.stream_handle()))
 
 
 def _grad_target(p: torch.Tensor):
@@ -38,8 +48,11 @@ class _LinearBnReluDropoutFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, gamma, beta, bn: nn.BatchNorm1d, p: float, seed, salt: int):
         lib = _lib.load()
-        z = torch.addmm(bias, x, weight.t())
-        M, N = z.shape
+        x = x.contiguous()
+        M, K = x.shape
+        N = weight.shape[0]
+        z = torch.empty(M, N, dtype=torch.float32, device=x.device)
+        _gemm(x, K, True, weight, K, True, z, M, N, K, bias=bias)                 # z = x W^T + b
         out = torch.empty_like(z)
         stats = torch.empty(2, N, dtype=torch.float32, device=z.device)
         ws = torch.empty(max(lib.dfm_bn_workspace_bytes(M, N) // 4, 1), dtype=torch.float32, device=z.device)
@@ -69,15 +82,17 @@ class _LinearBnReluDropoutFn(torch.autograd.Function):
             g_out.contiguous().data_ptr(), z.data_ptr(), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(), M, N,
             float(ctx.p), _lib.ptr(ctx.seed), ctx.salt, dz.data_ptr(), d_gamma.data_ptr(), d_beta.data_ptr(),
             ws.data_ptr(), _lib.stream_handle()))
+        K = x.shape[1]
         tw = _grad_target(w_p)
-        if tw is not None:
-            tw.addmm_(dz.t(), x)                       # dW accumulated in place (beta = 1)
-            d_w = None
-        else:
-            d_w = dz.t() @ x
+        d_w = None if tw is not None else torch.empty_like(weight)
+        # dW (N, K) (+)= dz^T x : both operands strided over the batch (the reduction index)
+        _gemm(dz, N, False, x, K, False, tw if tw is not None else d_w, N, K, M, accumulate=tw is not None)
         # d bias == 0 exactly (BatchNorm removes the batch mean): leave an existing buffer as is
         d_b = None if _grad_target(b_p) is not None else torch.zeros_like(b_p)
-        d_x = dz @ weight if ctx.needs_input_grad[0] else None
+        d_x = None
+        if ctx.needs_input_grad[0]:
+            d_x = torch.empty_like(x)
+            _gemm(dz, N, True, weight, K, False, d_x, M, K, N)                      # dx = dz W
         return (d_x, d_w, d_b, None if tg is not None else d_gamma, None if tb is not None else d_beta,
                 None, None, None, None)
 

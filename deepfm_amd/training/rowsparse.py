@@ -84,9 +84,13 @@ class RowSparseAdam:
         others = [p for p in model.parameters()
                   if id(p) not in table_ids and id(p) not in emb_ids and p.requires_grad]
         self.dense_params = emb_dense + others
-        self.n_l2 = sum(p.numel() for p in emb_dense)
-        total = sum(p.numel() for p in self.dense_params)
-        self.flat_param = torch.empty(total, dtype=torch.float32, device=dev)
+        # every parameter starts on a 64-byte boundary (16 floats) so kernels can use 16-byte
+        # vector loads on the views; the padding stays 0 (zero grad -> zero Adam update)
+        def padded(n):
+            return (n + 15) // 16 * 16
+        self.n_l2 = sum(padded(p.numel()) for p in emb_dense)
+        total = sum(padded(p.numel()) for p in self.dense_params)
+        self.flat_param = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_m = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_v = torch.zeros(total, dtype=torch.float32, device=dev)
@@ -96,7 +100,7 @@ class RowSparseAdam:
             self.flat_param[off:off + n].copy_(p.data.reshape(-1))
             p.data = self.flat_param[off:off + n].view_as(p)
             p.grad = self.flat_grad[off:off + n].view_as(p)
-            off += n
+            off += padded(n)
         self._owner = None
         self._gathered = None
         self._partials = None

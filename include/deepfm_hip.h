@@ -287,6 +287,19 @@ size_t dfm_bce_workspace_bytes(int64_t n);
 int dfm_bce_with_logits(const float* d_logits, const float* d_labels, int64_t n, float* d_loss,
                         float* d_g_logits, void* d_workspace, dfm_stream_t stream);
 
+/* ---------------------------------------------------------------------------------
+ * Exact-fp32 GEMM on the matrix cores (v_mfma_f32_32x32x2_f32) for the DNN tower's Linear
+ * layers (reference dnn.py:45-47):  C[m,n] (+)= sum_k A(m,k) * B(n,k) (+ bias[n]).
+ * `*_k_contiguous` = 1: element (r,k) at base[r*ld + k];  0: at base[k*ld + r].  Forward
+ * (x W^T + b), d input (dz W) and d weight (dz^T x, accumulate = 1) of nn.Linear are this one
+ * entry point without transposed copies.  d_workspace (dfm_gemm_workspace_bytes) enables a
+ * split reduction with fixed-order slab summation for small outputs with a long k (d weight).
+ * ------------------------------------------------------------------------------- */
+size_t dfm_gemm_workspace_bytes(int m, int n, int k);
+int dfm_gemm_f32(const float* d_a, int64_t lda, int a_k_contiguous, const float* d_b, int64_t ldb,
+                 int b_k_contiguous, float* d_c, int64_t ldc, int m, int n, int k,
+                 const float* d_bias, int accumulate, void* d_workspace, dfm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

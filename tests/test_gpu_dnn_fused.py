@@ -111,3 +111,26 @@ def test_fused_bce_matches_torch_and_oracle():
     oloss, odz = O.bce_with_logits(z, y)
     assert abs(float(loss) - float(oloss)) < 1e-5
     assert_close(npy(zt.grad), 3.0 * odz, rtol=1e-4, what="dz vs oracle")
+
+
+@pytest.mark.parametrize("shape", [(4096, 256, 624), (4096, 64, 128), (100, 33, 70), (5, 3, 7), (256, 624, 4096),
+                                   (64, 128, 4096)])
+def test_gemm_f32_all_layouts(shape):
+    """csrc/gemm_f32.hip (exact fp32 MFMA) against torch fp64 for the four operand layouts,
+    ragged tiles and the split-reduction shapes of the weight gradient."""
+    from deepfm_amd.models.layers.dnn import _gemm
+    M, N, K = shape
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    a = torch.randn(M, K, device="cuda", generator=g)
+    b = torch.randn(N, K, device="cuda", generator=g)
+    bias = torch.randn(N, device="cuda", generator=g)
+    want = (a.double() @ b.double().t()).float()
+    at, bt = a.t().contiguous(), b.t().contiguous()          # (K, M), (K, N): K-strided operands
+    for a_kc, b_kc in ((True, True), (True, False), (False, True), (False, False)):
+        c = torch.full((M, N), 7.0, device="cuda")
+        _gemm(a if a_kc else at, K if a_kc else M, a_kc, b if b_kc else bt, K if b_kc else N, b_kc, c, M, N, K,
+              bias=bias)
+        assert_close(npy(c), npy(want + bias), rtol=1e-5, atol_scale=2e-6, what=f"layout {a_kc},{b_kc}")
+    c = torch.ones(M, N, device="cuda")
+    _gemm(at, M, False, bt, N, False, c, M, N, K, accumulate=True)
+    assert_close(npy(c), npy(want + 1.0), rtol=1e-5, atol_scale=2e-6, what="accumulate")
