@@ -9,6 +9,7 @@ import torch.nn as nn
 from deepfm_amd.models.base import BaseCTRModel
 from deepfm_amd.models.layers.attention import MultiHeadSelfAttention
 from deepfm_amd.models.layers.dnn import DNN
+from deepfm_amd.models.layers.linear import MfmaLinear
 from deepfm_amd.models.layers.fm import FMInteraction
 
 
@@ -21,7 +22,7 @@ class AttentionDeepFM(BaseCTRModel):
                                                 c.attention.num_layers, c.attention.use_residual)
         dnn_in = self.schema.num_fields * fm_dim + self.schema.total_embedding_dim
         self.dnn = DNN(dnn_in, c.dnn.hidden_units, c.dnn.activation, c.dnn.dropout, c.dnn.use_batch_norm)
-        self.output_linear = nn.Linear(self.dnn.output_dim, 1)
+        self.output_linear = MfmaLinear(self.dnn.output_dim, 1)
 
     def _forward_components(self, first_order, field_embeddings, flat_embeddings) -> torch.Tensor:
         refined = self.attention(field_embeddings)
