@@ -1,0 +1,353 @@
+// Field self-attention, GEMM-structured path (reference deepfm/models/layers/attention.py:91-120).
+//
+// The projections of an _AttentionBlock are plain GEMMs over the B*F rows of x — Q|K|V = x Wqkv^T
+// + b (attention.py:95-97) and out = O Wo^T + bo (:115) — and run on dfm_gemm_f32 (exact fp32
+// MFMA).  What is left is small and per sample:
+//   * attn_core_fwd / attn_core_bwd: softmax(Q_h K_h^T / sqrt(hd)) V_h for one (sample, head) per
+//     wave (:100-112).  F = 39 "tokens": lane i owns query row i; K_h / V_h rows are LDS
+//     broadcasts; the (B, heads, F, F) score tensor of the reference never leaves registers/LDS.
+//     The backward recomputes P from Q, K.
+//   * layernorm_fwd / layernorm_bwd: LayerNorm(out + x) over D (:117-118), one row per lane
+//     group, parameter gradients as fixed-order partial sums.
+#include "common.h"
+
+using namespace dfm;
+
+namespace {
+constexpr int kMaxF = 64;     // one lane per query row
+constexpr int kWavesPerBlock = 4;
+}  // namespace
+
+// qkv (B*F, 3A): row = [q (A) | k (A) | v (A)];  o (B*F, A).  One wave per (b, h).
+// LDS per wave: k_h, v_h (F x hd each) and the score rows P (F x F; lane i owns row i — a
+// runtime-indexed register array would be demoted to scratch).
+template <int HD>
+__global__ __launch_bounds__(kWavesPerBlock * 64) void attn_core_fwd(const float* __restrict__ qkv, int64_t B,
+                                                                       int F, int A, int heads,
+                                                                       float* __restrict__ o) {
+  extern __shared__ float lds[];
+  const int lane = lane_id(), wave = wave_id_uniform();
+  const int64_t unit = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave;   // (b, h)
+  if (unit >= B * heads) return;
+  const int64_t b = unit / heads;
+  const int h = static_cast<int>(unit % heads);
+  float* ks = lds + static_cast<size_t>(wave) * (2 * F * HD + F * F);
+  float* vs = ks + F * HD;
+  float* Ps = vs + F * HD;
+  const float* base = qkv + b * F * 3 * A + h * HD;
+  for (int i = lane; i < F * HD; i += 64) {
+    const int j = i / HD, e = i % HD;
+    ks[i] = base[static_cast<int64_t>(j) * 3 * A + A + e];
+    vs[i] = base[static_cast<int64_t>(j) * 3 * A + 2 * A + e];
+  }
+  // wave-private LDS: same-wave LDS ops are ordered, no barrier needed
+  const bool live = lane < F;
+  const int row = live ? lane : 0;
+  float* prow = Ps + row * F;
+  float q[HD];
+#pragma unroll
+  for (int e = 0; e < HD; ++e) q[e] = base[static_cast<int64_t>(row) * 3 * A + e];
+  const float inv_scale = 1.f / sqrtf(static_cast<float>(HD));
+  // scores of this lane's row; running max
+  float mx = -INFINITY;
+  for (int j = 0; j < F; ++j) {
+    float acc = 0.f;
+#pragma unroll
+    for (int e = 0; e < HD; ++e) acc = fmaf(q[e], ks[j * HD + e], acc);
+    acc *= inv_scale;
+    if (live) prow[j] = acc;
+    mx = fmaxf(mx, acc);
+  }
+  float sum = 0.f;
+  for (int j = 0; j < F; ++j) {
+    const float ev = expf(prow[j] - mx);
+    if (live) prow[j] = ev;
+    sum += ev;
+  }
+  const float inv = 1.f / sum;
+  float out[HD];
+#pragma unroll
+  for (int e = 0; e < HD; ++e) out[e] = 0.f;
+  for (int j = 0; j < F; ++j) {
+    const float p = prow[j] * inv;
+#pragma unroll
+    for (int e = 0; e < HD; ++e) out[e] = fmaf(p, vs[j * HD + e], out[e]);
+  }
+  if (live) {
+    float* dst = o + (b * F + lane) * A + h * HD;
+#pragma unroll
+    for (int e = 0; e < HD; ++e) dst[e] = out[e];
+  }
+}
+
+// d_qkv (B*F, 3A) from d_o (B*F, A); recomputes P.  LDS per wave: q, k, v, dO (F x hd each) and
+// P, dS (F x F each).
+template <int HD>
+__global__ __launch_bounds__(kWavesPerBlock * 64) void attn_core_bwd(const float* __restrict__ qkv,
+                                                                       const float* __restrict__ d_o, int64_t B,
+                                                                       int F, int A, int heads,
+                                                                       float* __restrict__ d_qkv) {
+  extern __shared__ float lds[];
+  const int lane = lane_id(), wave = wave_id_uniform();
+  const int64_t unit = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave;
+  if (unit >= B * heads) return;
+  const int64_t b = unit / heads;
+  const int h = static_cast<int>(unit % heads);
+  float* qs = lds + static_cast<size_t>(wave) * (4 * F * HD + 2 * F * F);
+  float* ks = qs + F * HD;
+  float* vs = ks + F * HD;
+  float* gs = vs + F * HD;          // dO
+  float* Ps = gs + F * HD;          // P  (row i, col j at i*F + j)
+  float* Ss = Ps + F * F;           // dS
+  const float* base = qkv + b * F * 3 * A + h * HD;
+  const float* gbase = d_o + b * F * A + h * HD;
+  for (int i = lane; i < F * HD; i += 64) {
+    const int j = i / HD, e = i % HD;
+    qs[i] = base[static_cast<int64_t>(j) * 3 * A + e];
+    ks[i] = base[static_cast<int64_t>(j) * 3 * A + A + e];
+    vs[i] = base[static_cast<int64_t>(j) * 3 * A + 2 * A + e];
+    gs[i] = gbase[static_cast<int64_t>(j) * A + e];
+  }
+  const bool live = lane < F;
+  const int row = live ? lane : 0;
+  const float inv_scale = 1.f / sqrtf(static_cast<float>(HD));
+  float q[HD], g[HD];
+#pragma unroll
+  for (int e = 0; e < HD; ++e) { q[e] = qs[row * HD + e]; g[e] = gs[row * HD + e]; }
+  // P row and dP row of this lane (rows live in LDS: dead lanes compute row 0 but never write)
+  float* prow = Ps + row * F;
+  float* srow = Ss + row * F;
+  float mx = -INFINITY;
+  for (int j = 0; j < F; ++j) {
+    float acc = 0.f;
+#pragma unroll
+    for (int e = 0; e < HD; ++e) acc = fmaf(q[e], ks[j * HD + e], acc);
+    acc *= inv_scale;
+    if (live) prow[j] = acc;
+    mx = fmaxf(mx, acc);
+  }
+  float sum = 0.f;
+  for (int j = 0; j < F; ++j) {
+    const float ev = expf(prow[j] - mx);
+    if (live) prow[j] = ev;
+    sum += ev;
+  }
+  const float inv = 1.f / sum;
+  float dot = 0.f;
+  float dq[HD];
+#pragma unroll
+  for (int e = 0; e < HD; ++e) dq[e] = 0.f;
+  for (int j = 0; j < F; ++j) {
+    const float p = prow[j] * inv;
+    float dp = 0.f;
+#pragma unroll
+    for (int e = 0; e < HD; ++e) dp = fmaf(g[e], vs[j * HD + e], dp);
+    if (live) { prow[j] = p; srow[j] = dp; }                     // Ss holds dP for now
+    dot = fmaf(dp, p, dot);
+  }
+  for (int j = 0; j < F; ++j) {
+    const float ds = live ? prow[j] * (srow[j] - dot) * inv_scale : 0.f;
+    if (live) srow[j] = ds;
+#pragma unroll
+    for (int e = 0; e < HD; ++e) dq[e] = fmaf(ds, ks[j * HD + e], dq[e]);
+  }
+  float* dbase = d_qkv + b * F * 3 * A + h * HD;
+  if (live) {
+#pragma unroll
+    for (int e = 0; e < HD; ++e) dbase[static_cast<int64_t>(row) * 3 * A + e] = dq[e];
+  }
+  // column sweeps: lane j owns key/value row j.  dK[j] = sum_i dS[i][j] q[i]; dV[j] = sum_i P[i][j] dO[i]
+  float dk[HD], dv[HD];
+#pragma unroll
+  for (int e = 0; e < HD; ++e) { dk[e] = 0.f; dv[e] = 0.f; }
+  for (int i = 0; i < F; ++i) {
+    const float ds = live ? Ss[i * F + row] : 0.f;
+    const float p = live ? Ps[i * F + row] : 0.f;
+#pragma unroll
+    for (int e = 0; e < HD; ++e) {
+      dk[e] = fmaf(ds, qs[i * HD + e], dk[e]);
+      dv[e] = fmaf(p, gs[i * HD + e], dv[e]);
+    }
+  }
+  if (live) {
+#pragma unroll
+    for (int e = 0; e < HD; ++e) {
+      dbase[static_cast<int64_t>(row) * 3 * A + A + e] = dk[e];
+      dbase[static_cast<int64_t>(row) * 3 * A + 2 * A + e] = dv[e];
+    }
+  }
+}
+
+// ---- LayerNorm over the last dimension (D <= 256), rows = B*F ---------------------------------
+// out = LN(y + res) * gamma + beta;  stats[row] = (mean, rstd).  One thread per row.
+__global__ __launch_bounds__(256) void layernorm_fwd(const float* __restrict__ y, const float* __restrict__ res,
+                                                     int64_t rows, int D, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, float eps,
+                                                     float* __restrict__ out, float* __restrict__ stats) {
+  const int64_t r = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (r >= rows) return;
+  const float* yr = y + r * D;
+  const float* xr = res + r * D;
+  float mu = 0.f;
+  for (int d = 0; d < D; ++d) mu += yr[d] + xr[d];
+  mu /= D;
+  float var = 0.f;
+  for (int d = 0; d < D; ++d) { const float c = yr[d] + xr[d] - mu; var = fmaf(c, c, var); }
+  const float rstd = rsqrtf(var / D + eps);
+  for (int d = 0; d < D; ++d) out[r * D + d] = (yr[d] + xr[d] - mu) * rstd * gamma[d] + beta[d];
+  stats[2 * r] = mu;
+  stats[2 * r + 1] = rstd;
+}
+
+// g_s = rstd * (g*gamma - mean(g*gamma) - xhat * mean(g*gamma*xhat));  partial d gamma / d beta per
+// workgroup (rows of one block, added in row order) into partial[block][2][D].
+__global__ __launch_bounds__(256) void layernorm_bwd(const float* __restrict__ g, const float* __restrict__ y,
+                                                     const float* __restrict__ res,
+                                                     const float* __restrict__ stats, int64_t rows, int D,
+                                                     const float* __restrict__ gamma, float* __restrict__ g_s,
+                                                     float* __restrict__ partial) {
+  extern __shared__ float acc[];     // [2][D] per-block sums, then per-thread staging of xhat*g
+  const int64_t r = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  const bool live = r < rows;
+  float mu = 0.f, rstd = 0.f, m1 = 0.f, m2 = 0.f;
+  if (live) {
+    mu = stats[2 * r]; rstd = stats[2 * r + 1];
+    for (int d = 0; d < D; ++d) {
+      const float xh = (y[r * D + d] + res[r * D + d] - mu) * rstd;
+      const float gg = g[r * D + d] * gamma[d];
+      m1 += gg;
+      m2 = fmaf(gg, xh, m2);
+    }
+    m1 /= D; m2 /= D;
+    for (int d = 0; d < D; ++d) {
+      const float xh = (y[r * D + d] + res[r * D + d] - mu) * rstd;
+      const float gg = g[r * D + d] * gamma[d];
+      g_s[r * D + d] = rstd * (gg - m1 - xh * m2);
+    }
+  }
+  // d gamma[d] = sum_rows g*xhat, d beta[d] = sum_rows g: thread d sums the block's rows in order
+  __syncthreads();
+  for (int d = threadIdx.x; d < D; d += 256) {
+    float sg = 0.f, sb = 0.f;
+    const int64_t r0 = static_cast<int64_t>(blockIdx.x) * 256;
+    const int64_t r1 = r0 + 256 < rows ? r0 + 256 : rows;
+    for (int64_t rr = r0; rr < r1; ++rr) {
+      const float xh = (y[rr * D + d] + res[rr * D + d] - stats[2 * rr]) * stats[2 * rr + 1];
+      const float gv = g[rr * D + d];
+      sg = fmaf(gv, xh, sg);
+      sb += gv;
+    }
+    partial[(static_cast<int64_t>(blockIdx.x) * 2 + 0) * D + d] = sg;
+    partial[(static_cast<int64_t>(blockIdx.x) * 2 + 1) * D + d] = sb;
+  }
+  (void)acc;
+}
+
+__global__ __launch_bounds__(256) void layernorm_bwd_finalize(const float* __restrict__ partial, int blocks, int D,
+                                                              float* __restrict__ d_gamma,
+                                                              float* __restrict__ d_beta) {
+  const int d = blockIdx.x * 256 + threadIdx.x;
+  if (d >= D) return;
+  float sg = 0.f, sb = 0.f;
+  for (int i = 0; i < blocks; ++i) {
+    sg += partial[(static_cast<int64_t>(i) * 2 + 0) * D + d];
+    sb += partial[(static_cast<int64_t>(i) * 2 + 1) * D + d];
+  }
+  d_gamma[d] += sg;
+  d_beta[d] += sb;
+}
+
+namespace {
+int check_core(int F, int A, int heads) {
+  DFM_REQUIRE(F > 0 && F <= kMaxF, "attention core supports up to %d fields (got %d)", kMaxF, F);
+  DFM_REQUIRE(heads > 0 && A % heads == 0, "attention_dim must be divisible by num_heads");
+  const int hd = A / heads;
+  DFM_REQUIRE(hd == 4 || hd == 8 || hd == 16 || hd == 32, "attention core supports head_dim 4/8/16/32 (got %d)", hd);
+  return DFM_OK;
+}
+}  // namespace
+
+extern "C" int dfm_attention_core_supported(int num_fields, int attention_dim, int num_heads) {
+  if (num_fields <= 0 || num_fields > kMaxF || num_heads <= 0 || attention_dim % num_heads) return 0;
+  const int hd = attention_dim / num_heads;
+  return hd == 4 || hd == 8 || hd == 16 || hd == 32;
+}
+
+extern "C" int dfm_attention_core_forward(const float* d_qkv, int64_t batch, int num_fields, int attention_dim,
+                                          int num_heads, float* d_o, dfm_stream_t stream) {
+  DFM_REQUIRE(d_qkv && d_o, "null argument");
+  if (int rc = check_core(num_fields, attention_dim, num_heads)) return rc;
+  if (batch == 0) return DFM_OK;
+  const int hd = attention_dim / num_heads;
+  const int64_t units = batch * num_heads;
+  const dim3 grid(static_cast<unsigned>((units + kWavesPerBlock - 1) / kWavesPerBlock)), block(kWavesPerBlock * 64);
+  const size_t lds = sizeof(float) * kWavesPerBlock * (2 * num_fields * hd + num_fields * num_fields);
+  DFM_REQUIRE(lds <= 64 * 1024, "attention core needs %zu bytes of LDS", lds);
+  hipStream_t st = as_stream(stream);
+#define DFM_CORE(HD) hipLaunchKernelGGL(attn_core_fwd<HD>, grid, block, lds, st, d_qkv, batch, num_fields, attention_dim, num_heads, d_o)
+  if (hd == 4) DFM_CORE(4); else if (hd == 8) DFM_CORE(8); else if (hd == 16) DFM_CORE(16); else DFM_CORE(32);
+#undef DFM_CORE
+  DFM_LAUNCH_CHECK();
+  return DFM_OK;
+}
+
+extern "C" int dfm_attention_core_backward(const float* d_qkv, const float* d_g_o, int64_t batch, int num_fields,
+                                           int attention_dim, int num_heads, float* d_g_qkv,
+                                           dfm_stream_t stream) {
+  DFM_REQUIRE(d_qkv && d_g_o && d_g_qkv, "null argument");
+  if (int rc = check_core(num_fields, attention_dim, num_heads)) return rc;
+  if (batch == 0) return DFM_OK;
+  const int hd = attention_dim / num_heads;
+  const int64_t units = batch * num_heads;
+  const dim3 grid(static_cast<unsigned>((units + kWavesPerBlock - 1) / kWavesPerBlock)), block(kWavesPerBlock * 64);
+  const size_t lds = sizeof(float) * kWavesPerBlock * (4 * num_fields * hd + 2 * num_fields * num_fields);
+  DFM_REQUIRE(lds <= 160 * 1024, "attention core backward needs %zu bytes of LDS", lds);
+  hipStream_t st = as_stream(stream);
+#define DFM_CORE(HD)                                                                                        \
+  do {                                                                                                      \
+    DFM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_core_bwd<HD>),                       \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));    \
+    hipLaunchKernelGGL(attn_core_bwd<HD>, grid, block, lds, st, d_qkv, d_g_o, batch, num_fields,            \
+                       attention_dim, num_heads, d_g_qkv);                                                   \
+  } while (0)
+  if (hd == 4) DFM_CORE(4); else if (hd == 8) DFM_CORE(8); else if (hd == 16) DFM_CORE(16); else DFM_CORE(32);
+#undef DFM_CORE
+  DFM_LAUNCH_CHECK();
+  return DFM_OK;
+}
+
+extern "C" size_t dfm_layernorm_workspace_bytes(int64_t rows, int dim) {
+  return sizeof(float) * 2 * static_cast<size_t>((rows + 255) / 256) * dim;
+}
+
+extern "C" int dfm_layernorm_forward(const float* d_y, const float* d_res, int64_t rows, int dim,
+                                     const float* d_gamma, const float* d_beta, float eps, float* d_out,
+                                     float* d_stats, dfm_stream_t stream) {
+  DFM_REQUIRE(d_y && d_res && d_gamma && d_beta && d_out && d_stats, "null argument");
+  DFM_REQUIRE(rows >= 0 && dim > 0, "bad shape");
+  if (rows == 0) return DFM_OK;
+  hipLaunchKernelGGL(layernorm_fwd, dim3(static_cast<unsigned>((rows + 255) / 256)), dim3(256), 0, as_stream(stream),
+                     d_y, d_res, rows, dim, d_gamma, d_beta, eps, d_out, d_stats);
+  DFM_LAUNCH_CHECK();
+  return DFM_OK;
+}
+
+extern "C" int dfm_layernorm_backward(const float* d_g_out, const float* d_y, const float* d_res,
+                                      const float* d_stats, int64_t rows, int dim, const float* d_gamma,
+                                      float* d_g_sum, float* d_g_gamma, float* d_g_beta, void* d_workspace,
+                                      dfm_stream_t stream) {
+  DFM_REQUIRE(d_g_out && d_y && d_res && d_stats && d_gamma && d_g_sum && d_g_gamma && d_g_beta && d_workspace,
+              "null argument");
+  DFM_REQUIRE(rows >= 0 && dim > 0, "bad shape");
+  if (rows == 0) return DFM_OK;
+  hipStream_t st = as_stream(stream);
+  const int blocks = static_cast<int>((rows + 255) / 256);
+  float* partial = static_cast<float*>(d_workspace);
+  hipLaunchKernelGGL(layernorm_bwd, dim3(blocks), dim3(256), 0, st, d_g_out, d_y, d_res, d_stats, rows, dim, d_gamma,
+                     d_g_sum, partial);
+  DFM_LAUNCH_CHECK();
+  hipLaunchKernelGGL(layernorm_bwd_finalize, dim3((dim + 255) / 256), dim3(256), 0, st, partial, blocks, dim,
+                     d_g_gamma, d_g_beta);
+  DFM_LAUNCH_CHECK();
+  return DFM_OK;
+}

@@ -34,6 +34,9 @@ class _AttentionBlock(nn.Module):
         self.W_out = nn.Linear(attention_dim, embed_dim)
         if use_residual:
             self.layer_norm = nn.LayerNorm(embed_dim)
+        # projections as GEMMs over the B*F rows (dfm_gemm_f32) + per-(sample, head) core kernel;
+        # False (or an unsupported shape) selects the single fused LDS kernel of csrc/attention.hip
+        self.gemm_path = True
 
     def _param_list(self):
         ps = [self.W_q.weight, self.W_q.bias, self.W_k.weight, self.W_k.bias, self.W_v.weight,
@@ -43,6 +46,10 @@ class _AttentionBlock(nn.Module):
         return ps
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        lib = _lib.load()
+        if self.gemm_path and lib.dfm_attention_core_supported(x.shape[1], self.attention_dim, self.num_heads) \
+                and self.embed_dim % 4 == 0 and self.attention_dim % 4 == 0:
+            return _AttnGemmFn.apply(self, x, *self._param_list())
         return _AttnFn.apply(self, x, *self._param_list())
 
 
@@ -73,6 +80,91 @@ def _ptrs(tensors):
     for i, t in enumerate(tensors):
         arr[i] = t.data_ptr()
     return arr
+
+
+class _AttnGemmFn(torch.autograd.Function):
+    """One _AttentionBlock as: QKV GEMM -> attention core -> output GEMM -> (+x, LayerNorm)."""
+
+    @staticmethod
+    def forward(ctx, block: _AttentionBlock, x: torch.Tensor, *params):
+        from deepfm_amd.models.layers.dnn import _gemm
+        lib = _lib.load()
+        x = x.contiguous()
+        B, F, D = x.shape
+        A, H = block.attention_dim, block.num_heads
+        M = B * F
+        wq, bq, wk, bk, wv, bv, wo, bo = (p.contiguous() for p in params[:8])
+        w_qkv = torch.cat([wq, wk, wv], dim=0)                      # (3A, D)
+        b_qkv = torch.cat([bq, bk, bv], dim=0)
+        X = x.view(M, D)
+        qkv = torch.empty(M, 3 * A, dtype=torch.float32, device=x.device)
+        _gemm(X, D, True, w_qkv, D, True, qkv, M, 3 * A, D, bias=b_qkv)
+        o = torch.empty(M, A, dtype=torch.float32, device=x.device)
+        _lib.check(lib.dfm_attention_core_forward(qkv.data_ptr(), B, F, A, H, o.data_ptr(), _lib.stream_handle()))
+        y = torch.empty(M, D, dtype=torch.float32, device=x.device)
+        _gemm(o, A, True, wo, A, True, y, M, D, A, bias=bo)
+        stats = None
+        if block.use_residual:
+            gamma, beta = params[8].contiguous(), params[9].contiguous()
+            out = torch.empty(M, D, dtype=torch.float32, device=x.device)
+            stats = torch.empty(M, 2, dtype=torch.float32, device=x.device)
+            _lib.check(lib.dfm_layernorm_forward(y.data_ptr(), X.data_ptr(), M, D, gamma.data_ptr(), beta.data_ptr(),
+                                                 float(block.layer_norm.eps), out.data_ptr(), stats.data_ptr(),
+                                                 _lib.stream_handle()))
+        else:
+            gamma = beta = None
+            out = y
+        ctx.block, ctx.dims = block, (B, F, D, A, H)
+        ctx.save_for_backward(X, qkv, o, y, stats, w_qkv, wo, gamma)
+        return out.view(B, F, D)
+
+    @staticmethod
+    def backward(ctx, g_out: torch.Tensor):
+        from deepfm_amd.models.layers.dnn import _gemm
+        lib = _lib.load()
+        block = ctx.block
+        B, F, D, A, H = ctx.dims
+        M = B * F
+        X, qkv, o, y, stats, w_qkv, wo, gamma = ctx.saved_tensors
+        dev = X.device
+        g = g_out.contiguous().view(M, D)
+        ones = torch.ones(M, 1, dtype=torch.float32, device=dev)
+        grads = []
+        if block.use_residual:
+            g_y = torch.empty(M, D, dtype=torch.float32, device=dev)
+            d_gamma = torch.zeros(D, dtype=torch.float32, device=dev)
+            d_beta = torch.zeros(D, dtype=torch.float32, device=dev)
+            ws = torch.empty(max(lib.dfm_layernorm_workspace_bytes(M, D) // 4, 1), dtype=torch.float32, device=dev)
+            _lib.check(lib.dfm_layernorm_backward(g.data_ptr(), y.data_ptr(), X.data_ptr(), stats.data_ptr(), M, D,
+                                                  gamma.data_ptr(), g_y.data_ptr(), d_gamma.data_ptr(),
+                                                  d_beta.data_ptr(), ws.data_ptr(), _lib.stream_handle()))
+        else:
+            g_y = g
+        d_wo = torch.empty(D, A, dtype=torch.float32, device=dev)
+        _gemm(g_y, D, False, o, A, False, d_wo, D, A, M)                         # dWo = g_y^T O
+        d_bo = torch.empty(D, 1, dtype=torch.float32, device=dev)
+        _gemm(g_y, D, False, ones, 1, False, d_bo, D, 1, M)
+        d_o = torch.empty(M, A, dtype=torch.float32, device=dev)
+        _gemm(g_y, D, True, wo, A, False, d_o, M, A, D)                          # dO = g_y Wo
+        d_qkv = torch.empty(M, 3 * A, dtype=torch.float32, device=dev)
+        _lib.check(lib.dfm_attention_core_backward(qkv.data_ptr(), d_o.data_ptr(), B, F, A, H, d_qkv.data_ptr(),
+                                                   _lib.stream_handle()))
+        d_wqkv = torch.empty(3 * A, D, dtype=torch.float32, device=dev)
+        _gemm(d_qkv, 3 * A, False, X, D, False, d_wqkv, 3 * A, D, M)             # dWqkv = dQKV^T X
+        d_bqkv = torch.empty(3 * A, 1, dtype=torch.float32, device=dev)
+        _gemm(d_qkv, 3 * A, False, ones, 1, False, d_bqkv, 3 * A, 1, M)
+        if block.use_residual:
+            d_x = g_y                                                            # residual branch, then +=
+            _gemm(d_qkv, 3 * A, True, w_qkv, D, False, d_x, M, D, 3 * A, accumulate=True)
+        else:
+            d_x = torch.empty(M, D, dtype=torch.float32, device=dev)
+            _gemm(d_qkv, 3 * A, True, w_qkv, D, False, d_x, M, D, 3 * A)
+        d_bqkv = d_bqkv.view(-1)
+        grads = [d_wqkv[:A], d_bqkv[:A], d_wqkv[A:2 * A], d_bqkv[A:2 * A], d_wqkv[2 * A:], d_bqkv[2 * A:],
+                 d_wo, d_bo.view(-1)]
+        if block.use_residual:
+            grads += [d_gamma, d_beta]
+        return (None, d_x.view(B, F, D)) + tuple(grads)
 
 
 class _AttnFn(torch.autograd.Function):

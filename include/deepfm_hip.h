@@ -257,6 +257,24 @@ int dfm_attention_backward(const float* d_x, const float* d_g_out, int64_t batch
                            const float* const* params, float* d_g_x, float* const* g_params,
                            void* d_workspace, dfm_stream_t stream);
 
+/* GEMM-structured attention path (attention.py:91-120): the projections run on dfm_gemm_f32 over
+ * the B*F rows; these are the remaining per-sample pieces.
+ *   core   : o[b,i,h*hd:(h+1)*hd] = softmax(q_h k_h^T / sqrt(hd)) v_h, qkv (B*F, 3A) rows [q|k|v]
+ *            (F <= 64, head_dim in {4,8,16,32}); the backward recomputes the probabilities
+ *   LN     : out = LayerNorm(y + res) * gamma + beta over the last dim; stats (rows, 2) = mean, rstd;
+ *            backward gives d(y+res) and ADDS d gamma / d beta */
+int dfm_attention_core_supported(int num_fields, int attention_dim, int num_heads);
+int dfm_attention_core_forward(const float* d_qkv, int64_t batch, int num_fields, int attention_dim,
+                               int num_heads, float* d_o, dfm_stream_t stream);
+int dfm_attention_core_backward(const float* d_qkv, const float* d_g_o, int64_t batch, int num_fields,
+                                int attention_dim, int num_heads, float* d_g_qkv, dfm_stream_t stream);
+size_t dfm_layernorm_workspace_bytes(int64_t rows, int dim);
+int dfm_layernorm_forward(const float* d_y, const float* d_res, int64_t rows, int dim, const float* d_gamma,
+                          const float* d_beta, float eps, float* d_out, float* d_stats, dfm_stream_t stream);
+int dfm_layernorm_backward(const float* d_g_out, const float* d_y, const float* d_res, const float* d_stats,
+                           int64_t rows, int dim, const float* d_gamma, float* d_g_sum, float* d_g_gamma,
+                           float* d_g_beta, void* d_workspace, dfm_stream_t stream);
+
 /* ---------------------------------------------------------------------------------
  * DNN tower glue (reference deepfm/models/layers/dnn.py:45-55): BatchNorm1d (training
  * statistics) -> ReLU -> Dropout between the Linear GEMMs, two launches each way.
