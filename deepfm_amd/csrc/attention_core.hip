@@ -80,8 +80,9 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void attn_core_fwd(const float
   }
 }
 
-// d_qkv (B*F, 3A) from d_o (B*F, A); recomputes P.  LDS per wave: q, k, v, dO (F x hd each) and
-// P, dS (F x F each).
+// d_qkv (B*F, 3A) from d_o (B*F, A); recomputes P.  LDS per wave: q, k, v, dO (F x hd each) and ONE
+// F x F matrix that holds P for the dV sweep and is then overwritten by dS for the dK sweep (dP is
+// recomputed instead of stored: 16 FMAs per element buy a second resident workgroup per CU).
 template <int HD>
 __global__ __launch_bounds__(kWavesPerBlock * 64) void attn_core_bwd(const float* __restrict__ qkv,
                                                                        const float* __restrict__ d_o, int64_t B,
@@ -93,12 +94,11 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void attn_core_bwd(const float
   if (unit >= B * heads) return;
   const int64_t b = unit / heads;
   const int h = static_cast<int>(unit % heads);
-  float* qs = lds + static_cast<size_t>(wave) * (4 * F * HD + 2 * F * F);
+  float* qs = lds + static_cast<size_t>(wave) * (4 * F * HD + F * F);
   float* ks = qs + F * HD;
   float* vs = ks + F * HD;
   float* gs = vs + F * HD;          // dO
-  float* Ps = gs + F * HD;          // P  (row i, col j at i*F + j)
-  float* Ss = Ps + F * F;           // dS
+  float* Ms = gs + F * HD;          // P, later dS  (row i, col j at i*F + j)
   const float* base = qkv + b * F * 3 * A + h * HD;
   const float* gbase = d_o + b * F * A + h * HD;
   for (int i = lane; i < F * HD; i += 64) {
@@ -114,147 +114,177 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void attn_core_bwd(const float
   float q[HD], g[HD];
 #pragma unroll
   for (int e = 0; e < HD; ++e) { q[e] = qs[row * HD + e]; g[e] = gs[row * HD + e]; }
-  // P row and dP row of this lane (rows live in LDS: dead lanes compute row 0 but never write)
-  float* prow = Ps + row * F;
-  float* srow = Ss + row * F;
+  float* mrow = Ms + row * F;       // dead lanes shadow row 0 and never write
+  // ---- P row of this lane ---------------------------------------------------------------------
   float mx = -INFINITY;
   for (int j = 0; j < F; ++j) {
     float acc = 0.f;
 #pragma unroll
     for (int e = 0; e < HD; ++e) acc = fmaf(q[e], ks[j * HD + e], acc);
     acc *= inv_scale;
-    if (live) prow[j] = acc;
+    if (live) mrow[j] = acc;
     mx = fmaxf(mx, acc);
   }
   float sum = 0.f;
   for (int j = 0; j < F; ++j) {
-    const float ev = expf(prow[j] - mx);
-    if (live) prow[j] = ev;
+    const float ev = expf(mrow[j] - mx);
+    if (live) mrow[j] = ev;
     sum += ev;
   }
   const float inv = 1.f / sum;
-  float dot = 0.f;
-  float dq[HD];
-#pragma unroll
-  for (int e = 0; e < HD; ++e) dq[e] = 0.f;
+  float dot = 0.f;                  // sum_j dP_ij P_ij
   for (int j = 0; j < F; ++j) {
-    const float p = prow[j] * inv;
+    const float p = mrow[j] * inv;
     float dp = 0.f;
 #pragma unroll
     for (int e = 0; e < HD; ++e) dp = fmaf(g[e], vs[j * HD + e], dp);
-    if (live) { prow[j] = p; srow[j] = dp; }                     // Ss holds dP for now
+    if (live) mrow[j] = p;
     dot = fmaf(dp, p, dot);
   }
-  for (int j = 0; j < F; ++j) {
-    const float ds = live ? prow[j] * (srow[j] - dot) * inv_scale : 0.f;
-    if (live) srow[j] = ds;
-#pragma unroll
-    for (int e = 0; e < HD; ++e) dq[e] = fmaf(ds, ks[j * HD + e], dq[e]);
-  }
+  // ---- dV[j] = sum_i P[i][j] dO[i]   (lane j owns key/value row j) ----------------------------------
   float* dbase = d_qkv + b * F * 3 * A + h * HD;
-  if (live) {
+  {
+    float dv[HD];
 #pragma unroll
-    for (int e = 0; e < HD; ++e) dbase[static_cast<int64_t>(row) * 3 * A + e] = dq[e];
-  }
-  // column sweeps: lane j owns key/value row j.  dK[j] = sum_i dS[i][j] q[i]; dV[j] = sum_i P[i][j] dO[i]
-  float dk[HD], dv[HD];
+    for (int e = 0; e < HD; ++e) dv[e] = 0.f;
+    for (int i = 0; i < F; ++i) {
+      const float p = Ms[i * F + row];
 #pragma unroll
-  for (int e = 0; e < HD; ++e) { dk[e] = 0.f; dv[e] = 0.f; }
-  for (int i = 0; i < F; ++i) {
-    const float ds = live ? Ss[i * F + row] : 0.f;
-    const float p = live ? Ps[i * F + row] : 0.f;
+      for (int e = 0; e < HD; ++e) dv[e] = fmaf(p, gs[i * HD + e], dv[e]);
+    }
+    if (live) {
 #pragma unroll
-    for (int e = 0; e < HD; ++e) {
-      dk[e] = fmaf(ds, qs[i * HD + e], dk[e]);
-      dv[e] = fmaf(p, gs[i * HD + e], dv[e]);
+      for (int e = 0; e < HD; ++e) dbase[static_cast<int64_t>(row) * 3 * A + 2 * A + e] = dv[e];
     }
   }
-  if (live) {
+  // ---- dS row (overwrites P), dQ -----------------------------------------------------------------
+  {
+    float dq[HD];
 #pragma unroll
-    for (int e = 0; e < HD; ++e) {
-      dbase[static_cast<int64_t>(row) * 3 * A + A + e] = dk[e];
-      dbase[static_cast<int64_t>(row) * 3 * A + 2 * A + e] = dv[e];
+    for (int e = 0; e < HD; ++e) dq[e] = 0.f;
+    for (int j = 0; j < F; ++j) {
+      float dp = 0.f;
+#pragma unroll
+      for (int e = 0; e < HD; ++e) dp = fmaf(g[e], vs[j * HD + e], dp);
+      const float ds = mrow[j] * (dp - dot) * inv_scale;
+      if (live) mrow[j] = ds;
+#pragma unroll
+      for (int e = 0; e < HD; ++e) dq[e] = fmaf(ds, ks[j * HD + e], dq[e]);
+    }
+    if (live) {
+#pragma unroll
+      for (int e = 0; e < HD; ++e) dbase[static_cast<int64_t>(row) * 3 * A + e] = dq[e];
+    }
+  }
+  // ---- dK[j] = sum_i dS[i][j] q[i] --------------------------------------------------------------
+  {
+    float dk[HD];
+#pragma unroll
+    for (int e = 0; e < HD; ++e) dk[e] = 0.f;
+    for (int i = 0; i < F; ++i) {
+      const float ds = Ms[i * F + row];
+#pragma unroll
+      for (int e = 0; e < HD; ++e) dk[e] = fmaf(ds, qs[i * HD + e], dk[e]);
+    }
+    if (live) {
+#pragma unroll
+      for (int e = 0; e < HD; ++e) dbase[static_cast<int64_t>(row) * 3 * A + A + e] = dk[e];
     }
   }
 }
 
-// ---- LayerNorm over the last dimension (D <= 256), rows = B*F ---------------------------------
-// out = LN(y + res) * gamma + beta;  stats[row] = (mean, rstd).  One thread per row.
+// ---- LayerNorm over the last dimension, rows = B*F ---------------------------------------------
+// out = LN(y + res) * gamma + beta;  stats[row] = (mean, rstd).
+// LPR = pow2 >= D lanes per row (D <= 64): a wave covers 64/LPR consecutive rows with fully
+// coalesced loads; the row reductions are xor-shuffles inside the LPR-lane group.
 __global__ __launch_bounds__(256) void layernorm_fwd(const float* __restrict__ y, const float* __restrict__ res,
-                                                     int64_t rows, int D, const float* __restrict__ gamma,
+                                                     int64_t rows, int D, int lpr, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, float eps,
                                                      float* __restrict__ out, float* __restrict__ stats) {
-  const int64_t r = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
-  if (r >= rows) return;
-  const float* yr = y + r * D;
-  const float* xr = res + r * D;
-  float mu = 0.f;
-  for (int d = 0; d < D; ++d) mu += yr[d] + xr[d];
+  const int64_t t = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  const int64_t r = t / lpr;
+  const int d = static_cast<int>(t % lpr);
+  const bool live = r < rows && d < D;
+  const float v = live ? y[r * D + d] + res[r * D + d] : 0.f;
+  float mu = v;
+  for (int m = 1; m < lpr; m <<= 1) mu += __shfl_xor(mu, m, kWave);
   mu /= D;
-  float var = 0.f;
-  for (int d = 0; d < D; ++d) { const float c = yr[d] + xr[d] - mu; var = fmaf(c, c, var); }
+  const float c = live ? v - mu : 0.f;
+  float var = c * c;
+  for (int m = 1; m < lpr; m <<= 1) var += __shfl_xor(var, m, kWave);
   const float rstd = rsqrtf(var / D + eps);
-  for (int d = 0; d < D; ++d) out[r * D + d] = (yr[d] + xr[d] - mu) * rstd * gamma[d] + beta[d];
-  stats[2 * r] = mu;
-  stats[2 * r + 1] = rstd;
+  if (live) {
+    out[r * D + d] = c * rstd * gamma[d] + beta[d];
+    if (d == 0) { stats[2 * r] = mu; stats[2 * r + 1] = rstd; }
+  }
 }
 
-// g_s = rstd * (g*gamma - mean(g*gamma) - xhat * mean(g*gamma*xhat));  partial d gamma / d beta per
-// workgroup (rows of one block, added in row order) into partial[block][2][D].
+// g_s = rstd * (g*gamma - mean(g*gamma) - xhat * mean(g*gamma*xhat)).  A workgroup owns kLnRows
+// consecutive rows; lane (sub-row, d) also accumulates d gamma[d] = sum g*xhat and d beta[d] = sum g
+// over its rows, combined across sub-rows in a fixed order into partial[block][2][D].
+constexpr int kLnRows = 128;
 __global__ __launch_bounds__(256) void layernorm_bwd(const float* __restrict__ g, const float* __restrict__ y,
                                                      const float* __restrict__ res,
-                                                     const float* __restrict__ stats, int64_t rows, int D,
+                                                     const float* __restrict__ stats, int64_t rows, int D, int lpr,
                                                      const float* __restrict__ gamma, float* __restrict__ g_s,
                                                      float* __restrict__ partial) {
-  extern __shared__ float acc[];     // [2][D] per-block sums, then per-thread staging of xhat*g
-  const int64_t r = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
-  const bool live = r < rows;
-  float mu = 0.f, rstd = 0.f, m1 = 0.f, m2 = 0.f;
-  if (live) {
-    mu = stats[2 * r]; rstd = stats[2 * r + 1];
-    for (int d = 0; d < D; ++d) {
-      const float xh = (y[r * D + d] + res[r * D + d] - mu) * rstd;
-      const float gg = g[r * D + d] * gamma[d];
-      m1 += gg;
-      m2 = fmaf(gg, xh, m2);
+  __shared__ float red[2][256];
+  const int rpp = 256 / lpr;                       // rows per pass
+  const int sr = threadIdx.x / lpr, d = threadIdx.x % lpr;
+  const int64_t r0 = static_cast<int64_t>(blockIdx.x) * kLnRows;
+  const float ga = d < D ? gamma[d] : 0.f;
+  float sg = 0.f, sb = 0.f;
+  for (int pass = 0; pass < kLnRows / rpp; ++pass) {
+    const int64_t r = r0 + pass * rpp + sr;
+    const bool live = r < rows && d < D;
+    float gv = 0.f, xh = 0.f, rstd = 0.f;
+    if (live) {
+      rstd = stats[2 * r + 1];
+      xh = (y[r * D + d] + res[r * D + d] - stats[2 * r]) * rstd;
+      gv = g[r * D + d];
     }
+    const float gg = gv * ga;
+    float m1 = gg, m2 = gg * xh;
+    for (int m = 1; m < lpr; m <<= 1) { m1 += __shfl_xor(m1, m, kWave); m2 += __shfl_xor(m2, m, kWave); }
     m1 /= D; m2 /= D;
-    for (int d = 0; d < D; ++d) {
-      const float xh = (y[r * D + d] + res[r * D + d] - mu) * rstd;
-      const float gg = g[r * D + d] * gamma[d];
-      g_s[r * D + d] = rstd * (gg - m1 - xh * m2);
-    }
+    if (live) g_s[r * D + d] = rstd * (gg - m1 - xh * m2);
+    sg = fmaf(gv, xh, sg);
+    sb += gv;
   }
-  // d gamma[d] = sum_rows g*xhat, d beta[d] = sum_rows g: thread d sums the block's rows in order
+  red[0][threadIdx.x] = sg;
+  red[1][threadIdx.x] = sb;
   __syncthreads();
-  for (int d = threadIdx.x; d < D; d += 256) {
-    float sg = 0.f, sb = 0.f;
-    const int64_t r0 = static_cast<int64_t>(blockIdx.x) * 256;
-    const int64_t r1 = r0 + 256 < rows ? r0 + 256 : rows;
-    for (int64_t rr = r0; rr < r1; ++rr) {
-      const float xh = (y[rr * D + d] + res[rr * D + d] - stats[2 * rr]) * stats[2 * rr + 1];
-      const float gv = g[rr * D + d];
-      sg = fmaf(gv, xh, sg);
-      sb += gv;
-    }
-    partial[(static_cast<int64_t>(blockIdx.x) * 2 + 0) * D + d] = sg;
-    partial[(static_cast<int64_t>(blockIdx.x) * 2 + 1) * D + d] = sb;
+  if (sr == 0 && d < D) {
+    float tg = 0.f, tb = 0.f;
+    for (int i = 0; i < rpp; ++i) { tg += red[0][i * lpr + d]; tb += red[1][i * lpr + d]; }
+    partial[(static_cast<int64_t>(blockIdx.x) * 2 + 0) * D + d] = tg;
+    partial[(static_cast<int64_t>(blockIdx.x) * 2 + 1) * D + d] = tb;
   }
-  (void)acc;
 }
 
+// d gamma / d beta += column sums of the partial planes: 16 lanes per column, fixed order
 __global__ __launch_bounds__(256) void layernorm_bwd_finalize(const float* __restrict__ partial, int blocks, int D,
                                                               float* __restrict__ d_gamma,
                                                               float* __restrict__ d_beta) {
-  const int d = blockIdx.x * 256 + threadIdx.x;
-  if (d >= D) return;
+  __shared__ float red[2][16][16];
+  const int cl = threadIdx.x % 16, sl = threadIdx.x / 16;
+  const int d = blockIdx.x * 16 + cl;
   float sg = 0.f, sb = 0.f;
-  for (int i = 0; i < blocks; ++i) {
-    sg += partial[(static_cast<int64_t>(i) * 2 + 0) * D + d];
-    sb += partial[(static_cast<int64_t>(i) * 2 + 1) * D + d];
+  if (d < D) {
+    for (int i = sl; i < blocks; i += 16) {
+      sg += partial[(static_cast<int64_t>(i) * 2 + 0) * D + d];
+      sb += partial[(static_cast<int64_t>(i) * 2 + 1) * D + d];
+    }
   }
-  d_gamma[d] += sg;
-  d_beta[d] += sb;
+  red[0][sl][cl] = sg;
+  red[1][sl][cl] = sb;
+  __syncthreads();
+  if (sl == 0 && d < D) {
+    float tg = 0.f, tb = 0.f;
+    for (int i = 0; i < 16; ++i) { tg += red[0][i][cl]; tb += red[1][i][cl]; }
+    d_gamma[d] += tg;
+    d_beta[d] += tb;
+  }
 }
 
 namespace {
@@ -300,7 +330,7 @@ extern "C" int dfm_attention_core_backward(const float* d_qkv, const float* d_g_
   const int hd = attention_dim / num_heads;
   const int64_t units = batch * num_heads;
   const dim3 grid(static_cast<unsigned>((units + kWavesPerBlock - 1) / kWavesPerBlock)), block(kWavesPerBlock * 64);
-  const size_t lds = sizeof(float) * kWavesPerBlock * (4 * num_fields * hd + 2 * num_fields * num_fields);
+  const size_t lds = sizeof(float) * kWavesPerBlock * (4 * num_fields * hd + num_fields * num_fields);
   DFM_REQUIRE(lds <= 160 * 1024, "attention core backward needs %zu bytes of LDS", lds);
   hipStream_t st = as_stream(stream);
 #define DFM_CORE(HD)                                                                                        \
@@ -316,18 +346,23 @@ extern "C" int dfm_attention_core_backward(const float* d_qkv, const float* d_g_
   return DFM_OK;
 }
 
+namespace {
+int ln_lanes(int dim) { int l = 1; while (l < dim) l <<= 1; return l; }
+}
 extern "C" size_t dfm_layernorm_workspace_bytes(int64_t rows, int dim) {
-  return sizeof(float) * 2 * static_cast<size_t>((rows + 255) / 256) * dim;
+  return sizeof(float) * 2 * static_cast<size_t>((rows + kLnRows - 1) / kLnRows) * dim;
 }
 
 extern "C" int dfm_layernorm_forward(const float* d_y, const float* d_res, int64_t rows, int dim,
                                      const float* d_gamma, const float* d_beta, float eps, float* d_out,
                                      float* d_stats, dfm_stream_t stream) {
   DFM_REQUIRE(d_y && d_res && d_gamma && d_beta && d_out && d_stats, "null argument");
-  DFM_REQUIRE(rows >= 0 && dim > 0, "bad shape");
+  DFM_REQUIRE(rows >= 0 && dim > 0 && dim <= 64, "LayerNorm kernel supports 1 <= dim <= 64");
   if (rows == 0) return DFM_OK;
-  hipLaunchKernelGGL(layernorm_fwd, dim3(static_cast<unsigned>((rows + 255) / 256)), dim3(256), 0, as_stream(stream),
-                     d_y, d_res, rows, dim, d_gamma, d_beta, eps, d_out, d_stats);
+  const int lpr = ln_lanes(dim);
+  const int64_t threads = rows * lpr;
+  hipLaunchKernelGGL(layernorm_fwd, dim3(static_cast<unsigned>((threads + 255) / 256)), dim3(256), 0,
+                     as_stream(stream), d_y, d_res, rows, dim, lpr, d_gamma, d_beta, eps, d_out, d_stats);
   DFM_LAUNCH_CHECK();
   return DFM_OK;
 }
@@ -338,15 +373,15 @@ extern "C" int dfm_layernorm_backward(const float* d_g_out, const float* d_y, co
                                       dfm_stream_t stream) {
   DFM_REQUIRE(d_g_out && d_y && d_res && d_stats && d_gamma && d_g_sum && d_g_gamma && d_g_beta && d_workspace,
               "null argument");
-  DFM_REQUIRE(rows >= 0 && dim > 0, "bad shape");
+  DFM_REQUIRE(rows >= 0 && dim > 0 && dim <= 64, "LayerNorm kernel supports 1 <= dim <= 64");
   if (rows == 0) return DFM_OK;
   hipStream_t st = as_stream(stream);
-  const int blocks = static_cast<int>((rows + 255) / 256);
+  const int blocks = static_cast<int>((rows + kLnRows - 1) / kLnRows);
   float* partial = static_cast<float*>(d_workspace);
-  hipLaunchKernelGGL(layernorm_bwd, dim3(blocks), dim3(256), 0, st, d_g_out, d_y, d_res, d_stats, rows, dim, d_gamma,
-                     d_g_sum, partial);
+  hipLaunchKernelGGL(layernorm_bwd, dim3(blocks), dim3(256), 0, st, d_g_out, d_y, d_res, d_stats, rows, dim,
+                     ln_lanes(dim), d_gamma, d_g_sum, partial);
   DFM_LAUNCH_CHECK();
-  hipLaunchKernelGGL(layernorm_bwd_finalize, dim3((dim + 255) / 256), dim3(256), 0, st, partial, blocks, dim,
+  hipLaunchKernelGGL(layernorm_bwd_finalize, dim3((dim + 15) / 16), dim3(256), 0, st, partial, blocks, dim,
                      d_g_gamma, d_g_beta);
   DFM_LAUNCH_CHECK();
   return DFM_OK;

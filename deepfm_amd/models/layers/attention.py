@@ -48,7 +48,7 @@ class _AttentionBlock(nn.Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         lib = _lib.load()
         if self.gemm_path and lib.dfm_attention_core_supported(x.shape[1], self.attention_dim, self.num_heads) \
-                and self.embed_dim % 4 == 0 and self.attention_dim % 4 == 0:
+                and self.embed_dim % 4 == 0 and self.attention_dim % 4 == 0 and self.embed_dim <= 64:
             return _AttnGemmFn.apply(self, x, *self._param_list())
         return _AttnFn.apply(self, x, *self._param_list())
 
