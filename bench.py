@@ -140,11 +140,12 @@ def main():
 
     total = args.steps + args.warmup
     ids, dense, labels = make_pool(total, n_sparse, n_dense, B, V, 1 + rank, dev)
-    step.load_batch(ids[0], dense[0], labels[0])
+    records = step.pack_batches(ids, dense, labels)      # one record per batch, resident in HBM
+    step.load_packed(records[0])
     step.capture()
 
     def run(i, timed):
-        step.load_batch(ids[i], dense[i], labels[i])
+        step.load_packed(records[i])                      # one D2D copy per step
         step.run(time_gather=timed)
 
     for i in range(args.warmup):

@@ -128,7 +128,8 @@ class _AttnGemmFn(torch.autograd.Function):
         X, qkv, o, y, stats, w_qkv, wo, gamma = ctx.saved_tensors
         dev = X.device
         g = g_out.contiguous().view(M, D)
-        ones = torch.ones(M, 1, dtype=torch.float32, device=dev)
+        from deepfm_amd.models.layers.linear import ones_column
+        ones = ones_column(M, dev)
         grads = []
         if block.use_residual:
             g_y = torch.empty(M, D, dtype=torch.float32, device=dev)

@@ -15,6 +15,18 @@ import torch.nn as nn
 from deepfm_amd.models.layers.dnn import _gemm, _grad_target
 
 
+_ONES = {}
+
+
+def ones_column(m: int, device: torch.device) -> torch.Tensor:
+    """Cached (m, 1) vector of ones: bias gradients are column sums computed as a GEMM."""
+    key = (m, device.type, device.index)
+    t = _ONES.get(key)
+    if t is None:
+        t = _ONES[key] = torch.ones(m, 1, dtype=torch.float32, device=device)
+    return t
+
+
 class _LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
@@ -40,7 +52,7 @@ class _LinearFn(torch.autograd.Function):
         d_b = None
         if b_p is not None:
             tb = _grad_target(b_p)
-            ones = torch.ones(M, 1, dtype=torch.float32, device=g.device)
+            ones = ones_column(M, g.device)
             d_b = None if tb is not None else torch.empty_like(b_p)
             tgt = (tb if tb is not None else d_b).view(N, 1)
             _gemm(g, N, False, ones, 1, False, tgt, N, 1, M, accumulate=tb is not None)     # column sums of g

@@ -34,10 +34,17 @@ class RowSparseTrainStep:
         specs = list(model.schema.fields.values())
         self.n_sparse = sum(s.feature_type is FeatureType.SPARSE for s in specs)
         self.n_dense = sum(s.feature_type is FeatureType.DENSE for s in specs)
-        # static, packed inputs: one row per field; the per-field (B,) views keep the dict contract
-        self.ids = torch.zeros(max(self.n_sparse, 1), batch_size, dtype=torch.int64, device=dev)
-        self.dense = torch.zeros(max(self.n_dense, 1), batch_size, dtype=torch.float32, device=dev)
-        self.labels = torch.zeros(batch_size, dtype=torch.float32, device=dev)
+        # static, packed inputs in ONE buffer [ids (S,B) int64 | dense (Dn,B) f32 | labels (B) f32]: a
+        # whole batch is loaded with a single device-to-device copy; the per-field (B,) views keep
+        # the reference's dict contract
+        ns, nd = max(self.n_sparse, 1), max(self.n_dense, 1)
+        self.packed_bytes = ns * batch_size * 8 + nd * batch_size * 4 + batch_size * 4
+        self.packed = torch.zeros(self.packed_bytes, dtype=torch.uint8, device=dev)
+        o1 = ns * batch_size * 8
+        o2 = o1 + nd * batch_size * 4
+        self.ids = self.packed[:o1].view(torch.int64).view(ns, batch_size)
+        self.dense = self.packed[o1:o2].view(torch.float32).view(nd, batch_size)
+        self.labels = self.packed[o2:].view(torch.float32)
         self.inputs: List[torch.Tensor] = []
         si = di = 0
         for s in specs:
@@ -64,6 +71,26 @@ class RowSparseTrainStep:
         if self.n_dense:
             self.dense.copy_(dense, non_blocking=True)
         self.labels.copy_(labels, non_blocking=True)
+
+    def pack_batches(self, ids: torch.Tensor, dense: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+        """(n, S, B) int64, (n, Dn, B) f32, (n, B) f32 -> (n, packed_bytes) uint8 records for
+        ``load_packed`` (done once, outside any timed region)."""
+        n = labels.shape[0]
+        parts = []
+        if self.n_sparse:
+            parts.append(ids.contiguous().view(n, -1).view(torch.uint8))
+        else:
+            parts.append(torch.zeros(n, self.B * 8, dtype=torch.uint8, device=labels.device))
+        if self.n_dense:
+            parts.append(dense.contiguous().view(n, -1).view(torch.uint8))
+        else:
+            parts.append(torch.zeros(n, self.B * 4, dtype=torch.uint8, device=labels.device))
+        parts.append(labels.contiguous().view(n, -1).view(torch.uint8))
+        return torch.cat(parts, dim=1).contiguous()
+
+    def load_packed(self, record: torch.Tensor) -> None:
+        """One device-to-device copy of a pack_batches() record into the static inputs."""
+        self.packed.copy_(record, non_blocking=True)
 
     def _gather(self) -> None:
         self.emb.forward_into(self.inputs, self.B, self.fo, self.fe)
