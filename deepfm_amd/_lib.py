@@ -12,7 +12,8 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libdeepfm_hip.so")
+# DFM_LIB_PATH: load another build of the same library (A/B timing of kernel variants)
+LIB_PATH = os.environ.get("DFM_LIB_PATH") or os.path.join(_HERE, "lib", "libdeepfm_hip.so")
 
 MAX_FIELDS = 64
 ROWPLAN_CHUNK = 4096

@@ -26,7 +26,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BM = 64, BN = 64, BK = 32;
 constexpr int LDS_STRIDE = BK + 1;               // padded row: bank = (row + k) % 32
-constexpr int kThreads = 256;
+constexpr int kThreads = 512;                    // 8 waves: 4 output tiles x 2 k-halves
 
 // Stage a (64 rows x 32 k) slice of an operand into LDS as [row][k] (stride 33).
 //   KC:      global element (r, k) at base[r*ld + k]  -> float4 along k
@@ -37,11 +37,11 @@ constexpr int kThreads = 256;
 // the guarded element-wise path runs (ragged shapes; correctness only).
 template <bool KC, bool FAST>
 __device__ __forceinline__ void load_slice(const float* __restrict__ base, int64_t ld, int r0, int rows, int k0,
-                                           int kend, float4 (&v)[2], bool (&okv)[2]) {
+                                           int kend, float4 (&v)[1], bool (&okv)[1]) {
   const int tid = threadIdx.x;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int p = tid + i * kThreads;             // 512 float4 pieces per slice
+  for (int i = 0; i < 1; ++i) {
+    const int p = tid + i * kThreads;             // 512 float4 pieces per slice (one per thread)
     int r, k;
     if (KC) { r = r0 + (p >> 3); k = k0 + (p & 7) * 4; }        // 8 pieces per row, along k
     else    { k = k0 + (p >> 4); r = r0 + (p & 15) * 4; }       // 16 pieces per k, along r
@@ -65,12 +65,12 @@ __device__ __forceinline__ void load_slice(const float* __restrict__ base, int64
 }
 
 template <bool KC>
-__device__ __forceinline__ void store_slice(float* __restrict__ lds, const float4 (&vin)[2], const bool (&okv)[2]) {
+__device__ __forceinline__ void store_slice(float* __restrict__ lds, const float4 (&vin)[1], const bool (&okv)[1]) {
   const int tid = threadIdx.x;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < 1; ++i) {
     const int p = tid + i * kThreads;
-    float4 v[2];
+    float4 v[1];
     v[i] = okv[i] ? vin[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     if (KC) {
       const int row = p >> 3, kq = (p & 7) * 4;
@@ -95,12 +95,16 @@ __global__ __launch_bounds__(kThreads) void gemm_f32_kernel(
   __shared__ float lds_b[2][BN * LDS_STRIDE];
   const int lane = lane_id(), wave = wave_id_uniform();
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;   // this wave's 32x32 tile inside the block tile
+  // waves 0-3 and 4-7 own the same four 32x32 tiles but opposite halves of every 32-deep k slice:
+  // each SIMD then holds two independent MFMA chains (one per wave) that hide each other's LDS
+  // latency; the two partial tiles are added through LDS at the end (fixed order: half 0 + half 1)
+  const int tile = wave & 3, khalf = wave >> 2;
+  const int wm = (tile >> 1) * 32, wn = (tile & 1) * 32;
   const int kb = blockIdx.z * k_per_split;
   const int ke = kb + k_per_split < K ? kb + k_per_split : K;
   f32x16 acc = {};
-  float4 va[2], vb[2];
-  bool oka[2], okb[2];
+  float4 va[1], vb[1];
+  bool oka[1], okb[1];
   load_slice<A_KC, A_FAST>(A, lda, m0, M, kb, ke, va, oka);
   load_slice<B_KC, B_FAST>(B, ldb, n0, N, kb, ke, vb, okb);
   store_slice<A_KC>(lds_a[0], va, oka);
@@ -122,13 +126,24 @@ __global__ __launch_bounds__(kThreads) void gemm_f32_kernel(
       load_slice<A_KC, A_FAST>(A, lda, m0, M, k0 + 2 * BK, ke, va, oka);
       load_slice<B_KC, B_FAST>(B, ldb, n0, N, k0 + 2 * BK, ke, vb, okb);
     }
-    const float* pa = lds_a[buf] + (wm + r) * LDS_STRIDE + hf;
-    const float* pb = lds_b[buf] + (wn + r) * LDS_STRIDE + hf;
+    const float* pa = lds_a[buf] + (wm + r) * LDS_STRIDE + hf + khalf * (BK / 2);
+    const float* pb = lds_b[buf] + (wn + r) * LDS_STRIDE + hf + khalf * (BK / 2);
 #pragma unroll
-    for (int kk = 0; kk < BK; kk += 2)
+    for (int kk = 0; kk < BK / 2; kk += 2)
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[kk], pb[kk], acc, 0, 0, 0);
     __syncthreads();
   }
+  // combine the two k-halves: waves 4-7 park their tile in LDS (the staging buffers are free after
+  // the loop's last barrier), waves 0-3 add it and write the result
+  float* park = lds_a[0];                      // 4 tiles x 16 regs x 64 lanes = 16 KiB <= sizeof(lds_a)
+  if (khalf == 1) {
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) park[(tile * 16 + reg) * 64 + lane] = acc[reg];
+  }
+  __syncthreads();
+  if (khalf == 1) return;
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg) acc[reg] += park[(tile * 16 + reg) * 64 + lane];
   // accumulator: col n = lane & 31, row m = (reg&3) + 8*(reg>>2) + 4*hf
   const int n = n0 + wn + r;
   if (n >= N) return;

@@ -27,11 +27,36 @@ def _pair(in_dim, hidden, dropout):
     return fused, plain
 
 
+def _relu_masks_agree(fused, plain, x):
+    """True when both paths sit on the same side of every ReLU kink for this input.  The two
+    paths sum the Linear layers in different orders, so a pre-activation within a few ulp of 0
+    can land on different sides; the derivative is discontinuous there, and through BatchNorm
+    one flipped element moves the gradient of every row — gradient parity is only defined
+    away from the kinks."""
+    from deepfm_amd.models.layers.dnn import _LinearBnReluDropoutFn
+    fa, pb = copy.deepcopy(fused), copy.deepcopy(plain)      # keep the running statistics untouched
+    ha, hb = x, x
+    with torch.no_grad():
+        for i in range(len(fa.mlp) // 4):
+            lin, bn, act, drop = (fa.mlp[4 * i + j] for j in range(4))
+            ha = _LinearBnReluDropoutFn.apply(ha, lin.weight, lin.bias, bn.weight, bn.bias, bn, 0.0, None, i)
+            hb = pb.mlp[4 * i + 2](pb.mlp[4 * i + 1](pb.mlp[4 * i](hb)))
+            if not torch.equal(ha > 0, hb > 0):
+                return False
+    return True
+
+
 @pytest.mark.parametrize("shape", [(4096, 624, [256, 128, 64]), (37, 10, [7, 5]), (2, 3, [4])])
 def test_fused_matches_torch_modules(shape):
     B, in_dim, hidden = shape
     fused, plain = _pair(in_dim, hidden, 0.0)
-    x = torch.randn(B, in_dim, device="cuda") * 2 + 0.5
+    for attempt in range(20):
+        g0 = torch.Generator(device="cuda").manual_seed(100 + attempt)
+        x = torch.randn(B, in_dim, device="cuda", generator=g0) * 2 + 0.5
+        if _relu_masks_agree(fused, plain, x):
+            break
+    else:
+        pytest.fail("no input without a ReLU-kink disagreement in 20 draws")
     xa, xb = x.clone().requires_grad_(), x.clone().requires_grad_()
     ya, yb = fused(xa), plain(xb)
     rtol = 1e-2 if B < 8 else 1e-4        # a batch of 2 makes BatchNorm itself ill-conditioned
@@ -44,7 +69,9 @@ def test_fused_matches_torch_modules(shape):
         zero_grad = k.endswith(".bias") and int(k.split(".")[1]) % 4 == 0     # Linear bias before BN
         assert pa.grad is not None, k
         # (identically-zero gradient: both sides hold rounding noise that grows with the batch)
-        assert_close(npy(pa.grad), npy(pb.grad), rtol=rtol, what=k, floor=1e-3 if zero_grad else 0.0)
+        # a batch of 2 normalises to exactly +-1: every gradient through BatchNorm cancels to ~1e-6
+        floor = 1e-3 if zero_grad else (1e-6 if B < 8 else 0.0)
+        assert_close(npy(pa.grad), npy(pb.grad), rtol=rtol, what=k, floor=floor)
     for (k, ba), (_, bb) in zip(fused.named_buffers(), plain.named_buffers()):
         if k.endswith("num_batches_tracked"):
             assert int(ba) == int(bb) == 1
