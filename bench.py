@@ -109,11 +109,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    # DFM_BENCH_REHEARSAL=1: every rank on cuda:0 with the gloo backend — exercises the N>1 code
+    # path (two graphs + eager exchange) on a one-GPU box; its timings mean nothing
+    rehearsal = os.environ.get("DFM_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from deepfm_amd.config import ExperimentConfig
     from deepfm_amd.models import create_model
@@ -210,6 +218,7 @@ def main():
                 "global_batch": B * world,
                 "parallelism": f"dp{world}",
                 "hip_graph": not args.no_graph,
+                **({"rehearsal": "gloo, all ranks on cuda:0 (not a measurement)"} if rehearsal else {}),
                 "table_layout": "separate tensors" if args.unpacked else "packed 256-B row records",
                 "final_loss": loss,
             },

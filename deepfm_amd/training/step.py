@@ -161,6 +161,9 @@ class RowSparseTrainStep:
         if self.graph_a is not None:
             self.graph_a.replay()
             if self.graph_b is not None:
+                # the replay produced the row gradients; the Python-side flag was only set while
+                # the graph was being captured
+                self.emb.rowsparse.has_grad = True
                 self.opt.exchange()
                 self.graph_b.replay()
         else:
