@@ -1,0 +1,68 @@
+"""Worker of tests/test_gpu_dp_rehearsal.py: one data-parallel rank of the row-sparse step.
+
+Every rank runs on cuda:0 with the gloo backend (a one-GPU box cannot host two RCCL ranks);
+the step code is the one bench.py runs under RCCL: graph A -> eager exchange -> graph B.
+Rank 0 writes a JSON line with the per-rank parameter digests."""
+import hashlib
+import json
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def digest(t: torch.Tensor) -> str:
+    return hashlib.sha256(t.detach().cpu().contiguous().numpy().tobytes()).hexdigest()
+
+
+def main():
+    use_graph = sys.argv[1] == "graph"
+    steps = int(sys.argv[2])
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("gloo")
+    from deepfm_amd.config import ExperimentConfig
+    from deepfm_amd.models import create_model
+    from deepfm_amd.training.rowsparse import RowSparseAdam
+    from deepfm_amd.training.step import RowSparseTrainStep
+    from tests.helpers import schema_from_fields
+    from tools_shared import criteo_fields
+
+    B, V, D = 512, 300, 16          # small vocabulary: the ranks' row lists overlap heavily
+    fields = criteo_fields(V, D)
+    cfg = ExperimentConfig()
+    torch.manual_seed(0)
+    with torch.device(dev):
+        model = create_model("deepfm", schema_from_fields(fields), cfg)
+    model.train()
+    model.embedding.pack_tables_()
+    model.embedding.set_grad_mode("rowsparse")
+    opt = RowSparseAdam(model, lr=1e-2, l2=1e-5, max_grad_norm=1.0)
+    step = RowSparseTrainStep(model, opt, B, use_graph=use_graph)
+    g = torch.Generator(device=dev).manual_seed(100 + rank)          # a different shard per rank
+    ids = torch.randint(0, V, (steps + 1, 26, B), generator=g, device=dev, dtype=torch.int64)
+    dense = torch.rand((steps + 1, 13, B), generator=g, device=dev)
+    labels = (torch.rand((steps + 1, B), generator=g, device=dev) < 0.3).float()
+    step.load_batch(ids[0], dense[0], labels[0])
+    step.capture()
+    for i in range(steps):
+        step.load_batch(ids[i + 1], dense[i + 1], labels[i + 1])
+        step.run()
+    torch.cuda.synchronize()
+    tables = torch.cat([p.detach().reshape(-1) for p in model.embedding.table_parameters()])
+    mine = {"flat": digest(opt.flat_param), "tables": digest(tables), "loss": float(step.loss),
+            "moved": float((tables != 0).float().mean())}
+    out = [None] * world
+    dist.all_gather_object(out, mine)
+    if rank == 0:
+        print("RESULT " + json.dumps(out), flush=True)
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
