@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--vocab", type=int, default=1_000_000)
     ap.add_argument("--dim", type=int, default=16)
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly")
+    ap.add_argument("--autograd", action="store_true", help="torch.autograd step instead of the fused tower kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--unpacked", action="store_true", help="keep the tables as separate contiguous tensors")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -144,7 +145,9 @@ def main():
     model.embedding.set_grad_mode("rowsparse")
     hp = dict(lr=cfg.training.lr, l2=cfg.feature.embedding_l2_reg, max_grad_norm=cfg.training.gradient_clip_norm)
     opt = RowSparseAdam(model, lr=hp["lr"], l2=hp["l2"], max_grad_norm=hp["max_grad_norm"])
-    step = RowSparseTrainStep(model, opt, B, use_graph=not args.no_graph)
+    from deepfm_amd.training.fused_step import FusedDeepFMStep
+    fused = FusedDeepFMStep.eligible(model) and not args.autograd
+    step = (FusedDeepFMStep if fused else RowSparseTrainStep)(model, opt, B, use_graph=not args.no_graph)
 
     total = args.steps + args.warmup
     ids, dense, labels = make_pool(total, n_sparse, n_dense, B, V, 1 + rank, dev)
@@ -218,6 +221,7 @@ def main():
                 "global_batch": B * world,
                 "parallelism": f"dp{world}",
                 "hip_graph": not args.no_graph,
+                "step": "fused tower kernels (no autograd)" if fused else "torch.autograd over the HIP ops",
                 **({"rehearsal": "gloo, all ranks on cuda:0 (not a measurement)"} if rehearsal else {}),
                 "table_layout": "separate tensors" if args.unpacked else "packed 256-B row records",
                 "final_loss": loss,

@@ -46,6 +46,18 @@ class Table(C.Structure):
                 ("stride2", C.c_int32), ("stride1", C.c_int32)]
 
 
+class BnBwd(C.Structure):
+    """struct dfm_bn_bwd"""
+    _fields_ = [("z", C.c_void_p), ("mean_rstd", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p),
+                ("dy", C.c_void_p), ("means", C.c_void_p), ("g_gamma", C.c_void_p), ("g_beta", C.c_void_p),
+                ("seed", C.c_void_p), ("workspace", C.c_void_p), ("p_drop", C.c_float), ("salt", C.c_int32)]
+
+
+class FmBwd(C.Structure):
+    """struct dfm_fm_bwd"""
+    _fields_ = [("g_fm", C.c_void_p), ("fm_sum", C.c_void_p), ("e", C.c_void_p), ("dim", C.c_int32)]
+
+
 # name -> (restype, argtypes); must list every symbol of include/deepfm_hip.h
 _P, _I, _L, _F, _SZ = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 SIGNATURES = {
@@ -57,7 +69,7 @@ SIGNATURES = {
     "dfm_embedding_plan_destroy": (_I, [_P]),
     "dfm_embedding_plan_is_uniform": (_I, [_P]),
     "dfm_embedding_workspace_bytes": (_SZ, [_P, _L]),
-    "dfm_embedding_forward": (_I, [_P, C.POINTER(_P), _L, _P, _P, _P, _P, _P, _P, _P]),
+    "dfm_embedding_forward": (_I, [_P, C.POINTER(_P), _L, _P, _P, _P, _P, _P, _P, _P, _P]),
     "dfm_embedding_backward_dense": (_I, [_P, C.POINTER(_P), _L, _P, _P, _P, C.POINTER(FieldGrad), _P, _P]),
     "dfm_embedding_backward_dense_fields": (_I, [_P, C.POINTER(_P), _L, _P, _P, _P, C.POINTER(FieldGrad), _P]),
     "dfm_rowplan_build": (_I, [C.POINTER(_P), C.POINTER(C.c_int32), _I, _L, _P, _P, _P, _P, _P, _P]),
@@ -92,6 +104,15 @@ SIGNATURES = {
     "dfm_layernorm_workspace_bytes": (_SZ, [_L, _I]),
     "dfm_layernorm_forward": (_I, [_P, _P, _L, _I, _P, _P, _F, _P, _P, _P]),
     "dfm_layernorm_backward": (_I, [_P, _P, _P, _P, _L, _I, _P, _P, _P, _P, _P, _P]),
+    "dfm_linear_bn_workspace_bytes": (_SZ, [_L, _I]),
+    "dfm_linear_bn_forward": (_I, [_P, _L, _P, _P, _L, _I, _I, _P, _P, _P, _P, _P, _F, _F, _P, _P]),
+    "dfm_bn_relu_dropout_apply": (_I, [_P, _L, _I, _P, _P, _P, _F, _P, _I, _P, _P]),
+    "dfm_bn_bwd_workspace_bytes": (_SZ, [_L, _I]),
+    "dfm_bn_backward_apply": (_I, [_P, _P, _P, _P, _P, _L, _I, _P, _P]),
+    "dfm_head_bce_workspace_bytes": (_SZ, [_L, _I]),
+    "dfm_head_bce": (_I, [_P, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(BnBwd), _P, _P]),
+    "dfm_linear_backward_workspace_bytes": (_SZ, [_L, _I, _I]),
+    "dfm_linear_backward": (_I, [_P, _L, _I, _P, _I, _P, _P, _P, C.POINTER(BnBwd), C.POINTER(FmBwd), _P, _P]),
     "dfm_fm_forward": (_I, [_P, _L, _I, _I, _P, _P]),
     "dfm_fm_backward": (_I, [_P, _P, _L, _I, _I, _P, _P]),
 }

@@ -11,6 +11,7 @@
 // device memory so the same mask is rebuilt in the backward and a captured graph sees a new
 // seed every replay.  z is (M, N) row-major, N <= 4096.
 #include "common.h"
+#include "dropout.h"
 
 using namespace dfm;
 
@@ -18,23 +19,8 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kRowsPerSlice = 16;
 
-__device__ __forceinline__ uint32_t mix32(uint64_t x) {
-  x ^= x >> 33; x *= 0xff51afd7ed558ccdull;
-  x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull;
-  x ^= x >> 33;
-  return static_cast<uint32_t>(x);
-}
-__device__ __forceinline__ float drop_scale(int64_t seed, int salt, int64_t idx, uint32_t thresh, float inv_keep) {
-  if (thresh == 0) return 1.f;
-  const uint32_t r = mix32(static_cast<uint64_t>(seed) * 0x9E3779B97F4A7C15ull + (static_cast<uint64_t>(salt) << 40) + static_cast<uint64_t>(idx));
-  return r >= thresh ? inv_keep : 0.f;
-}
 inline int slices_for(int64_t M) { return static_cast<int>((M + kRowsPerSlice - 1) / kRowsPerSlice); }
-inline uint32_t thresh_for(float p) {
-  if (p <= 0.f) return 0;
-  const double t = static_cast<double>(p) * 4294967296.0;
-  return t >= 4294967295.0 ? 4294967295u : static_cast<uint32_t>(t);
-}
+inline uint32_t thresh_for(float p) { return dropout_thresh(p); }
 }  // namespace
 
 // Three launches each way: partial column sums over 16-row slices (one workgroup per slice,

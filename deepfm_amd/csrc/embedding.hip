@@ -70,7 +70,8 @@ struct UniformArgs {
 template <int D, int W, bool HAS_SPARSE, bool HAS_DENSE>
 __device__ __forceinline__ void emb_fwd_uniform_body(
     const UniformArgs& args, int ns, int nd, int64_t B, int F, float* __restrict__ first_order,
-    float* __restrict__ fe, float* __restrict__ fm_out, int32_t* error_flag, int ablate = 0) {
+    float* __restrict__ fe, float* __restrict__ fm_out, float* __restrict__ fm_sum, int32_t* error_flag,
+    int ablate = 0) {
   constexpr int LPR = D / 4;        // lanes per row (16 B each)
   constexpr int SPW = kWave / LPR;  // samples per wave == samples per block
   constexpr int US = HAS_SPARSE ? 4 : 0;  // sparse slots in flight per wave
@@ -191,6 +192,8 @@ __device__ __forceinline__ void emb_fwd_uniform_body(
       first_order[b] = acc[8];
       if (fm_out) fm_out[b] = 0.5f * t;
     }
+    // S[b, :] = sum_f e[b, f, :] for the FM backward g * (S - e)
+    if (live && fm_sum) st4(fm_sum + b * D + q * 4, make_float4(acc[0], acc[1], acc[2], acc[3]));
   }
 }
 
@@ -198,16 +201,16 @@ __device__ __forceinline__ void emb_fwd_uniform_body(
 template <int D, int W, bool HAS_SPARSE, bool HAS_DENSE>
 __global__ __launch_bounds__(W * 64) void emb_fwd_uniform(
     UniformArgs args, int ns, int nd, int64_t B, int F, float* __restrict__ first_order,
-    float* __restrict__ fe, float* __restrict__ fm_out, int32_t* error_flag, int ablate) {
-  emb_fwd_uniform_body<D, W, HAS_SPARSE, HAS_DENSE>(args, ns, nd, B, F, first_order, fe, fm_out, error_flag, ablate);
+    float* __restrict__ fe, float* __restrict__ fm_out, float* __restrict__ fm_sum, int32_t* error_flag, int ablate) {
+  emb_fwd_uniform_body<D, W, HAS_SPARSE, HAS_DENSE>(args, ns, nd, B, F, first_order, fe, fm_out, fm_sum, error_flag, ablate);
 }
 // ... or in device memory owned by the plan (refreshed only when a pointer changes)
 template <int D, int W, bool HAS_SPARSE, bool HAS_DENSE>
 __global__ __launch_bounds__(W * 64) void emb_fwd_uniform_mem(
     const UniformArgs* __restrict__ args, int ns, int nd, int64_t B, int F,
     float* __restrict__ first_order, float* __restrict__ fe, float* __restrict__ fm_out,
-    int32_t* error_flag, int ablate) {
-  emb_fwd_uniform_body<D, W, HAS_SPARSE, HAS_DENSE>(*args, ns, nd, B, F, first_order, fe, fm_out, error_flag, ablate);
+    float* __restrict__ fm_sum, int32_t* error_flag, int ablate) {
+  emb_fwd_uniform_body<D, W, HAS_SPARSE, HAS_DENSE>(*args, ns, nd, B, F, first_order, fe, fm_out, fm_sum, error_flag, ablate);
 }
 
 // ======================================================================================
@@ -532,7 +535,7 @@ static int gather_waves() {
 
 template <int D>
 static int launch_uniform(const dfm_embedding_plan* plan, const PtrTable& in, int64_t B,
-                          float* fo, float* fe, float* fm_out, int32_t* err, hipStream_t st) {
+                          float* fo, float* fe, float* fm_out, float* fm_sum, int32_t* err, hipStream_t st) {
   constexpr int SPW = kWave / (D / 4);
   UniformArgs args;
   memset(&args, 0, sizeof(args));
@@ -571,10 +574,10 @@ static int launch_uniform(const dfm_embedding_plan* plan, const PtrTable& in, in
   do {                                                                                                  \
     if (d_args)                                                                                         \
       hipLaunchKernelGGL((emb_fwd_uniform_mem<D, WV, HS, HD>), grid, dim3(WV * 64), 0, st, d_args, ns,  \
-                         nd, B, F, fo, fe, fm_out, err, g_ablate);                                      \
+                         nd, B, F, fo, fe, fm_out, fm_sum, err, g_ablate);                                      \
     else                                                                                                \
       hipLaunchKernelGGL((emb_fwd_uniform<D, WV, HS, HD>), grid, dim3(WV * 64), 0, st, args, ns, nd, B, \
-                         F, fo, fe, fm_out, err, g_ablate);                                             \
+                         F, fo, fe, fm_out, fm_sum, err, g_ablate);                                             \
   } while (0)
 #define DFM_GATHER_PICK(WV)                                    \
   do {                                                         \
@@ -595,7 +598,7 @@ static int launch_uniform(const dfm_embedding_plan* plan, const PtrTable& in, in
 
 extern "C" int dfm_embedding_forward(const dfm_embedding_plan* plan, const void* const* inputs, int64_t batch,
                           float* d_first_order, float* d_field_emb, float* d_flat_emb,
-                          float* d_fm_out, void* d_workspace, int32_t* d_error_flag,
+                          float* d_fm_out, float* d_fm_sum, void* d_workspace, int32_t* d_error_flag,
                           dfm_stream_t stream) {
   DFM_REQUIRE(plan && inputs && d_first_order && d_field_emb, "null argument");
   DFM_REQUIRE(batch >= 0 && batch < (int64_t(1) << 31), "batch %lld out of range", (long long)batch);
@@ -605,17 +608,17 @@ extern "C" int dfm_embedding_forward(const dfm_embedding_plan* plan, const void*
   hipStream_t st = as_stream(stream);
   if (plan->uniform && (d_flat_emb == nullptr || d_flat_emb == d_field_emb)) {
     switch (plan->fm_dim) {
-      case 4:   return launch_uniform<4>(plan, in, batch, d_first_order, d_field_emb, d_fm_out, d_error_flag, st);
-      case 8:   return launch_uniform<8>(plan, in, batch, d_first_order, d_field_emb, d_fm_out, d_error_flag, st);
-      case 16:  return launch_uniform<16>(plan, in, batch, d_first_order, d_field_emb, d_fm_out, d_error_flag, st);
-      case 32:  return launch_uniform<32>(plan, in, batch, d_first_order, d_field_emb, d_fm_out, d_error_flag, st);
-      case 64:  return launch_uniform<64>(plan, in, batch, d_first_order, d_field_emb, d_fm_out, d_error_flag, st);
-      case 128: return launch_uniform<128>(plan, in, batch, d_first_order, d_field_emb, d_fm_out, d_error_flag, st);
-      case 256: return launch_uniform<256>(plan, in, batch, d_first_order, d_field_emb, d_fm_out, d_error_flag, st);
+      case 4:   return launch_uniform<4>(plan, in, batch, d_first_order, d_field_emb, d_fm_out, d_fm_sum, d_error_flag, st);
+      case 8:   return launch_uniform<8>(plan, in, batch, d_first_order, d_field_emb, d_fm_out, d_fm_sum, d_error_flag, st);
+      case 16:  return launch_uniform<16>(plan, in, batch, d_first_order, d_field_emb, d_fm_out, d_fm_sum, d_error_flag, st);
+      case 32:  return launch_uniform<32>(plan, in, batch, d_first_order, d_field_emb, d_fm_out, d_fm_sum, d_error_flag, st);
+      case 64:  return launch_uniform<64>(plan, in, batch, d_first_order, d_field_emb, d_fm_out, d_fm_sum, d_error_flag, st);
+      case 128: return launch_uniform<128>(plan, in, batch, d_first_order, d_field_emb, d_fm_out, d_fm_sum, d_error_flag, st);
+      case 256: return launch_uniform<256>(plan, in, batch, d_first_order, d_field_emb, d_fm_out, d_fm_sum, d_error_flag, st);
       default: break;
     }
   }
-  DFM_REQUIRE(d_fm_out == nullptr, "fused FM output needs a uniform plan");
+  DFM_REQUIRE(d_fm_out == nullptr && d_fm_sum == nullptr, "fused FM outputs need a uniform plan");
   DFM_REQUIRE(d_flat_emb && d_flat_emb != d_field_emb, "general plan needs a separate flat_embeddings buffer");
   DFM_REQUIRE(d_workspace, "general plan needs workspace (dfm_embedding_workspace_bytes)");
   float* fo_parts = static_cast<float*>(d_workspace);

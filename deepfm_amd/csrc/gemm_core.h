@@ -1,0 +1,150 @@
+// Device-side core of the exact-fp32 MFMA GEMM (v_mfma_f32_32x32x2_f32), shared by the plain
+// GEMM entry point (gemm_f32.hip) and the fused DNN-tower kernels (tower.hip).
+//
+//   acc(m, n) = sum_{k in [kb, ke)} A(m, k) * B(n, k)      for one 64 x 64 output tile
+// Each operand is "K-contiguous" (element (r,k) at base[r*ld + k]) or "K-strided" (element
+// (r,k) at base[k*ld + r]).  A workgroup of 8 waves owns the tile: waves 0-3 and 4-7 hold the
+// same four 32 x 32 MFMA tiles but opposite halves of every 32-deep k slice (two independent
+// MFMA chains per SIMD); the halves are added through LDS in a fixed order (half 0 + half 1)
+// and the result lives in the accumulators of waves 0-3.  64 x 32 slices of A and B are staged
+// through LDS (coalesced 16-byte global loads in either layout, padded rows: conflict-free
+// fragment reads), double buffered.
+#pragma once
+
+#include "common.h"
+
+namespace dfm {
+namespace gemm {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 64, BN = 64, BK = 32;
+constexpr int LDS_STRIDE = BK + 1;               // padded row: bank = (row + k) % 32
+constexpr int kThreads = 512;                    // 8 waves: 4 output tiles x 2 k-halves
+
+struct Smem {
+  float a[2][BM * LDS_STRIDE];
+  float b[2][BN * LDS_STRIDE];
+};
+
+// Position of this thread's accumulator registers inside the workgroup's 64 x 64 tile.
+struct TilePos {
+  int tile, khalf;   // which 32x32 tile (0..3), which k-half (0: the wave that ends up with the sum)
+  int wm, wn;        // tile origin inside the block tile
+  int r, hf;         // column inside the tile (lane & 31), row-half selector (lane >> 5)
+  __device__ __forceinline__ TilePos() {
+    const int lane = lane_id(), wave = wave_id_uniform();
+    tile = wave & 3; khalf = wave >> 2;
+    wm = (tile >> 1) * 32; wn = (tile & 1) * 32;
+    r = lane & 31; hf = lane >> 5;
+  }
+  // accumulator register `reg` holds row (reg&3) + 8*(reg>>2) + 4*hf of the 32x32 tile, column r
+  __device__ __forceinline__ int row(int reg) const { return wm + (reg & 3) + 8 * (reg >> 2) + 4 * hf; }
+  __device__ __forceinline__ int col() const { return wn + r; }
+};
+
+// Stage a (64 rows x 32 k) slice of an operand into LDS as [row][k] (stride 33).
+//   KC:      global element (r, k) at base[r*ld + k]  -> float4 along k
+//   strided: global element (r, k) at base[k*ld + r]  -> float4 along r
+// FAST (chosen on the host): every 16-byte piece is either entirely inside the operand or
+// entirely outside (leading dimension and base 16-byte aligned, the vectorised extent a
+// multiple of 4), so the load is branch-free: clamp the address, load, select zero.  Otherwise
+// the guarded element-wise path runs (ragged shapes; correctness only).
+template <bool KC, bool FAST>
+__device__ __forceinline__ void load_slice(const float* __restrict__ base, int64_t ld, int r0, int rows, int k0,
+                                           int kend, float4& v, bool& okv) {
+  const int p = threadIdx.x;                      // 512 float4 pieces per slice, one per thread
+  int r, k;
+  if (KC) { r = r0 + (p >> 3); k = k0 + (p & 7) * 4; }        // 8 pieces per row, along k
+  else    { k = k0 + (p >> 4); r = r0 + (p & 15) * 4; }       // 16 pieces per k, along r
+  const int64_t off = KC ? static_cast<int64_t>(r) * ld + k : static_cast<int64_t>(k) * ld + r;
+  if (FAST) {
+    // the zero-select is applied at the LDS store: consuming the value here would make the
+    // compiler wait for this load before the MFMAs of the current slice
+    okv = r < rows && k < kend;
+    v = ld4(base + (okv ? off : 0));
+  } else {
+    float e[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool ok = KC ? (r < rows && k + j < kend) : (k < kend && r + j < rows);
+      e[j] = ok ? base[off + j] : 0.f;
+    }
+    v = make_float4(e[0], e[1], e[2], e[3]);
+    okv = true;
+  }
+}
+
+template <bool KC>
+__device__ __forceinline__ void store_slice(float* __restrict__ lds, const float4& vin, bool okv) {
+  const int p = threadIdx.x;
+  const float4 v = okv ? vin : make_float4(0.f, 0.f, 0.f, 0.f);
+  if (KC) {
+    const int row = p >> 3, kq = (p & 7) * 4;
+    float* d = lds + row * LDS_STRIDE + kq;
+    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+  } else {
+    const int kk = p >> 4, rq = (p & 15) * 4;
+    float* d = lds + rq * LDS_STRIDE + kk;
+    d[0] = v.x; d[LDS_STRIDE] = v.y; d[2 * LDS_STRIDE] = v.z; d[3 * LDS_STRIDE] = v.w;
+  }
+}
+
+// The whole k loop of one output tile.  On return `acc` is complete in the waves with
+// pos.khalf == 0; every wave has passed the same barriers and `sm` is free for the epilogue.
+template <bool A_KC, bool B_KC, bool A_FAST, bool B_FAST>
+__device__ __forceinline__ void mainloop(const float* __restrict__ A, int64_t lda, const float* __restrict__ B,
+                                         int64_t ldb, int M, int N, int m0, int n0, int kb, int ke, Smem& sm,
+                                         const TilePos& pos, f32x16& acc) {
+  const int lane = lane_id();
+  float4 va, vb;
+  bool oka, okb;
+  load_slice<A_KC, A_FAST>(A, lda, m0, M, kb, ke, va, oka);
+  load_slice<B_KC, B_FAST>(B, ldb, n0, N, kb, ke, vb, okb);
+  store_slice<A_KC>(sm.a[0], va, oka);
+  store_slice<B_KC>(sm.b[0], vb, okb);
+  if (kb + BK < ke) {
+    load_slice<A_KC, A_FAST>(A, lda, m0, M, kb + BK, ke, va, oka);
+    load_slice<B_KC, B_FAST>(B, ldb, n0, N, kb + BK, ke, vb, okb);
+  }
+  __syncthreads();
+  int buf = 0;
+  for (int k0 = kb; k0 < ke; k0 += BK, buf ^= 1) {
+    // slice k0+BK (already in registers) -> the other LDS buffer; then fetch slice k0+2*BK
+    if (k0 + BK < ke) {
+      store_slice<A_KC>(sm.a[buf ^ 1], va, oka);
+      store_slice<B_KC>(sm.b[buf ^ 1], vb, okb);
+    }
+    if (k0 + 2 * BK < ke) {
+      load_slice<A_KC, A_FAST>(A, lda, m0, M, k0 + 2 * BK, ke, va, oka);
+      load_slice<B_KC, B_FAST>(B, ldb, n0, N, k0 + 2 * BK, ke, vb, okb);
+    }
+    const float* pa = sm.a[buf] + (pos.wm + pos.r) * LDS_STRIDE + pos.hf + pos.khalf * (BK / 2);
+    const float* pb = sm.b[buf] + (pos.wn + pos.r) * LDS_STRIDE + pos.hf + pos.khalf * (BK / 2);
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; kk += 2)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[kk], pb[kk], acc, 0, 0, 0);
+    __syncthreads();
+  }
+  // combine the two k-halves: waves 4-7 park their tile in LDS (the staging buffers are free after
+  // the loop's last barrier), waves 0-3 add it (fixed order: half 0 + half 1)
+  float* park = &sm.a[0][0];                   // 4 tiles x 16 regs x 64 lanes = 16 KiB <= sizeof(sm.a)
+  if (pos.khalf == 1) {
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) park[(pos.tile * 16 + reg) * 64 + lane] = acc[reg];
+  }
+  __syncthreads();
+  if (pos.khalf == 0) {
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) acc[reg] += park[(pos.tile * 16 + reg) * 64 + lane];
+  }
+  __syncthreads();
+}
+
+// Host side: branch-free tile loads need all-or-nothing 16-byte pieces (see load_slice).
+static inline bool operand_fast(const float* p, int64_t ld, bool kc, int rows, int kdim) {
+  return (reinterpret_cast<uintptr_t>(p) & 15) == 0 && ld % 4 == 0 && (kc ? kdim % 4 == 0 : rows % 4 == 0);
+}
+
+}  // namespace gemm
+}  // namespace dfm

@@ -17,73 +17,10 @@
 // per-lane fragment reads are conflict-free), double buffered.  Small outputs with a long
 // reduction (dW: reduce over the batch) are split over workgroup rows into slabs that are added
 // in a fixed order.
-#include "common.h"
+#include "gemm_core.h"
 
 using namespace dfm;
-
-namespace {
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int BM = 64, BN = 64, BK = 32;
-constexpr int LDS_STRIDE = BK + 1;               // padded row: bank = (row + k) % 32
-constexpr int kThreads = 512;                    // 8 waves: 4 output tiles x 2 k-halves
-
-// Stage a (64 rows x 32 k) slice of an operand into LDS as [row][k] (stride 33).
-//   KC:      global element (r, k) at base[r*ld + k]  -> float4 along k
-//   strided: global element (r, k) at base[k*ld + r]  -> float4 along r
-// FAST (chosen on the host): every 16-byte piece is either entirely inside the operand or
-// entirely outside (leading dimension and base 16-byte aligned, the vectorised extent a
-// multiple of 4), so the load is branch-free: clamp the address, load, select zero.  Otherwise
-// the guarded element-wise path runs (ragged shapes; correctness only).
-template <bool KC, bool FAST>
-__device__ __forceinline__ void load_slice(const float* __restrict__ base, int64_t ld, int r0, int rows, int k0,
-                                           int kend, float4 (&v)[1], bool (&okv)[1]) {
-  const int tid = threadIdx.x;
-#pragma unroll
-  for (int i = 0; i < 1; ++i) {
-    const int p = tid + i * kThreads;             // 512 float4 pieces per slice (one per thread)
-    int r, k;
-    if (KC) { r = r0 + (p >> 3); k = k0 + (p & 7) * 4; }        // 8 pieces per row, along k
-    else    { k = k0 + (p >> 4); r = r0 + (p & 15) * 4; }       // 16 pieces per k, along r
-    const int64_t off = KC ? static_cast<int64_t>(r) * ld + k : static_cast<int64_t>(k) * ld + r;
-    if (FAST) {
-      // the zero-select is applied at the LDS store: consuming the value here would make the
-      // compiler wait for this load before the MFMAs of the current slice
-      okv[i] = r < rows && k < kend;
-      v[i] = ld4(base + (okv[i] ? off : 0));
-    } else {
-      float e[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const bool ok = KC ? (r < rows && k + j < kend) : (k < kend && r + j < rows);
-        e[j] = ok ? base[off + (KC ? j : j)] : 0.f;
-      }
-      v[i] = make_float4(e[0], e[1], e[2], e[3]);
-      okv[i] = true;
-    }
-  }
-}
-
-template <bool KC>
-__device__ __forceinline__ void store_slice(float* __restrict__ lds, const float4 (&vin)[1], const bool (&okv)[1]) {
-  const int tid = threadIdx.x;
-#pragma unroll
-  for (int i = 0; i < 1; ++i) {
-    const int p = tid + i * kThreads;
-    float4 v[1];
-    v[i] = okv[i] ? vin[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-    if (KC) {
-      const int row = p >> 3, kq = (p & 7) * 4;
-      float* d = lds + row * LDS_STRIDE + kq;
-      d[0] = v[i].x; d[1] = v[i].y; d[2] = v[i].z; d[3] = v[i].w;
-    } else {
-      const int kk = p >> 4, rq = (p & 15) * 4;
-      float* d = lds + rq * LDS_STRIDE + kk;
-      d[0] = v[i].x; d[LDS_STRIDE] = v[i].y; d[2 * LDS_STRIDE] = v[i].z; d[3 * LDS_STRIDE] = v[i].w;
-    }
-  }
-}
-}  // namespace
+using namespace dfm::gemm;
 
 // grid (tiles_n, tiles_m, splits)
 template <bool A_KC, bool B_KC, bool A_FAST, bool B_FAST>
@@ -91,67 +28,21 @@ __global__ __launch_bounds__(kThreads) void gemm_f32_kernel(
     const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb, float* __restrict__ C,
     int64_t ldc, int M, int N, int K, const float* __restrict__ bias, int accumulate, int k_per_split,
     float* __restrict__ slabs) {
-  __shared__ float lds_a[2][BM * LDS_STRIDE];
-  __shared__ float lds_b[2][BN * LDS_STRIDE];
-  const int lane = lane_id(), wave = wave_id_uniform();
+  __shared__ Smem sm;
+  const TilePos pos;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-  // waves 0-3 and 4-7 own the same four 32x32 tiles but opposite halves of every 32-deep k slice:
-  // each SIMD then holds two independent MFMA chains (one per wave) that hide each other's LDS
-  // latency; the two partial tiles are added through LDS at the end (fixed order: half 0 + half 1)
-  const int tile = wave & 3, khalf = wave >> 2;
-  const int wm = (tile >> 1) * 32, wn = (tile & 1) * 32;
   const int kb = blockIdx.z * k_per_split;
   const int ke = kb + k_per_split < K ? kb + k_per_split : K;
   f32x16 acc = {};
-  float4 va[1], vb[1];
-  bool oka[1], okb[1];
-  load_slice<A_KC, A_FAST>(A, lda, m0, M, kb, ke, va, oka);
-  load_slice<B_KC, B_FAST>(B, ldb, n0, N, kb, ke, vb, okb);
-  store_slice<A_KC>(lds_a[0], va, oka);
-  store_slice<B_KC>(lds_b[0], vb, okb);
-  if (kb + BK < ke) {
-    load_slice<A_KC, A_FAST>(A, lda, m0, M, kb + BK, ke, va, oka);
-    load_slice<B_KC, B_FAST>(B, ldb, n0, N, kb + BK, ke, vb, okb);
-  }
-  __syncthreads();
-  const int r = lane & 31, hf = lane >> 5;
-  int buf = 0;
-  for (int k0 = kb; k0 < ke; k0 += BK, buf ^= 1) {
-    // slice k0+BK (already in registers) -> the other LDS buffer; then fetch slice k0+2*BK
-    if (k0 + BK < ke) {
-      store_slice<A_KC>(lds_a[buf ^ 1], va, oka);
-      store_slice<B_KC>(lds_b[buf ^ 1], vb, okb);
-    }
-    if (k0 + 2 * BK < ke) {
-      load_slice<A_KC, A_FAST>(A, lda, m0, M, k0 + 2 * BK, ke, va, oka);
-      load_slice<B_KC, B_FAST>(B, ldb, n0, N, k0 + 2 * BK, ke, vb, okb);
-    }
-    const float* pa = lds_a[buf] + (wm + r) * LDS_STRIDE + hf + khalf * (BK / 2);
-    const float* pb = lds_b[buf] + (wn + r) * LDS_STRIDE + hf + khalf * (BK / 2);
-#pragma unroll
-    for (int kk = 0; kk < BK / 2; kk += 2)
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[kk], pb[kk], acc, 0, 0, 0);
-    __syncthreads();
-  }
-  // combine the two k-halves: waves 4-7 park their tile in LDS (the staging buffers are free after
-  // the loop's last barrier), waves 0-3 add it and write the result
-  float* park = lds_a[0];                      // 4 tiles x 16 regs x 64 lanes = 16 KiB <= sizeof(lds_a)
-  if (khalf == 1) {
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg) park[(tile * 16 + reg) * 64 + lane] = acc[reg];
-  }
-  __syncthreads();
-  if (khalf == 1) return;
-#pragma unroll
-  for (int reg = 0; reg < 16; ++reg) acc[reg] += park[(tile * 16 + reg) * 64 + lane];
-  // accumulator: col n = lane & 31, row m = (reg&3) + 8*(reg>>2) + 4*hf
-  const int n = n0 + wn + r;
+  mainloop<A_KC, B_KC, A_FAST, B_FAST>(A, lda, B, ldb, M, N, m0, n0, kb, ke, sm, pos, acc);
+  if (pos.khalf == 1) return;
+  const int n = n0 + pos.col();
   if (n >= N) return;
   if (slabs) {
     float* sl = slabs + static_cast<int64_t>(blockIdx.z) * M * N;
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
-      const int m = m0 + wm + (reg & 3) + 8 * (reg >> 2) + 4 * hf;
+      const int m = m0 + pos.row(reg);
       if (m < M) sl[static_cast<int64_t>(m) * N + n] = acc[reg];
     }
     return;
@@ -159,7 +50,7 @@ __global__ __launch_bounds__(kThreads) void gemm_f32_kernel(
   const float bv = bias ? bias[n] : 0.f;
 #pragma unroll
   for (int reg = 0; reg < 16; ++reg) {
-    const int m = m0 + wm + (reg & 3) + 8 * (reg >> 2) + 4 * hf;
+    const int m = m0 + pos.row(reg);
     if (m < M) {
       float* dst = C + static_cast<int64_t>(m) * ldc + n;
       const float v = acc[reg] + bv;
@@ -218,10 +109,8 @@ extern "C" int dfm_gemm_f32(const float* d_a, int64_t lda, int a_k_contiguous, c
   const dim3 grid((n + BN - 1) / BN, (m + BM - 1) / BM, splits), block(kThreads);
   hipStream_t st = as_stream(stream);
   // branch-free tile loads need all-or-nothing 16-byte pieces (see load_slice)
-  auto fast = [](const float* p, int64_t ld, bool kc, int rows, int kdim) {
-    return (reinterpret_cast<uintptr_t>(p) & 15) == 0 && ld % 4 == 0 && (kc ? kdim % 4 == 0 : rows % 4 == 0);
-  };
-  const bool af = fast(d_a, lda, a_k_contiguous != 0, m, k), bf = fast(d_b, ldb, b_k_contiguous != 0, n, k);
+  const bool af = operand_fast(d_a, lda, a_k_contiguous != 0, m, k);
+  const bool bf = operand_fast(d_b, ldb, b_k_contiguous != 0, n, k);
 #define DFM_GEMM_LAUNCH(AK, BK_, AF, BF)                                                                    \
   hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_, AF, BF>), grid, block, 0, st, d_a, lda, d_b, ldb, d_c, ldc, m, \
                      n, k, d_bias, accumulate, k_per_split, slabs)

@@ -262,13 +262,13 @@ class FeatureEmbedding(nn.Module):
     # ------------------------------------------------------------------ kernels
     def forward_into(self, inputs: List[torch.Tensor], B: int, fo: torch.Tensor, fe: torch.Tensor,
                      flat: Optional[torch.Tensor] = None, fm_out: Optional[torch.Tensor] = None,
-                     ws: Optional[torch.Tensor] = None) -> None:
+                     ws: Optional[torch.Tensor] = None, fm_sum: Optional[torch.Tensor] = None) -> None:
         """Enqueue the gather into caller-owned buffers (no allocation: graph/bench path)."""
         plan = self._ensure_plan(inputs[0].device)
         if B > 0:
             _lib.check(_lib.load().dfm_embedding_forward(
                 plan, self._ptr_array(inputs), B, fo.data_ptr(), fe.data_ptr(), _lib.ptr(flat),
-                _lib.ptr(fm_out), _lib.ptr(ws), self._err.data_ptr(), _lib.stream_handle()))
+                _lib.ptr(fm_out), _lib.ptr(fm_sum), _lib.ptr(ws), self._err.data_ptr(), _lib.stream_handle()))
 
     def _launch_forward(self, inputs: List[torch.Tensor], B: int, want_fm: bool = False):
         dev = inputs[0].device

@@ -98,10 +98,11 @@ size_t dfm_embedding_workspace_bytes(const dfm_embedding_plan* plan, int64_t bat
  * For a uniform plan d_flat_emb may be NULL or equal to d_field_emb (aliased).
  * d_fm_out (B,1), optional (uniform plans only): the FMInteraction value
  * 0.5*sum_d[(sum_f e)^2 - sum_f e^2] (fm.py:18-23) computed from the rows while they
- * are in registers. */
+ * are in registers; d_fm_sum (B, fm_dim), optional: S = sum_f e, which the FM backward
+ * g*(S - e) needs (dfm_linear_backward's dfm_fm_bwd epilogue). */
 int dfm_embedding_forward(const dfm_embedding_plan* plan, const void* const* inputs, int64_t batch,
                           float* d_first_order, float* d_field_emb, float* d_flat_emb,
-                          float* d_fm_out, void* d_workspace, int32_t* d_error_flag,
+                          float* d_fm_out, float* d_fm_sum, void* d_workspace, int32_t* d_error_flag,
                           dfm_stream_t stream);
 
 /* Autograd of the forward w.r.t. every parameter as DENSE gradients — the reference
@@ -304,6 +305,79 @@ int dfm_bn_relu_dropout_backward(const float* d_g_out, const float* d_z, const f
 size_t dfm_bce_workspace_bytes(int64_t n);
 int dfm_bce_with_logits(const float* d_logits, const float* d_labels, int64_t n, float* d_loss,
                         float* d_g_logits, void* d_workspace, dfm_stream_t stream);
+
+/* ---------------------------------------------------------------------------------
+ * Fused DNN tower + head of the training step (reference dnn.py:45-55 [Linear -> BatchNorm1d ->
+ * ReLU -> Dropout] * n; deepfm.py:30-42 first_order + fm + output_linear(dnn); trainer.py:59,221
+ * BCEWithLogitsLoss).  Few launches instead of many (csrc/tower.hip):
+ *   forward, per layer : dfm_linear_bn_forward (GEMM + batch statistics), dfm_bn_relu_dropout_apply
+ *   head               : dfm_head_bce (logits, loss, d logits, head gradients, last BN's mask)
+ *   backward, per layer: dfm_bn_backward_apply, dfm_linear_backward (dW and dx in one launch; the
+ *                        dx epilogue is the lower layer's BatchNorm mask or the FM backward)
+ * Workspaces must be zero-filled once after allocation; the kernels leave their counters at zero.
+ * All reductions have a fixed order (no floating-point atomics).
+ * ------------------------------------------------------------------------------- */
+
+/* BatchNorm -> ReLU -> Dropout backward, first half: dy = g * [y > 0] * dropout mask/(1-p) with
+ * y = gamma*(z-mean)*rstd + beta, its column means, and the affine gradients. */
+typedef struct dfm_bn_bwd {
+  const float* z;          /* (batch, features) pre-activations saved by the forward */
+  const float* mean_rstd;  /* (2, features) batch mean, 1/sqrt(var+eps) */
+  const float* gamma;      /* (features) BatchNorm weight */
+  const float* beta;       /* (features) BatchNorm bias */
+  float* dy;               /* out (batch, features) */
+  float* means;            /* out (2, features): mean(dy), mean(dy * xhat) */
+  float* g_gamma;          /* (features), ADDED: sum dy * xhat */
+  float* g_beta;           /* (features), ADDED: sum dy */
+  const int64_t* seed;     /* device dropout seed (NULL when p_drop == 0) */
+  void* workspace;         /* dfm_bn_bwd_workspace_bytes(batch, features) */
+  float p_drop;
+  int32_t salt;            /* layer index, as passed to dfm_bn_relu_dropout_apply */
+} dfm_bn_bwd;
+
+/* FMInteraction backward folded into the first Linear's d input: d e = d flat + g_fm * (S - e). */
+typedef struct dfm_fm_bwd {
+  const float* g_fm;       /* (batch) d loss / d fm value */
+  const float* fm_sum;     /* (batch, dim) S = sum_f e (dfm_embedding_forward's d_fm_sum) */
+  const float* e;          /* (batch, fields * dim) field embeddings */
+  int32_t dim;
+} dfm_fm_bwd;
+
+size_t dfm_linear_bn_workspace_bytes(int64_t batch, int features);
+/* z (batch, out) = x W^T + b; d_mean_rstd (2, out) = batch mean and 1/sqrt(biased var + eps);
+ * running_mean / running_var / num_batches_tracked updated like nn.BatchNorm1d when non-NULL. */
+int dfm_linear_bn_forward(const float* d_x, int64_t ldx, const float* d_w, const float* d_bias,
+                          int64_t batch, int out_features, int in_features, float* d_z,
+                          float* d_mean_rstd, float* d_running_mean, float* d_running_var,
+                          int64_t* d_num_batches, float momentum, float eps, void* d_workspace,
+                          dfm_stream_t stream);
+/* out = dropout_p(relu(gamma * (z - mean) * rstd + beta)); features % 4 == 0. */
+int dfm_bn_relu_dropout_apply(const float* d_z, int64_t batch, int features, const float* d_mean_rstd,
+                              const float* d_gamma, const float* d_beta, float p_drop,
+                              const int64_t* d_seed, int salt, float* d_out, dfm_stream_t stream);
+size_t dfm_bn_bwd_workspace_bytes(int64_t batch, int features);
+/* dz = gamma * rstd * (dy - mean(dy) - xhat * mean(dy * xhat)); d_dz may alias d_dy. */
+int dfm_bn_backward_apply(const float* d_dy, const float* d_z, const float* d_mean_rstd,
+                          const float* d_gamma, const float* d_means, int64_t batch, int features,
+                          float* d_dz, dfm_stream_t stream);
+size_t dfm_head_bce_workspace_bytes(int64_t batch, int features);
+/* logits = (first_order + fm) + (a w^T + b)   (NULL first_order / fm / b count as 0);
+ * *d_loss = mean BCE-with-logits; d_g_logits = (sigmoid - y) / batch; d_g_w (features) and d_g_b (1)
+ * are ADDED; the gradient w.r.t. a goes through `bn` (the BatchNorm block that produced a) when
+ * given, else it is written to d_g_a (batch, features).  features % 32 == 0, <= 256. */
+int dfm_head_bce(const float* d_a, int64_t batch, int features, const float* d_w, const float* d_b,
+                 const float* d_first_order, const float* d_fm, const float* d_labels, float* d_logits,
+                 float* d_loss, float* d_g_logits, float* d_g_w, float* d_g_b, float* d_g_a,
+                 const dfm_bn_bwd* bn, void* d_workspace, dfm_stream_t stream);
+size_t dfm_linear_backward_workspace_bytes(int64_t batch, int out_features, int in_features);
+/* Backward of z = x W^T + b given dz (batch, out): d_g_w (out, in) += dz^T x, and the gradient
+ * w.r.t. x (batch, in) either stored to d_g_x (plus the FM backward when `fm` is given), or pushed
+ * through the BatchNorm block that produced x (`bn_below`; d_g_x unused).  The bias gradient is
+ * not computed: in front of a training-mode BatchNorm it is identically zero. */
+int dfm_linear_backward(const float* d_dz, int64_t batch, int out_features, const float* d_x,
+                        int in_features, const float* d_w, float* d_g_w, float* d_g_x,
+                        const dfm_bn_bwd* bn_below, const dfm_fm_bwd* fm, void* d_workspace,
+                        dfm_stream_t stream);
 
 /* ---------------------------------------------------------------------------------
  * Exact-fp32 GEMM on the matrix cores (v_mfma_f32_32x32x2_f32) for the DNN tower's Linear

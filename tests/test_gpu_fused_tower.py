@@ -1,0 +1,310 @@
+"""GPU: the fused DNN-tower kernels (csrc/tower.hip) against torch fp64 restatements of the
+reference modules (dnn.py:45-55 Linear/BatchNorm1d/ReLU/Dropout, deepfm.py:30-42 head,
+trainer.py:59 BCEWithLogitsLoss, fm.py:18-23 backward), and the fused DeepFM step against the
+oracle's training step and against the autograd step."""
+import copy
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ctr_oracle as O
+from tests.helpers import assert_close, npy
+from tests.test_gpu_models_step import _oracle_state, _pool, _small_deepfm
+
+pytestmark = pytest.mark.gpu
+
+
+def _ws(nbytes):
+    return torch.zeros(max((nbytes + 3) // 4, 1), dtype=torch.int32, device="cuda")
+
+
+def _bn_ctx(z, stats, gamma, beta, dy, means, g_gamma, g_beta, ws, p=0.0, seed=None, salt=0):
+    from deepfm_amd import _lib
+    c = _lib.BnBwd()
+    c.z, c.mean_rstd, c.gamma, c.beta = z.data_ptr(), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr()
+    c.dy, c.means, c.g_gamma, c.g_beta = dy.data_ptr(), means.data_ptr(), g_gamma.data_ptr(), g_beta.data_ptr()
+    c.seed = seed.data_ptr() if seed is not None else None
+    c.workspace, c.p_drop, c.salt = ws.data_ptr(), p, salt
+    return c
+
+
+@pytest.mark.parametrize("shape", [(4096, 256, 624), (4099, 40, 52), (37, 70, 12), (2, 4, 8), (700, 128, 256)])
+def test_linear_bn_forward_matches_torch(shape):
+    from deepfm_amd import _lib
+    lib = _lib.load()
+    M, N, K = shape
+    g = torch.Generator(device="cuda").manual_seed(M + N)
+    x = torch.randn(M, K, device="cuda", generator=g) * 1.5 + 0.3
+    w = torch.randn(N, K, device="cuda", generator=g) / K ** 0.5
+    b = torch.randn(N, device="cuda", generator=g) * 3.0        # far-from-zero column means
+    rm, rv = torch.zeros(N, device="cuda"), torch.ones(N, device="cuda")
+    nb = torch.zeros(1, dtype=torch.int64, device="cuda")
+    z = torch.empty(M, N, device="cuda")
+    stats = torch.empty(2, N, device="cuda")
+    ws = _ws(lib.dfm_linear_bn_workspace_bytes(M, N))
+    for _ in range(2):      # twice: the workspace counters must come back to zero
+        _lib.check(lib.dfm_linear_bn_forward(x.data_ptr(), K, w.data_ptr(), b.data_ptr(), M, N, K, z.data_ptr(),
+                                             stats.data_ptr(), rm.data_ptr(), rv.data_ptr(), nb.data_ptr(), 0.1, 1e-5,
+                                             ws.data_ptr(), _lib.stream_handle()))
+    zd = x.double() @ w.double().t() + b.double()
+    assert_close(npy(z), npy(zd), rtol=1e-5, what="z")
+    mean, var = zd.mean(0), zd.var(0, unbiased=False)
+    assert_close(npy(stats[0]), npy(mean), rtol=1e-5, what="mean")
+    assert_close(npy(stats[1]), npy((var + 1e-5).rsqrt()), rtol=2e-5, what="rstd")
+    assert int(nb) == 2
+    unb = var * M / max(M - 1, 1)
+    want_rm = 0.9 * (0.9 * 0 + 0.1 * mean) + 0.1 * mean
+    want_rv = 0.9 * (0.9 * 1 + 0.1 * unb) + 0.1 * unb
+    assert_close(npy(rm), npy(want_rm), rtol=1e-5, what="running_mean")
+    assert_close(npy(rv), npy(want_rv), rtol=2e-5, what="running_var")
+
+
+def _torch_tower_ref(x, lins, bns, head_w, head_b, fo, fm, labels, e=None, fm_from_e=False):
+    """fp64 autograd restatement: [Linear, BatchNorm1d(train), ReLU] * n -> head -> BCE."""
+    h = x
+    zs = []
+    for (w, b), (ga, be) in zip(lins, bns):
+        z = h @ w.t() + b
+        mu, var = z.mean(0), z.var(0, unbiased=False)
+        h = torch.relu(ga * (z - mu) * (var + 1e-5).rsqrt() + be)
+        zs.append(z)
+    logits = (fo + fm) + (h @ head_w.t() + head_b).view(-1)
+    loss = torch.nn.functional.binary_cross_entropy_with_logits(logits, labels)
+    return logits, loss
+
+
+@pytest.mark.parametrize("M,K", [(4096, 64), (777, 32), (33, 256)])
+def test_head_bce_matches_torch(M, K):
+    from deepfm_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator(device="cuda").manual_seed(M + K)
+    z = torch.randn(M, K, device="cuda", generator=g)
+    gamma = torch.rand(K, device="cuda", generator=g) + 0.5
+    beta = torch.randn(K, device="cuda", generator=g) * 0.3
+    w = torch.randn(1, K, device="cuda", generator=g) / K ** 0.5
+    b = torch.randn(1, device="cuda", generator=g)
+    fo, fm = torch.randn(M, device="cuda", generator=g), torch.randn(M, device="cuda", generator=g)
+    y = (torch.rand(M, device="cuda", generator=g) < 0.3).float()
+    # reference in fp64 with autograd
+    zd = z.double().requires_grad_()
+    gd, bd, wd, b_d = (t.double().requires_grad_() for t in (gamma, beta, w, b))
+    mu, var = zd.mean(0), zd.var(0, unbiased=False)
+    stats = torch.stack([mu.detach(), (var.detach() + 1e-5).rsqrt()]).float().contiguous()
+    xhat = (zd - mu.detach()) * (var.detach() + 1e-5).rsqrt()          # statistics held fixed: the kernel's half
+    yv = gd * xhat + bd
+    a = torch.relu(yv)
+    logits = (fo.double() + fm.double()) + (a @ wd.t() + b_d).view(-1)
+    loss = torch.nn.functional.binary_cross_entropy_with_logits(logits, y.double())
+    dy_ref, = torch.autograd.grad(loss, yv, retain_graph=True)
+    loss.backward()
+    # kernel
+    a32 = a.detach().float().contiguous()
+    out = {k: torch.zeros(s, device="cuda") for k, s in dict(logits=M, loss=1, dl=M, gw=K, gb=1, dy=(M, K), means=(2, K),
+                                                                gg=K, gbeta=K).items()}
+    wsb, wsh = _ws(lib.dfm_bn_bwd_workspace_bytes(M, K)), _ws(lib.dfm_head_bce_workspace_bytes(M, K))
+    ctx = _bn_ctx(z, stats, gamma, beta, out["dy"], out["means"], out["gg"], out["gbeta"], wsb)
+    for rep in range(2):
+        for k in ("gw", "gb", "gg", "gbeta"):
+            out[k].zero_()
+        _lib.check(lib.dfm_head_bce(a32.data_ptr(), M, K, w.data_ptr(), b.data_ptr(), fo.data_ptr(), fm.data_ptr(),
+                                    y.data_ptr(), out["logits"].data_ptr(), out["loss"].data_ptr(), out["dl"].data_ptr(),
+                                    out["gw"].data_ptr(), out["gb"].data_ptr(), None, C.byref(ctx), wsh.data_ptr(),
+                                    _lib.stream_handle()))
+    assert_close(npy(out["logits"]), npy(logits), rtol=1e-5, what="logits")
+    assert abs(float(out["loss"]) - float(loss)) < 1e-6
+    dl_ref = (torch.sigmoid(logits) - y.double()) / M
+    assert_close(npy(out["dl"]), npy(dl_ref), rtol=1e-5, what="d logits")
+    assert_close(npy(out["gw"]), npy(wd.grad.view(-1)), rtol=1e-4, what="d head weight")
+    assert_close(npy(out["gb"]), npy(b_d.grad), rtol=1e-4, what="d head bias")
+    assert_close(npy(out["dy"]), npy(dy_ref), rtol=1e-5, what="dy")
+    assert_close(npy(out["means"][0]), npy(dy_ref.mean(0)), rtol=1e-4, what="mean dy")
+    assert_close(npy(out["means"][1]), npy((dy_ref * xhat.detach()).mean(0)), rtol=1e-4, what="mean dy xhat")
+    assert_close(npy(out["gbeta"]), npy(bd.grad), rtol=1e-4, what="d beta")
+    assert_close(npy(out["gg"]), npy(gd.grad), rtol=1e-4, what="d gamma")
+    # without a BatchNorm context: plain d a
+    ga = torch.zeros(M, K, device="cuda")
+    out["gw"].zero_(); out["gb"].zero_()
+    _lib.check(lib.dfm_head_bce(a32.data_ptr(), M, K, w.data_ptr(), b.data_ptr(), None, None, y.data_ptr(),
+                                out["logits"].data_ptr(), out["loss"].data_ptr(), out["dl"].data_ptr(),
+                                out["gw"].data_ptr(), out["gb"].data_ptr(), ga.data_ptr(), None, wsh.data_ptr(),
+                                _lib.stream_handle()))
+    a2 = a.detach().clone().requires_grad_()
+    l2 = torch.nn.functional.binary_cross_entropy_with_logits((a2 @ wd.detach().t() + b_d.detach()).view(-1), y.double())
+    l2.backward()
+    assert abs(float(out["loss"]) - float(l2)) < 1e-6
+    assert_close(npy(ga), npy(a2.grad), rtol=1e-5, what="d a")
+
+
+@pytest.mark.parametrize("shape", [(4096, 128, 256), (4096, 256, 624), (1000, 36, 44), (65, 8, 12), (50, 6, 10)])
+@pytest.mark.parametrize("epi", ["plain", "bn", "fm"])
+def test_linear_backward_matches_torch(shape, epi):
+    from deepfm_amd import _lib
+    lib = _lib.load()
+    M, N, K = shape
+    if epi == "fm" and K % 4:
+        pytest.skip("fm epilogue needs K = fields * dim")
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    dz = torch.randn(M, N, device="cuda", generator=g)
+    x = torch.randn(M, K, device="cuda", generator=g)
+    w = torch.randn(N, K, device="cuda", generator=g) / K ** 0.5
+    gw = torch.ones(N, K, device="cuda")
+    ws = _ws(lib.dfm_linear_backward_workspace_bytes(M, N, K))
+    gx_ref = dz.double() @ w.double()
+    gw_ref = dz.double().t() @ x.double() + 1.0
+    gx = torch.zeros(M, K, device="cuda")
+    if epi == "plain":
+        _lib.check(lib.dfm_linear_backward(dz.data_ptr(), M, N, x.data_ptr(), K, w.data_ptr(), gw.data_ptr(), gx.data_ptr(),
+                                           None, None, ws.data_ptr(), _lib.stream_handle()))
+        assert_close(npy(gx), npy(gx_ref), rtol=1e-5, atol_scale=2e-6, what="dx")
+    elif epi == "fm":
+        D = 4
+        gfm = torch.randn(M, device="cuda", generator=g)
+        S = torch.randn(M, D, device="cuda", generator=g)
+        fmb = _lib.FmBwd()
+        fmb.g_fm, fmb.fm_sum, fmb.e, fmb.dim = gfm.data_ptr(), S.data_ptr(), x.data_ptr(), D
+        _lib.check(lib.dfm_linear_backward(dz.data_ptr(), M, N, x.data_ptr(), K, w.data_ptr(), gw.data_ptr(), gx.data_ptr(),
+                                           None, C.byref(fmb), ws.data_ptr(), _lib.stream_handle()))
+        want = gx_ref + gfm.double()[:, None] * (S.double().repeat(1, K // D) - x.double())
+        assert_close(npy(gx), npy(want), rtol=1e-5, atol_scale=2e-6, what="dx + fm backward")
+    else:
+        z = torch.randn(M, K, device="cuda", generator=g)
+        gamma = torch.rand(K, device="cuda", generator=g) + 0.5
+        beta = torch.randn(K, device="cuda", generator=g) * 0.3
+        mu, var = z.double().mean(0), z.double().var(0, unbiased=False)
+        stats = torch.stack([mu, (var + 1e-5).rsqrt()]).float().contiguous()
+        xhat = (z.double() - mu) * (var + 1e-5).rsqrt()
+        mask = (gamma.double() * xhat + beta.double()) > 0
+        dy_ref = gx_ref * mask
+        dy, means = torch.zeros(M, K, device="cuda"), torch.zeros(2, K, device="cuda")
+        gg, gb = torch.ones(K, device="cuda"), torch.ones(K, device="cuda")
+        wsb = _ws(lib.dfm_bn_bwd_workspace_bytes(M, K))
+        ctx = _bn_ctx(z, stats, gamma, beta, dy, means, gg, gb, wsb)
+        _lib.check(lib.dfm_linear_backward(dz.data_ptr(), M, N, x.data_ptr(), K, w.data_ptr(), gw.data_ptr(), None,
+                                           C.byref(ctx), None, ws.data_ptr(), _lib.stream_handle()))
+        # elements whose y sits within rounding of the ReLU kink may fall on either side
+        near = (gamma.double() * xhat + beta.double()).abs() < 1e-5
+        got = npy(dy).copy()
+        got[npy(near)] = npy(dy_ref)[npy(near)]
+        assert_close(got, npy(dy_ref), rtol=1e-5, atol_scale=2e-6, what="dy")
+        if not bool(near.any()):
+            assert_close(npy(means[0]), npy(dy_ref.mean(0)), rtol=1e-4, what="mean dy")
+            assert_close(npy(means[1]), npy((dy_ref * xhat).mean(0)), rtol=1e-4, what="mean dy xhat")
+            assert_close(npy(gb), npy(dy_ref.sum(0) + 1), rtol=1e-4, what="d beta")
+            assert_close(npy(gg), npy((dy_ref * xhat).sum(0) + 1), rtol=1e-4, what="d gamma")
+        # second half of the BatchNorm backward
+        dzl = torch.empty(M, K, device="cuda")
+        if K % 4 == 0:
+            _lib.check(lib.dfm_bn_backward_apply(dy.data_ptr(), z.data_ptr(), stats.data_ptr(), gamma.data_ptr(),
+                                                 means.data_ptr(), M, K, dzl.data_ptr(), _lib.stream_handle()))
+            dyd = dy.double()
+            want = gamma.double() * stats[1].double() * (dyd - dyd.mean(0) - xhat * (dyd * xhat).mean(0))
+            assert_close(npy(dzl), npy(want), rtol=1e-4, what="dz")
+    assert_close(npy(gw), npy(gw_ref), rtol=1e-5, atol_scale=2e-6, what="dW (accumulated)")
+
+
+def test_apply_and_mask_share_the_dropout_pattern():
+    """dfm_bn_relu_dropout_apply and the backward mask (dfm_head_bce / dfm_linear_backward) must
+    rebuild the same keep pattern from (seed, salt, element index)."""
+    from deepfm_amd import _lib
+    lib = _lib.load()
+    M, K, p = 2048, 64, 0.3
+    g = torch.Generator(device="cuda").manual_seed(5)
+    z = torch.randn(M, K, device="cuda", generator=g)
+    gamma, beta = torch.ones(K, device="cuda"), torch.zeros(K, device="cuda")
+    stats = torch.stack([z.mean(0), (z.var(0, unbiased=False) + 1e-5).rsqrt()]).contiguous()
+    seed = torch.tensor([1234567], dtype=torch.int64, device="cuda")
+    a = torch.empty(M, K, device="cuda")
+    _lib.check(lib.dfm_bn_relu_dropout_apply(z.data_ptr(), M, K, stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(), p,
+                                             seed.data_ptr(), 3, a.data_ptr(), _lib.stream_handle()))
+    xhat = (z - stats[0]) * stats[1]
+    relu_on = xhat > 0
+    kept = (a != 0)
+    frac = float(kept[relu_on].float().mean())
+    assert abs(frac - (1 - p)) < 0.02
+    assert_close(npy(a[kept]), npy(xhat[kept] / (1 - p)), rtol=1e-5, what="kept values scaled by 1/(1-p)")
+    w = torch.ones(1, K, device="cuda")
+    y = torch.zeros(M, device="cuda")
+    outs = [torch.zeros(n, device="cuda") for n in (M, 1, M, K, 1)]
+    dy, means, gg, gb = torch.zeros(M, K, device="cuda"), torch.zeros(2, K, device="cuda"), torch.zeros(K, device="cuda"), torch.zeros(K, device="cuda")
+    wsb, wsh = _ws(lib.dfm_bn_bwd_workspace_bytes(M, K)), _ws(lib.dfm_head_bce_workspace_bytes(M, K))
+    ctx = _bn_ctx(z, stats, gamma, beta, dy, means, gg, gb, wsb, p=p, seed=seed, salt=3)
+    _lib.check(lib.dfm_head_bce(a.data_ptr(), M, K, w.data_ptr(), None, None, None, y.data_ptr(), outs[0].data_ptr(),
+                                outs[1].data_ptr(), outs[2].data_ptr(), outs[3].data_ptr(), None, None, C.byref(ctx),
+                                wsh.data_ptr(), _lib.stream_handle()))
+    torch.cuda.synchronize()
+    assert torch.equal(dy != 0, kept)        # d logits > 0 everywhere (labels 0), so dy != 0 exactly where kept
+
+
+def _fused_pair(B, seed=0):
+    from deepfm_amd.training.fused_step import FusedDeepFMStep
+    from deepfm_amd.training.rowsparse import RowSparseAdam
+    fields, cfg, model = _small_deepfm(seed=seed)
+    hp = dict(lr=1e-3, l2=1e-5, max_grad_norm=1.0)
+    opt = RowSparseAdam(model, lr=hp["lr"], l2=hp["l2"], max_grad_norm=hp["max_grad_norm"])
+    return fields, cfg, model, hp, opt, FusedDeepFMStep
+
+
+@pytest.mark.parametrize("B", [512, 6000])
+def test_fused_deepfm_steps_vs_oracle(B):
+    fields, cfg, model, hp, opt, Step = _fused_pair(B)
+    params, state = _oracle_state(model)
+    step = Step(model, opt, B, use_graph=False)
+    rng = np.random.default_rng(3)
+    ids, dense, labels = _pool(fields, 3, B, rng)
+    ocfg = dict(fm_dim=16, hidden_units=cfg.dnn.hidden_units)
+    for i in range(3):
+        step.load_batch(torch.from_numpy(ids[i]).cuda(), torch.from_numpy(dense[i]).cuda(), torch.from_numpy(labels[i]).cuda())
+        step.run()
+        batch = {f["name"]: ids[i, j] for j, f in enumerate(fields[:26])}
+        batch.update({f["name"]: dense[i, j] for j, f in enumerate(fields[26:])})
+        oloss = O.deepfm_train_step_rowsparse(fields, params, state, batch, labels[i], ocfg, hp, i + 1, exact_order=(B <= 512))
+        assert abs(float(step.loss) - float(oloss)) < 2e-5 + 1e-4 * abs(float(oloss)), (i, float(step.loss), float(oloss))
+    got = {k: npy(v) for k, v in model.state_dict().items()}
+    for k, want in params.items():
+        if "running_" in k:
+            continue
+        if k.startswith("dnn.mlp.") and k.endswith(".bias") and int(k.split(".")[2]) % 4 == 0:
+            continue        # zero-gradient parameter (Linear bias in front of BatchNorm)
+        assert_close(got[k], want, rtol=1e-4, atol_scale=0.0, floor=1e-4, what=k)
+
+
+def test_fused_step_graph_replay_is_bitwise_equal_to_eager():
+    from tools_shared import criteo_fields
+    B = 1024
+    results = []
+    rng = np.random.default_rng(9)
+    fields = criteo_fields(300, 16)
+    ids, dense, labels = _pool(fields, 4, B, rng)
+    for use_graph in (False, True, True):
+        _, _, model, hp, opt, Step = _fused_pair(B, seed=4)
+        step = Step(model, opt, B, use_graph=use_graph)
+        start = copy.deepcopy(model.state_dict())
+        step.load_batch(torch.from_numpy(ids[0]).cuda(), torch.from_numpy(dense[0]).cuda(), torch.from_numpy(labels[0]).cuda())
+        step.capture()
+        model.load_state_dict(start)
+        for t in opt.exp_avg + opt.exp_avg_sq:
+            t.zero_()
+        opt.step_count.zero_(); opt.flat_m.zero_(); opt.flat_v.zero_()
+        for i in range(4):
+            step.load_batch(torch.from_numpy(ids[i]).cuda(), torch.from_numpy(dense[i]).cuda(), torch.from_numpy(labels[i]).cuda())
+            step.run()
+        torch.cuda.synchronize()
+        results.append({k: npy(v).copy() for k, v in model.state_dict().items()})
+    for k in results[0]:
+        assert np.array_equal(results[1][k], results[2][k]), f"graph replay not deterministic: {k}"
+        assert np.array_equal(results[0][k], results[1][k]), f"graph != eager: {k}"
+
+
+def test_fused_step_rejects_ineligible_models():
+    from deepfm_amd.config import ExperimentConfig
+    from deepfm_amd.models import create_model
+    from deepfm_amd.training.fused_step import FusedDeepFMStep
+    from tests.helpers import schema_from_fields
+    from tools_shared import criteo_fields
+    cfg = ExperimentConfig()
+    cfg.dnn.use_batch_norm = False
+    model = create_model("deepfm", schema_from_fields(criteo_fields(50, 16)), cfg).cuda().train()
+    model.embedding.set_grad_mode("rowsparse")
+    assert not FusedDeepFMStep.eligible(model)

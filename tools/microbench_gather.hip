@@ -166,7 +166,7 @@ int main(int argc, char** argv) {
   });
   time_loop("product dfm_embedding_forward", [&](int nb) {
     inputs_for(nb, in);
-    if (dfm_embedding_forward(plan, in.data(), B, fo, fe, nullptr, fm, nullptr, err, st)) {
+    if (dfm_embedding_forward(plan, in.data(), B, fo, fe, nullptr, fm, nullptr, nullptr, err, st)) {
       fprintf(stderr, "%s\n", dfm_last_error()); exit(1);
     }
   });
