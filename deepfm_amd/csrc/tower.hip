@@ -24,8 +24,8 @@
 //                                             (lower) layer's BatchNorm mask + column sums, or the
 //                                             FM backward g_fm*(S - e) added in place (layer 1).
 //
-// Every reduction has a fixed association (no floating-point atomics): results are bitwise
-// reproducible run to run.  Counters are self-cleaning (the last workgroup resets them).
+// Every reduction has a fixed association (no floating-point read-modify-write atomics): results
+// are bitwise reproducible run to run.  Counters are self-cleaning (the last workgroup resets them).
 #include "dropout.h"
 #include "gemm_core.h"
 
@@ -36,22 +36,35 @@ namespace {
 
 constexpr int kFinLanes = kThreads / BN;   // 8 partial-lanes per column in a last-workgroup reduction
 
+// Cross-workgroup hand-off without cache-wide fences.  gfx950 has one L2 per XCD and they are not
+// coherent with each other: an agent-scope fence (__threadfence) writes back and invalidates the
+// whole L2 of the issuing XCD, and doing that once per workgroup destroys the operand reuse of
+// every GEMM tile running beside it (measured: 3-6x slower kernels).  Instead, exactly the values
+// that cross workgroups (per-tile partial sums, dW slabs, the arrival counters) are written and
+// read with agent-scope relaxed atomics — sc1 stores write through to memory, sc1 loads bypass the
+// non-coherent cache levels — and ordering comes from "all my stores have completed" (s_waitcnt)
+// + workgroup barrier + the counter increment by one thread.
+__device__ __forceinline__ void st_agent(float* p, float v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float ld_agent(const float* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // "Am I the last workgroup of my group to get here?"  Every thread of the workgroup calls it
-// after its global writes; a true return means all the group's writes are visible.
+// after its st_agent writes; a true return means all the group's st_agent writes are in memory.
 __device__ __forceinline__ bool last_block_of(int* counter, int group_size) {
   __shared__ int s_last;
-  __threadfence();
+  __builtin_amdgcn_s_waitcnt(0);     // this wave's stores have completed (vmcnt/lgkmcnt 0)
   __syncthreads();
   if (threadIdx.x == 0) {
-    const int old = atomicAdd(counter, 1);
+    const int old = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int last = old == group_size - 1;
-    if (last) *counter = 0;          // ready for the next launch
+    if (last) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
     s_last = last;
   }
   __syncthreads();
-  const bool last = s_last != 0;
-  if (last) __threadfence();
-  return last;
+  return s_last != 0;
 }
 
 // Sum of `mine` over the kFinLanes partial-lanes of column c (fixed order), returned to all of them.
@@ -110,8 +123,8 @@ __device__ __forceinline__ void bn_mask_tile(const BnBwd& bn, const f32x16& g, c
   s2 += __shfl_xor(s2, 32, kWave);
   if (pos.hf == 0 && okn && m0 + pos.wm < M) {
     const int t = (m0 + pos.wm) / 32;
-    bn.partial[(static_cast<int64_t>(t) * 2 + 0) * N + n] = s1;
-    bn.partial[(static_cast<int64_t>(t) * 2 + 1) * N + n] = s2;
+    st_agent(bn.partial + (static_cast<int64_t>(t) * 2 + 0) * N + n, s1);
+    st_agent(bn.partial + (static_cast<int64_t>(t) * 2 + 1) * N + n, s2);
   }
 }
 
@@ -124,8 +137,8 @@ __device__ __forceinline__ void bn_mask_finalize(const BnBwd& bn, int n0, int M,
   float s1 = 0.f, s2 = 0.f;
   if (ok) {
     for (int t = pl; t < T; t += kFinLanes) {
-      s1 += bn.partial[(static_cast<int64_t>(t) * 2 + 0) * N + n];
-      s2 += bn.partial[(static_cast<int64_t>(t) * 2 + 1) * N + n];
+      s1 += ld_agent(bn.partial + (static_cast<int64_t>(t) * 2 + 0) * N + n);
+      s2 += ld_agent(bn.partial + (static_cast<int64_t>(t) * 2 + 1) * N + n);
     }
   }
   s1 = column_total(s1, red, c, pl);
@@ -182,8 +195,8 @@ __global__ __launch_bounds__(kThreads) void linear_bn_fwd_kernel(
     q += __shfl_xor(q, 32, kWave);
     if (pos.hf == 0 && okn && cnt_i > 0) {
       const int t = (m0 + pos.wm) / 32;
-      partial[(static_cast<int64_t>(t) * 2 + 0) * N + n] = mean_t;
-      partial[(static_cast<int64_t>(t) * 2 + 1) * N + n] = q;
+      st_agent(partial + (static_cast<int64_t>(t) * 2 + 0) * N + n, mean_t);
+      st_agent(partial + (static_cast<int64_t>(t) * 2 + 1) * N + n, q);
     }
   }
   if (!last_block_of(counters + blockIdx.x, gridDim.y)) return;
@@ -197,7 +210,7 @@ __global__ __launch_bounds__(kThreads) void linear_bn_fwd_kernel(
   if (ok) {
     for (int t = pl; t < T; t += kFinLanes) {
       const int cnt = M - 32 * t < 32 ? M - 32 * t : 32;
-      s = fmaf(static_cast<float>(cnt), partial[(static_cast<int64_t>(t) * 2) * N + n], s);
+      s = fmaf(static_cast<float>(cnt), ld_agent(partial + (static_cast<int64_t>(t) * 2) * N + n), s);
     }
   }
   const float mu = column_total(s, red, c, pl) / static_cast<float>(M);
@@ -205,8 +218,8 @@ __global__ __launch_bounds__(kThreads) void linear_bn_fwd_kernel(
   if (ok) {
     for (int t = pl; t < T; t += kFinLanes) {
       const int cnt = M - 32 * t < 32 ? M - 32 * t : 32;
-      const float d = partial[(static_cast<int64_t>(t) * 2) * N + n] - mu;
-      q += fmaf(static_cast<float>(cnt) * d, d, partial[(static_cast<int64_t>(t) * 2 + 1) * N + n]);
+      const float d = ld_agent(partial + (static_cast<int64_t>(t) * 2) * N + n) - mu;
+      q += fmaf(static_cast<float>(cnt) * d, d, ld_agent(partial + (static_cast<int64_t>(t) * 2 + 1) * N + n));
     }
   }
   const float var = column_total(q, red, c, pl) / static_cast<float>(M);   // biased, as BN normalises
@@ -364,7 +377,7 @@ __global__ __launch_bounds__(kHeadThreads) void head_bce_kernel(
   if (lane == 0) { red[wave][3 * K] = sl; red[wave][3 * K + 1] = sd; }
   __syncthreads();
   for (int o = tid; o < P; o += kHeadThreads)
-    hpart[static_cast<int64_t>(blockIdx.x) * P + o] = (red[0][o] + red[1][o]) + (red[2][o] + red[3][o]);
+    st_agent(hpart + static_cast<int64_t>(blockIdx.x) * P + o, (red[0][o] + red[1][o]) + (red[2][o] + red[3][o]));
   if (!last_block_of(counter, gridDim.x)) return;
   const int nb = gridDim.x;
   for (int o = tid; o < P; o += kHeadThreads) {
@@ -374,11 +387,11 @@ __global__ __launch_bounds__(kHeadThreads) void head_bce_kernel(
     for (; i + 8 <= nb; i += 8) {
       float tq[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) tq[u] = hpart[static_cast<int64_t>(i + u) * P + o];
+      for (int u = 0; u < 8; ++u) tq[u] = ld_agent(hpart + static_cast<int64_t>(i + u) * P + o);
 #pragma unroll
       for (int u = 0; u < 8; ++u) s += tq[u];
     }
-    for (; i < nb; ++i) s += hpart[static_cast<int64_t>(i) * P + o];
+    for (; i < nb; ++i) s += ld_agent(hpart + static_cast<int64_t>(i) * P + o);
     if (o < K) {
       if (has_bn) { bn.means[o] = s / static_cast<float>(M); bn.g_beta[o] += s; }
     } else if (o < 2 * K) {
@@ -426,7 +439,7 @@ __global__ __launch_bounds__(kThreads) void linear_bwd_kernel(
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
         const int m = m0 + pos.row(reg);
-        if (m < N) sl[static_cast<int64_t>(m) * K + n] = acc[reg];
+        if (m < N) st_agent(sl + static_cast<int64_t>(m) * K + n, acc[reg]);
       }
     }
     if (!last_block_of(dw_counters + tile, splits)) return;
@@ -440,11 +453,11 @@ __global__ __launch_bounds__(kThreads) void linear_bwd_kernel(
         for (; q + 4 <= splits; q += 4) {
           float tq[4];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) tq[u] = slabs[static_cast<int64_t>(q + u) * N * K + off];
+          for (int u = 0; u < 4; ++u) tq[u] = ld_agent(slabs + static_cast<int64_t>(q + u) * N * K + off);
 #pragma unroll
           for (int u = 0; u < 4; ++u) s += tq[u];
         }
-        for (; q < splits; ++q) s += slabs[static_cast<int64_t>(q) * N * K + off];
+        for (; q < splits; ++q) s += ld_agent(slabs + static_cast<int64_t>(q) * N * K + off);
         g_w[off] += s;
       }
     }
