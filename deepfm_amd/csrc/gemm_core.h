@@ -92,40 +92,76 @@ __device__ __forceinline__ void store_slice(float* __restrict__ lds, const float
 
 // The whole k loop of one output tile.  On return `acc` is complete in the waves with
 // pos.khalf == 0; every wave has passed the same barriers and `sm` is free for the epilogue.
+//
+// The loop is latency-bound, not MFMA-bound (8 MFMAs = ~0.2 us per slice against a ~1-2 us HBM /
+// Infinity-Cache round trip, and the small layers give a CU only one or two workgroups), so the
+// global loads run kPrefetch slices ahead in registers (one float4 per operand per thread and
+// slice), while LDS stays double-buffered: slice i is computed from LDS while slice i+1 moves
+// registers -> LDS and slice i+kPrefetch is requested from memory.
+constexpr int kPrefetch = 4;
+
+// One slice of the pipeline: slice at k = kc is in LDS buffer J & 1 and register slot J is free.
+// CHECK = false is the steady state (both the next slice and the slice kPrefetch ahead exist): no
+// branches, so the compiler counts the outstanding loads exactly (s_waitcnt vmcnt(4), not 0).
+template <bool A_KC, bool B_KC, bool A_FAST, bool B_FAST, int J, bool CHECK>
+__device__ __forceinline__ void pipe_step(const float* __restrict__ A, int64_t lda, const float* __restrict__ B,
+                                          int64_t ldb, int M, int N, int m0, int n0, int kc, int ke, Smem& sm,
+                                          const TilePos& pos, float4 (&va)[kPrefetch], float4 (&vb)[kPrefetch],
+                                          bool (&oka)[kPrefetch], bool (&okb)[kPrefetch], f32x16& acc) {
+  constexpr int buf = J & 1, nxt = (J + 1) % kPrefetch;
+  if (CHECK && kc >= ke) return;
+  if (!CHECK || kc + BK < ke) {                 // slice kc+BK: registers -> the other LDS buffer
+    store_slice<A_KC>(sm.a[buf ^ 1], va[nxt], oka[nxt]);
+    store_slice<B_KC>(sm.b[buf ^ 1], vb[nxt], okb[nxt]);
+  }
+  if (!CHECK || kc + kPrefetch * BK < ke) {     // slot J went to LDS one slice ago: refill it
+    load_slice<A_KC, A_FAST>(A, lda, m0, M, kc + kPrefetch * BK, ke, va[J], oka[J]);
+    load_slice<B_KC, B_FAST>(B, ldb, n0, N, kc + kPrefetch * BK, ke, vb[J], okb[J]);
+  }
+  const float* pa = sm.a[buf] + (pos.wm + pos.r) * LDS_STRIDE + pos.hf + pos.khalf * (BK / 2);
+  const float* pb = sm.b[buf] + (pos.wn + pos.r) * LDS_STRIDE + pos.hf + pos.khalf * (BK / 2);
+  // all 16 fragment values first, then the 8 dependent MFMAs: one LDS round trip per slice instead
+  // of one per MFMA pair (the MFMA chain on one accumulator cannot hide it)
+  float fa[BK / 4], fb[BK / 4];
+#pragma unroll
+  for (int i = 0; i < BK / 4; ++i) { fa[i] = pa[2 * i]; fb[i] = pb[2 * i]; }
+#pragma unroll
+  for (int i = 0; i < BK / 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[i], acc, 0, 0, 0);
+  __syncthreads();
+}
+
 template <bool A_KC, bool B_KC, bool A_FAST, bool B_FAST>
 __device__ __forceinline__ void mainloop(const float* __restrict__ A, int64_t lda, const float* __restrict__ B,
                                          int64_t ldb, int M, int N, int m0, int n0, int kb, int ke, Smem& sm,
                                          const TilePos& pos, f32x16& acc) {
+  static_assert(kPrefetch == 4, "the slot schedule below is written out for 4 slices in flight");
   const int lane = lane_id();
-  float4 va, vb;
-  bool oka, okb;
-  load_slice<A_KC, A_FAST>(A, lda, m0, M, kb, ke, va, oka);
-  load_slice<B_KC, B_FAST>(B, ldb, n0, N, kb, ke, vb, okb);
-  store_slice<A_KC>(sm.a[0], va, oka);
-  store_slice<B_KC>(sm.b[0], vb, okb);
-  if (kb + BK < ke) {
-    load_slice<A_KC, A_FAST>(A, lda, m0, M, kb + BK, ke, va, oka);
-    load_slice<B_KC, B_FAST>(B, ldb, n0, N, kb + BK, ke, vb, okb);
-  }
-  __syncthreads();
-  int buf = 0;
-  for (int k0 = kb; k0 < ke; k0 += BK, buf ^= 1) {
-    // slice k0+BK (already in registers) -> the other LDS buffer; then fetch slice k0+2*BK
-    if (k0 + BK < ke) {
-      store_slice<A_KC>(sm.a[buf ^ 1], va, oka);
-      store_slice<B_KC>(sm.b[buf ^ 1], vb, okb);
-    }
-    if (k0 + 2 * BK < ke) {
-      load_slice<A_KC, A_FAST>(A, lda, m0, M, k0 + 2 * BK, ke, va, oka);
-      load_slice<B_KC, B_FAST>(B, ldb, n0, N, k0 + 2 * BK, ke, vb, okb);
-    }
-    const float* pa = sm.a[buf] + (pos.wm + pos.r) * LDS_STRIDE + pos.hf + pos.khalf * (BK / 2);
-    const float* pb = sm.b[buf] + (pos.wn + pos.r) * LDS_STRIDE + pos.hf + pos.khalf * (BK / 2);
+  float4 va[kPrefetch], vb[kPrefetch];
+  bool oka[kPrefetch], okb[kPrefetch];
 #pragma unroll
-    for (int kk = 0; kk < BK / 2; kk += 2)
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[kk], pb[kk], acc, 0, 0, 0);
-    __syncthreads();
+  for (int j = 0; j < kPrefetch; ++j) {
+    oka[j] = okb[j] = false;
+    va[j] = vb[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (kb + j * BK < ke) {
+      load_slice<A_KC, A_FAST>(A, lda, m0, M, kb + j * BK, ke, va[j], oka[j]);
+      load_slice<B_KC, B_FAST>(B, ldb, n0, N, kb + j * BK, ke, vb[j], okb[j]);
+    }
   }
+  store_slice<A_KC>(sm.a[0], va[0], oka[0]);
+  store_slice<B_KC>(sm.b[0], vb[0], okb[0]);
+  __syncthreads();
+#define DFM_PIPE(J, CHECK)                                                                                      \
+  pipe_step<A_KC, B_KC, A_FAST, B_FAST, J, CHECK>(A, lda, B, ldb, M, N, m0, n0, k0 + (J) * BK, ke, sm, pos, va, \
+                                                  vb, oka, okb, acc)
+  // slice s lives in register slot s % 4 and LDS buffer s % 2
+  int k0 = kb;
+  for (; k0 + 2 * kPrefetch * BK <= ke; k0 += kPrefetch * BK) {    // all 8 slices of the window exist
+    DFM_PIPE(0, false); DFM_PIPE(1, false); DFM_PIPE(2, false); DFM_PIPE(3, false);
+  }
+  for (; k0 < ke; k0 += kPrefetch * BK) {
+    DFM_PIPE(0, true); DFM_PIPE(1, true); DFM_PIPE(2, true); DFM_PIPE(3, true);
+  }
+#undef DFM_PIPE
   // combine the two k-halves: waves 4-7 park their tile in LDS (the staging buffers are free after
   // the loop's last barrier), waves 0-3 add it (fixed order: half 0 + half 1)
   float* park = &sm.a[0][0];                   // 4 tiles x 16 regs x 64 lanes = 16 KiB <= sizeof(sm.a)
@@ -139,6 +175,17 @@ __device__ __forceinline__ void mainloop(const float* __restrict__ A, int64_t ld
     for (int reg = 0; reg < 16; ++reg) acc[reg] += park[(pos.tile * 16 + reg) * 64 + lane];
   }
   __syncthreads();
+}
+
+// Workgroups are dealt to the 8 XCDs round-robin in dispatch order, and each XCD has its own L2.
+// Tiles that share an operand slab (the n-tiles of one m-tile, the tiles of one batch split) are
+// adjacent in the LOGICAL order; this maps dispatch index -> logical index so that adjacent logical
+// tiles run on the same XCD and the shared slab is fetched into one L2 instead of eight.
+constexpr int kXcds = 8;
+__device__ __forceinline__ int xcd_logical_index(int w, int total) {
+  const int per = total / kXcds;
+  if (w >= per * kXcds) return w;            // ragged tail: identity
+  return (w % kXcds) * per + w / kXcds;
 }
 
 // Host side: branch-free tile loads need all-or-nothing 16-byte pieces (see load_slice).

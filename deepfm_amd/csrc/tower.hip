@@ -154,17 +154,19 @@ __device__ __forceinline__ void bn_mask_finalize(const BnBwd& bn, int n0, int M,
 }  // namespace
 
 // =====================================================================================
-// forward: z = x W^T + b with BatchNorm batch statistics.  grid (tiles_n, tiles_m)
+// forward: z = x W^T + b with BatchNorm batch statistics.  grid tiles_m * tiles_n (n fastest)
 // =====================================================================================
 template <bool FAST>
 __global__ __launch_bounds__(kThreads) void linear_bn_fwd_kernel(
     const float* __restrict__ x, int64_t ldx, const float* __restrict__ w, const float* __restrict__ bias,
-    float* __restrict__ z, int M, int N, int K, float* __restrict__ partial, int* __restrict__ counters,
-    float* __restrict__ mean_rstd, float* __restrict__ running_mean, float* __restrict__ running_var,
-    int64_t* __restrict__ num_batches, float momentum, float eps) {
+    float* __restrict__ z, int M, int N, int K, int tiles_n, float* __restrict__ partial,
+    int* __restrict__ counters, float* __restrict__ mean_rstd, float* __restrict__ running_mean,
+    float* __restrict__ running_var, int64_t* __restrict__ num_batches, float momentum, float eps) {
   __shared__ Smem sm;
   const TilePos pos;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int lt = xcd_logical_index(blockIdx.x, gridDim.x);
+  const int tn = lt % tiles_n, tiles_m = gridDim.x / tiles_n;
+  const int m0 = (lt / tiles_n) * BM, n0 = tn * BN;
   f32x16 acc = {};
   mainloop<true, true, FAST, FAST>(x, ldx, w, K, M, N, m0, n0, 0, K, sm, pos, acc);
   if (pos.khalf == 0) {
@@ -199,7 +201,7 @@ __global__ __launch_bounds__(kThreads) void linear_bn_fwd_kernel(
       st_agent(partial + (static_cast<int64_t>(t) * 2 + 1) * N + n, q);
     }
   }
-  if (!last_block_of(counters + blockIdx.x, gridDim.y)) return;
+  if (!last_block_of(counters + tn, tiles_m)) return;
   // ---- merge the tiles' (count, mean, M2) of this column tile: mean first, then M2 about it ----
   float* red = &sm.a[0][0];
   const int T = (M + 31) / 32;
@@ -232,7 +234,7 @@ __global__ __launch_bounds__(kThreads) void linear_bn_fwd_kernel(
       running_var[n] = (1.f - momentum) * running_var[n] + momentum * unbiased;
     }
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0 && num_batches) num_batches[0] += 1;
+  if (tn == 0 && threadIdx.x == 0 && num_batches) num_batches[0] += 1;
 }
 
 // a = dropout(relu(gamma * (z - mean) * rstd + beta)), 4 elements per thread (N % 4 == 0)
@@ -425,7 +427,7 @@ __global__ __launch_bounds__(kThreads) void linear_bwd_kernel(
   __shared__ Smem sm;
   const TilePos pos;
   f32x16 acc = {};
-  const int bid = blockIdx.x;
+  const int bid = xcd_logical_index(blockIdx.x, gridDim.x);
   if (bid < dw_tiles * splits) {
     // ---- dW (N x K) = sum over the batch: A = dz (k-strided), B = x (k-strided) ----
     const int tile = bid % dw_tiles, sp = bid / dw_tiles;
@@ -545,16 +547,17 @@ extern "C" int dfm_linear_bn_forward(const float* d_x, int64_t ldx, const float*
   const int M = static_cast<int>(batch), N = out_features, K = in_features;
   float* partial = static_cast<float*>(d_workspace);
   int* counters = reinterpret_cast<int*>(static_cast<char*>(d_workspace) + bn_partial_bytes(M, N));
-  const dim3 grid(tiles(N, BN), tiles(M, BM));
+  const int tn = tiles(N, BN);
+  const dim3 grid(static_cast<unsigned>(tn) * tiles(M, BM));
   const bool fast = operand_fast(d_x, ldx, true, M, K) && operand_fast(d_w, K, true, N, K);
   if (fast)
     hipLaunchKernelGGL(linear_bn_fwd_kernel<true>, grid, dim3(kThreads), 0, as_stream(stream), d_x, ldx, d_w, d_bias,
-                       d_z, M, N, K, partial, counters, d_mean_rstd, d_running_mean, d_running_var, d_num_batches,
-                       momentum, eps);
+                       d_z, M, N, K, tn, partial, counters, d_mean_rstd, d_running_mean, d_running_var,
+                       d_num_batches, momentum, eps);
   else
     hipLaunchKernelGGL(linear_bn_fwd_kernel<false>, grid, dim3(kThreads), 0, as_stream(stream), d_x, ldx, d_w, d_bias,
-                       d_z, M, N, K, partial, counters, d_mean_rstd, d_running_mean, d_running_var, d_num_batches,
-                       momentum, eps);
+                       d_z, M, N, K, tn, partial, counters, d_mean_rstd, d_running_mean, d_running_var,
+                       d_num_batches, momentum, eps);
   DFM_LAUNCH_CHECK();
   return DFM_OK;
 }
