@@ -49,13 +49,24 @@ class Table(C.Structure):
 class BnBwd(C.Structure):
     """struct dfm_bn_bwd"""
     _fields_ = [("z", C.c_void_p), ("mean_rstd", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p),
-                ("dy", C.c_void_p), ("means", C.c_void_p), ("g_gamma", C.c_void_p), ("g_beta", C.c_void_p),
+                ("dy", C.c_void_p), ("g_gamma", C.c_void_p), ("g_beta", C.c_void_p),
                 ("seed", C.c_void_p), ("workspace", C.c_void_p), ("p_drop", C.c_float), ("salt", C.c_int32)]
 
 
 class FmBwd(C.Structure):
     """struct dfm_fm_bwd"""
     _fields_ = [("g_fm", C.c_void_p), ("fm_sum", C.c_void_p), ("e", C.c_void_p), ("dim", C.c_int32)]
+
+
+class SlabRef(C.Structure):
+    """struct dfm_slab_ref"""
+    _fields_ = [("workspace", C.c_void_p), ("g_w", C.c_void_p), ("batch", C.c_int64), ("out_features", C.c_int32),
+                ("in_features", C.c_int32)]
+
+
+class HeadTail(C.Structure):
+    """struct dfm_head_tail"""
+    _fields_ = [("g_w", C.c_void_p), ("g_b", C.c_void_p), ("loss", C.c_void_p)]
 
 
 # name -> (restype, argtypes); must list every symbol of include/deepfm_hip.h
@@ -105,14 +116,14 @@ SIGNATURES = {
     "dfm_layernorm_forward": (_I, [_P, _P, _L, _I, _P, _P, _F, _P, _P, _P]),
     "dfm_layernorm_backward": (_I, [_P, _P, _P, _P, _L, _I, _P, _P, _P, _P, _P, _P]),
     "dfm_linear_bn_workspace_bytes": (_SZ, [_L, _I]),
-    "dfm_linear_bn_forward": (_I, [_P, _L, _P, _P, _L, _I, _I, _P, _P, _P, _P, _P, _F, _F, _P, _P]),
-    "dfm_bn_relu_dropout_apply": (_I, [_P, _L, _I, _P, _P, _P, _F, _P, _I, _P, _P]),
+    "dfm_linear_bn_forward": (_I, [_P, _L, _P, _P, _L, _I, _I, _P, _P, _P]),
+    "dfm_bn_relu_dropout_apply": (_I, [_P, _L, _I, _P, _P, _P, _P, _P, _P, _P, _F, _F, _F, _P, _I, _P, _P]),
     "dfm_bn_bwd_workspace_bytes": (_SZ, [_L, _I]),
-    "dfm_bn_backward_apply": (_I, [_P, _P, _P, _P, _P, _L, _I, _P, _P]),
-    "dfm_head_bce_workspace_bytes": (_SZ, [_L, _I]),
-    "dfm_head_bce": (_I, [_P, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(BnBwd), _P, _P]),
+    "dfm_bn_backward_apply": (_I, [C.POINTER(BnBwd), _L, _I, C.POINTER(HeadTail), _P, _P]),
+    "dfm_head_bce": (_I, [_P, _L, _I, _P, _P, _P, _P, _P, _P, _P, C.POINTER(BnBwd), _P]),
     "dfm_linear_backward_workspace_bytes": (_SZ, [_L, _I, _I]),
-    "dfm_linear_backward": (_I, [_P, _L, _I, _P, _I, _P, _P, _P, C.POINTER(BnBwd), C.POINTER(FmBwd), _P, _P]),
+    "dfm_linear_backward": (_I, [_P, _L, _I, _P, _I, _P, _P, C.POINTER(BnBwd), C.POINTER(FmBwd), _I, _P, _P]),
+    "dfm_linear_backward_finish": (_I, [C.POINTER(SlabRef), _I, _P]),
     "dfm_fm_forward": (_I, [_P, _L, _I, _I, _P, _P]),
     "dfm_fm_backward": (_I, [_P, _P, _L, _I, _I, _P, _P]),
 }

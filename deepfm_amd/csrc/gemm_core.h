@@ -8,7 +8,7 @@
 // MFMA chains per SIMD); the halves are added through LDS in a fixed order (half 0 + half 1)
 // and the result lives in the accumulators of waves 0-3.  64 x 32 slices of A and B are staged
 // through LDS (coalesced 16-byte global loads in either layout, padded rows: conflict-free
-// fragment reads), double buffered.
+// fragment reads), double buffered, and consumed from register fragments (see mainloop).
 #pragma once
 
 #include "common.h"
@@ -93,41 +93,57 @@ __device__ __forceinline__ void store_slice(float* __restrict__ lds, const float
 // The whole k loop of one output tile.  On return `acc` is complete in the waves with
 // pos.khalf == 0; every wave has passed the same barriers and `sm` is free for the epilogue.
 //
-// The loop is latency-bound, not MFMA-bound (8 MFMAs = ~0.2 us per slice against a ~1-2 us HBM /
-// Infinity-Cache round trip, and the small layers give a CU only one or two workgroups), so the
-// global loads run kPrefetch slices ahead in registers (one float4 per operand per thread and
-// slice), while LDS stays double-buffered: slice i is computed from LDS while slice i+1 moves
-// registers -> LDS and slice i+kPrefetch is requested from memory.
+// Software pipeline, three stages deep.  The fp32 MFMA chain (8 dependent v_mfma_f32_32x32x2 per
+// wave and slice, 2 waves per SIMD: 1024 cycles per slice) is the floor; everything else has to
+// hide under it, so while slice s is multiplied from REGISTER fragments,
+//   - the fragments of slice s+1 are read from LDS buffer (s+1)%2 into a second register set,
+//   - slice s+2 moves from its global-prefetch registers into LDS buffer s%2 (whose fragments were
+//     consumed one barrier ago),
+//   - slice s+6 is requested from memory into the register slot slice s+2 just left
+// (kPrefetch = 4 slots, one float4 per operand per thread and slice).  One barrier per slice.
 constexpr int kPrefetch = 4;
+constexpr int kFrag = BK / 4;        // fragment values per operand per lane per slice (this wave's k-half)
 
-// One slice of the pipeline: slice at k = kc is in LDS buffer J & 1 and register slot J is free.
-// CHECK = false is the steady state (both the next slice and the slice kPrefetch ahead exist): no
-// branches, so the compiler counts the outstanding loads exactly (s_waitcnt vmcnt(4), not 0).
+__device__ __forceinline__ void read_frags(const Smem& sm, int buf, const TilePos& pos, float (&fa)[kFrag],
+                                           float (&fb)[kFrag]) {
+  const float* pa = sm.a[buf] + (pos.wm + pos.r) * LDS_STRIDE + pos.hf + pos.khalf * (BK / 2);
+  const float* pb = sm.b[buf] + (pos.wn + pos.r) * LDS_STRIDE + pos.hf + pos.khalf * (BK / 2);
+#pragma unroll
+  for (int i = 0; i < kFrag; ++i) { fa[i] = pa[2 * i]; fb[i] = pb[2 * i]; }
+}
+
+// One slice of the pipeline (slice index s = J mod 4; kc = its k offset).  CHECK = false is the
+// steady state (slices s+1, s+2 and s+6 all exist): no branches, so the compiler counts the
+// outstanding loads exactly instead of waiting for all of them.
 template <bool A_KC, bool B_KC, bool A_FAST, bool B_FAST, int J, bool CHECK>
 __device__ __forceinline__ void pipe_step(const float* __restrict__ A, int64_t lda, const float* __restrict__ B,
                                           int64_t ldb, int M, int N, int m0, int n0, int kc, int ke, Smem& sm,
                                           const TilePos& pos, float4 (&va)[kPrefetch], float4 (&vb)[kPrefetch],
-                                          bool (&oka)[kPrefetch], bool (&okb)[kPrefetch], f32x16& acc) {
-  constexpr int buf = J & 1, nxt = (J + 1) % kPrefetch;
+                                          bool (&oka)[kPrefetch], bool (&okb)[kPrefetch], float (&fa)[kFrag],
+                                          float (&fb)[kFrag], f32x16& acc) {
+  constexpr int b1 = (J + 1) & 1, b2 = J & 1, slot = (J + 2) % kPrefetch;
   if (CHECK && kc >= ke) return;
-  if (!CHECK || kc + BK < ke) {                 // slice kc+BK: registers -> the other LDS buffer
-    store_slice<A_KC>(sm.a[buf ^ 1], va[nxt], oka[nxt]);
-    store_slice<B_KC>(sm.b[buf ^ 1], vb[nxt], okb[nxt]);
-  }
-  if (!CHECK || kc + kPrefetch * BK < ke) {     // slot J went to LDS one slice ago: refill it
-    load_slice<A_KC, A_FAST>(A, lda, m0, M, kc + kPrefetch * BK, ke, va[J], oka[J]);
-    load_slice<B_KC, B_FAST>(B, ldb, n0, N, kc + kPrefetch * BK, ke, vb[J], okb[J]);
-  }
-  const float* pa = sm.a[buf] + (pos.wm + pos.r) * LDS_STRIDE + pos.hf + pos.khalf * (BK / 2);
-  const float* pb = sm.b[buf] + (pos.wn + pos.r) * LDS_STRIDE + pos.hf + pos.khalf * (BK / 2);
-  // all 16 fragment values first, then the 8 dependent MFMAs: one LDS round trip per slice instead
-  // of one per MFMA pair (the MFMA chain on one accumulator cannot hide it)
-  float fa[BK / 4], fb[BK / 4];
+  float na[kFrag], nb[kFrag];
 #pragma unroll
-  for (int i = 0; i < BK / 4; ++i) { fa[i] = pa[2 * i]; fb[i] = pb[2 * i]; }
+  for (int i = 0; i < kFrag; ++i) na[i] = nb[i] = 0.f;
+  if (!CHECK || kc + BK < ke) read_frags(sm, b1, pos, na, nb);
+  if (!CHECK || kc + 2 * BK < ke) {
+    store_slice<A_KC>(sm.a[b2], va[slot], oka[slot]);
+    store_slice<B_KC>(sm.b[b2], vb[slot], okb[slot]);
+  }
+  if (!CHECK || kc + (kPrefetch + 2) * BK < ke) {
+    load_slice<A_KC, A_FAST>(A, lda, m0, M, kc + (kPrefetch + 2) * BK, ke, va[slot], oka[slot]);
+    load_slice<B_KC, B_FAST>(B, ldb, n0, N, kc + (kPrefetch + 2) * BK, ke, vb[slot], okb[slot]);
+  }
+  // keep the issue order [LDS reads, LDS writes, global loads] -> [MFMA chain]: left alone, the
+  // scheduler sinks each fragment read next to its MFMA and the chain stalls on LDS latency again
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-  for (int i = 0; i < BK / 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[i], acc, 0, 0, 0);
+  for (int i = 0; i < kFrag; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[i], acc, 0, 0, 0);
+  __builtin_amdgcn_sched_barrier(0);
   __syncthreads();
+#pragma unroll
+  for (int i = 0; i < kFrag; ++i) { fa[i] = na[i]; fb[i] = nb[i]; }
 }
 
 template <bool A_KC, bool B_KC, bool A_FAST, bool B_FAST>
@@ -147,15 +163,28 @@ __device__ __forceinline__ void mainloop(const float* __restrict__ A, int64_t ld
       load_slice<B_KC, B_FAST>(B, ldb, n0, N, kb + j * BK, ke, vb[j], okb[j]);
     }
   }
+  // slices 0 and 1 -> LDS buffers 0 and 1; their slots take slices 4 and 5
   store_slice<A_KC>(sm.a[0], va[0], oka[0]);
   store_slice<B_KC>(sm.b[0], vb[0], okb[0]);
+  store_slice<A_KC>(sm.a[1], va[1], oka[1]);
+  store_slice<B_KC>(sm.b[1], vb[1], okb[1]);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    if (kb + (kPrefetch + j) * BK < ke) {
+      load_slice<A_KC, A_FAST>(A, lda, m0, M, kb + (kPrefetch + j) * BK, ke, va[j], oka[j]);
+      load_slice<B_KC, B_FAST>(B, ldb, n0, N, kb + (kPrefetch + j) * BK, ke, vb[j], okb[j]);
+    }
+  }
   __syncthreads();
+  float fa[kFrag], fb[kFrag];
+  read_frags(sm, 0, pos, fa, fb);
+  __syncthreads();               // slice 0's fragments are in registers: buffer 0 may be overwritten
 #define DFM_PIPE(J, CHECK)                                                                                      \
   pipe_step<A_KC, B_KC, A_FAST, B_FAST, J, CHECK>(A, lda, B, ldb, M, N, m0, n0, k0 + (J) * BK, ke, sm, pos, va, \
-                                                  vb, oka, okb, acc)
-  // slice s lives in register slot s % 4 and LDS buffer s % 2
+                                                  vb, oka, okb, fa, fb, acc)
+  // slice s: LDS buffer s % 2, global-prefetch slot s % 4
   int k0 = kb;
-  for (; k0 + 2 * kPrefetch * BK <= ke; k0 += kPrefetch * BK) {    // all 8 slices of the window exist
+  for (; k0 + (kPrefetch + 5) * BK < ke; k0 += kPrefetch * BK) {   // slices up to s+9 exist: no checks
     DFM_PIPE(0, false); DFM_PIPE(1, false); DFM_PIPE(2, false); DFM_PIPE(3, false);
   }
   for (; k0 < ke; k0 += kPrefetch * BK) {

@@ -3,29 +3,35 @@
 // trainer.py:59,221: BCEWithLogitsLoss).
 //
 // On an MI355X a dependent kernel costs ~4.5 us whatever it does, and the tower's GEMMs are
-// 5-30 us each, so the tower is organised around FEW launches, not around FLOPs:
+// 5-30 us each, so the tower is organised around FEW launches, and around launches WITHOUT serial
+// tails (no "last workgroup finalises" inside a GEMM: the arrival atomic + two dependent passes over
+// memory cost ~10 us per kernel):
 //
 //   forward, per layer   linear_bn_fwd        z = x W^T + b on the exact-fp32 MFMA tile loop
-//                                             (gemm_core.h); the epilogue reduces per-column
-//                                             (mean, M2) over each 32-row MFMA tile, and the LAST
-//                                             workgroup of a column tile (device-scope counter)
-//                                             merges them in a fixed order (Chan) -> mean, rstd,
-//                                             running statistics.  No separate statistics pass.
-//                        bn_relu_dropout_apply a = dropout(relu(gamma*(z-mean)*rstd + beta))
-//   head                 head_bce             logit = (fo + fm) + (a.w + b); BCE loss; d logit;
-//                                             d w, d b; g = d logit * w pushed through the last
-//                                             BatchNorm's ReLU/dropout mask (dy) with its column
-//                                             sums (same last-workgroup reduction)
-//   backward, per layer  bn_bwd_apply         dz = gamma*rstd*(dy - mean(dy) - xhat*mean(dy*xhat))
+//                                             (gemm_core.h); the epilogue leaves per-column
+//                                             (mean, M2) of each 32-row MFMA tile in a workspace
+//                        bn_relu_dropout_apply a workgroup owns 64 columns x 64 rows: it first merges
+//                                             the tile statistics of its columns (Chan, fixed order,
+//                                             L2-resident) -> mean, rstd (+ running statistics from
+//                                             the row-group-0 workgroups), then
+//                                             a = dropout(relu(gamma*(z-mean)*rstd + beta))
+//   head                 head_bce             logit = (fo + fm) + (a.w + b); BCE terms; d logit;
+//                                             g = d logit * w pushed through the last BatchNorm's
+//                                             ReLU/dropout mask (dy); per-workgroup partial sums of
+//                                             dy, dy*xhat, d logit*a, loss, d logit
+//   backward, per layer  bn_bwd_apply         merges the partial sums of its columns (from head_bce or
+//                                             from the dx epilogue above it), adds d gamma / d beta
+//                                             (and the head's d w, d b, loss), then
+//                                             dz = gamma*rstd*(dy - mean(dy) - xhat*mean(dy*xhat))
 //                        linear_bwd           ONE launch for both GEMMs of a Linear backward:
 //                                             dW += dz^T x (batch split into slabs, the last
 //                                             workgroup of an output tile adds the slabs in order)
 //                                             and dx = dz W, whose epilogue is either the NEXT
-//                                             (lower) layer's BatchNorm mask + column sums, or the
-//                                             FM backward g_fm*(S - e) added in place (layer 1).
+//                                             (lower) layer's BatchNorm mask + per-tile column sums, or
+//                                             the FM backward g_fm*(S - e) added in place (layer 1).
 //
 // Every reduction has a fixed association (no floating-point read-modify-write atomics): results
-// are bitwise reproducible run to run.  Counters are self-cleaning (the last workgroup resets them).
+// are bitwise reproducible run to run.
 #include "dropout.h"
 #include "gemm_core.h"
 
@@ -34,49 +40,14 @@ using namespace dfm::gemm;
 
 namespace {
 
-constexpr int kFinLanes = kThreads / BN;   // 8 partial-lanes per column in a last-workgroup reduction
-
-// Cross-workgroup hand-off without cache-wide fences.  gfx950 has one L2 per XCD and they are not
-// coherent with each other: an agent-scope fence (__threadfence) writes back and invalidates the
-// whole L2 of the issuing XCD, and doing that once per workgroup destroys the operand reuse of
-// every GEMM tile running beside it (measured: 3-6x slower kernels).  Instead, exactly the values
-// that cross workgroups (per-tile partial sums, dW slabs, the arrival counters) are written and
-// read with agent-scope relaxed atomics — sc1 stores write through to memory, sc1 loads bypass the
-// non-coherent cache levels — and ordering comes from "all my stores have completed" (s_waitcnt)
-// + workgroup barrier + the counter increment by one thread.
-__device__ __forceinline__ void st_agent(float* p, float v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ float ld_agent(const float* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// "Am I the last workgroup of my group to get here?"  Every thread of the workgroup calls it
-// after its st_agent writes; a true return means all the group's st_agent writes are in memory.
-__device__ __forceinline__ bool last_block_of(int* counter, int group_size) {
-  __shared__ int s_last;
-  __builtin_amdgcn_s_waitcnt(0);     // this wave's stores have completed (vmcnt/lgkmcnt 0)
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const int old = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int last = old == group_size - 1;
-    if (last) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
-    s_last = last;
-  }
-  __syncthreads();
-  return s_last != 0;
-}
-
-// Sum of `mine` over the kFinLanes partial-lanes of column c (fixed order), returned to all of them.
-__device__ __forceinline__ float column_total(float mine, float* red, int c, int pl) {
-  red[pl * BN + c] = mine;
-  __syncthreads();
-  float tot = 0.f;
-#pragma unroll
-  for (int i = 0; i < kFinLanes; ++i) tot += red[i * BN + c];
-  __syncthreads();
-  return tot;
-}
+// No kernel here hands data to another workgroup of the same launch.  Two earlier designs did
+// ("the last workgroup of a column tile merges the statistics", "the last batch split adds the
+// slabs") and both lost: with __threadfence() every workgroup writes back and invalidates its
+// XCD's whole L2 (gfx950 has 8 non-coherent L2s) and the GEMM tiles beside it lose their operand
+// reuse (3-6x slower kernels); with agent-scope relaxed atomics (sc1 loads/stores) instead of
+// fences the kernels were correct and fast again, but each still ended in a serial tail — arrival
+// atomic, then dependent passes over memory — of ~10 us.  Merging partial results in the CONSUMER
+// kernel's prologue (L2-resident, fully parallel) costs nothing measurable.
 
 struct BnBwd {            // device view of dfm_bn_bwd
   const float* z;
@@ -84,20 +55,18 @@ struct BnBwd {            // device view of dfm_bn_bwd
   const float* gamma;
   const float* beta;
   float* dy;
-  float* means;
   float* g_gamma;
   float* g_beta;
   const int64_t* seed;
-  float* partial;         // [T][2][N]
-  int* counters;          // [tiles_n]
+  float* partial;         // [T][2][N] per-tile column sums of dy, dy*xhat
   uint32_t thresh;
   float inv_keep;
   int salt;
 };
 
-// Epilogue shared by head_bce and linear_bwd: the workgroup's writer waves hold g(m, n) for a
-// 32 x 32 tile; push it through the BatchNorm's ReLU/dropout mask, store dy, and leave per-tile
-// column sums of dy and dy*xhat in bn.partial.  N = features of the BatchNorm layer.
+// Epilogue shared by linear_bwd: the workgroup's writer waves hold g(m, n) for a 32 x 32 tile; push
+// it through the BatchNorm's ReLU/dropout mask, store dy, and leave per-tile column sums of dy and
+// dy*xhat in bn.partial (merged by bn_bwd_apply).  N = features of the BatchNorm layer.
 __device__ __forceinline__ void bn_mask_tile(const BnBwd& bn, const f32x16& g, const TilePos& pos, int m0, int n0,
                                              int M, int N) {
   const int n = n0 + pos.col();
@@ -123,157 +92,228 @@ __device__ __forceinline__ void bn_mask_tile(const BnBwd& bn, const f32x16& g, c
   s2 += __shfl_xor(s2, 32, kWave);
   if (pos.hf == 0 && okn && m0 + pos.wm < M) {
     const int t = (m0 + pos.wm) / 32;
-    st_agent(bn.partial + (static_cast<int64_t>(t) * 2 + 0) * N + n, s1);
-    st_agent(bn.partial + (static_cast<int64_t>(t) * 2 + 1) * N + n, s2);
+    bn.partial[(static_cast<int64_t>(t) * 2 + 0) * N + n] = s1;
+    bn.partial[(static_cast<int64_t>(t) * 2 + 1) * N + n] = s2;
   }
 }
 
-// Last workgroup of a column tile: means, d gamma, d beta from the per-tile sums (fixed order).
-__device__ __forceinline__ void bn_mask_finalize(const BnBwd& bn, int n0, int M, int N, float* red) {
-  const int T = (M + 31) / 32;
-  const int c = threadIdx.x & (BN - 1), pl = threadIdx.x / BN;
-  const int n = n0 + c;
-  const bool ok = n < N;
-  float s1 = 0.f, s2 = 0.f;
-  if (ok) {
-    for (int t = pl; t < T; t += kFinLanes) {
-      s1 += ld_agent(bn.partial + (static_cast<int64_t>(t) * 2 + 0) * N + n);
-      s2 += ld_agent(bn.partial + (static_cast<int64_t>(t) * 2 + 1) * N + n);
-    }
+// ---- column-tile workgroups of the apply kernels ------------------------------------------------
+// 256 threads = 16 column lanes (one float4 = 4 columns each: 64 columns) x 16 row lanes.
+constexpr int kApThreads = 256, kApCols = 64, kApRowLanes = 16, kApRows = 64;
+
+// Per-column totals over the 16 row lanes of two float4 accumulators (fixed order), to every thread.
+__device__ __forceinline__ void row_lane_totals(float4& a, float4& b, float (*red)[kApRowLanes][kApCols]) {
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  st4(&red[0][rl][cl * 4], a);
+  st4(&red[1][rl][cl * 4], b);
+  __syncthreads();
+  float4 ta = make_float4(0.f, 0.f, 0.f, 0.f), tb = ta;
+#pragma unroll
+  for (int i = 0; i < kApRowLanes; ++i) {
+    const float4 x = ld4(&red[0][i][cl * 4]), y = ld4(&red[1][i][cl * 4]);
+    ta.x += x.x; ta.y += x.y; ta.z += x.z; ta.w += x.w;
+    tb.x += y.x; tb.y += y.y; tb.z += y.z; tb.w += y.w;
   }
-  s1 = column_total(s1, red, c, pl);
-  s2 = column_total(s2, red, c, pl);
-  if (pl == 0 && ok) {
-    bn.means[n] = s1 / static_cast<float>(M);
-    bn.means[N + n] = s2 / static_cast<float>(M);
-    bn.g_beta[n] += s1;
-    bn.g_gamma[n] += s2;
-  }
+  __syncthreads();
+  a = ta; b = tb;
 }
 
 }  // namespace
 
 // =====================================================================================
-// forward: z = x W^T + b with BatchNorm batch statistics.  grid tiles_m * tiles_n (n fastest)
+// forward: z = x W^T + b, per-tile column statistics.  grid tiles_m * tiles_n (n fastest)
 // =====================================================================================
 template <bool FAST>
 __global__ __launch_bounds__(kThreads) void linear_bn_fwd_kernel(
     const float* __restrict__ x, int64_t ldx, const float* __restrict__ w, const float* __restrict__ bias,
-    float* __restrict__ z, int M, int N, int K, int tiles_n, float* __restrict__ partial,
-    int* __restrict__ counters, float* __restrict__ mean_rstd, float* __restrict__ running_mean,
-    float* __restrict__ running_var, int64_t* __restrict__ num_batches, float momentum, float eps) {
+    float* __restrict__ z, int M, int N, int K, int tiles_n, float* __restrict__ partial) {
   __shared__ Smem sm;
   const TilePos pos;
   const int lt = xcd_logical_index(blockIdx.x, gridDim.x);
-  const int tn = lt % tiles_n, tiles_m = gridDim.x / tiles_n;
-  const int m0 = (lt / tiles_n) * BM, n0 = tn * BN;
+  const int m0 = (lt / tiles_n) * BM, n0 = (lt % tiles_n) * BN;
   f32x16 acc = {};
   mainloop<true, true, FAST, FAST>(x, ldx, w, K, M, N, m0, n0, 0, K, sm, pos, acc);
-  if (pos.khalf == 0) {
-    const int n = n0 + pos.col();
-    const bool okn = n < N;
-    const float bv = (bias && okn) ? bias[n] : 0.f;
-    const int cnt_i = M - (m0 + pos.wm) < 32 ? M - (m0 + pos.wm) : 32;   // valid rows of this MFMA tile
-    float v[16];
-    float s = 0.f;
+  if (pos.khalf == 1) return;
+  const int n = n0 + pos.col();
+  const bool okn = n < N;
+  const float bv = (bias && okn) ? bias[n] : 0.f;
+  const int cnt_i = M - (m0 + pos.wm) < 32 ? M - (m0 + pos.wm) : 32;   // valid rows of this MFMA tile
+  float v[16];
+  float sum = 0.f;
 #pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-      const int m = m0 + pos.row(reg);
-      v[reg] = acc[reg] + bv;
-      if (m < M && okn) {
-        z[static_cast<int64_t>(m) * N + n] = v[reg];
-        s += v[reg];
+  for (int reg = 0; reg < 16; ++reg) {
+    const int m = m0 + pos.row(reg);
+    v[reg] = acc[reg] + bv;
+    if (m < M && okn) {
+      z[static_cast<int64_t>(m) * N + n] = v[reg];
+      sum += v[reg];
+    }
+  }
+  sum += __shfl_xor(sum, 32, kWave);
+  const float mean_t = cnt_i > 0 ? sum / static_cast<float>(cnt_i) : 0.f;
+  float q = 0.f;
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg) {
+    const int m = m0 + pos.row(reg);
+    const float d = v[reg] - mean_t;
+    if (m < M) q = fmaf(d, d, q);
+  }
+  q += __shfl_xor(q, 32, kWave);
+  if (pos.hf == 0 && okn && cnt_i > 0) {
+    const int t = (m0 + pos.wm) / 32;
+    partial[(static_cast<int64_t>(t) * 2 + 0) * N + n] = mean_t;     // tile mean
+    partial[(static_cast<int64_t>(t) * 2 + 1) * N + n] = q;          // tile M2 = sum (z - tile mean)^2
+  }
+}
+
+// a = dropout(relu(gamma * (z - mean) * rstd + beta)) for 64 columns x 64 rows per workgroup, after
+// merging the (count, mean, M2) of the column's 32-row tiles (Chan's formula about tile 0's mean, so
+// nothing cancels).  grid (column tiles, row groups); row group 0 also publishes the statistics.
+__global__ __launch_bounds__(kApThreads) void bn_relu_dropout_apply_kernel(
+    const float* __restrict__ z, int M, int N, const float* __restrict__ partial, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float* __restrict__ mean_rstd, float* __restrict__ running_mean,
+    float* __restrict__ running_var, int64_t* __restrict__ num_batches, float momentum, float eps, uint32_t thresh,
+    float inv_keep, const int64_t* __restrict__ seed_ptr, int salt, float* __restrict__ out) {
+  __shared__ float red[2][kApRowLanes][kApCols];
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c = blockIdx.x * kApCols + cl * 4;
+  const bool okc = c < N;                       // N % 4 == 0: a float4 is all in or all out
+  const int cc = okc ? c : 0;
+  const int T = (M + 31) / 32;
+  const float4 m0v = ld4(partial + cc);         // tile 0's means: the shift
+  float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+  for (int t = rl; t < T; t += kApRowLanes) {
+    const float cnt = static_cast<float>(M - 32 * t < 32 ? M - 32 * t : 32);
+    const float4 mt = ld4(partial + (static_cast<int64_t>(t) * 2 + 0) * N + cc);
+    const float4 qt = ld4(partial + (static_cast<int64_t>(t) * 2 + 1) * N + cc);
+    const float dx = mt.x - m0v.x, dy = mt.y - m0v.y, dz = mt.z - m0v.z, dw = mt.w - m0v.w;
+    s1.x = fmaf(cnt, dx, s1.x); s1.y = fmaf(cnt, dy, s1.y); s1.z = fmaf(cnt, dz, s1.z); s1.w = fmaf(cnt, dw, s1.w);
+    s2.x += fmaf(cnt * dx, dx, qt.x); s2.y += fmaf(cnt * dy, dy, qt.y);
+    s2.z += fmaf(cnt * dz, dz, qt.z); s2.w += fmaf(cnt * dw, dw, qt.w);
+  }
+  row_lane_totals(s1, s2, red);
+  const float invM = 1.f / static_cast<float>(M);
+  float mu[4], rs[4], var[4];
+  const float s1a[4] = {s1.x, s1.y, s1.z, s1.w}, s2a[4] = {s2.x, s2.y, s2.z, s2.w};
+  const float sh[4] = {m0v.x, m0v.y, m0v.z, m0v.w};
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const float d = s1a[u] * invM;               // mean - shift
+    mu[u] = sh[u] + d;
+    var[u] = fmaxf(s2a[u] * invM - d * d, 0.f);  // biased, as BN normalises
+    rs[u] = rsqrtf(var[u] + eps);
+  }
+  if (blockIdx.y == 0 && rl == 0 && okc) {
+    st4(mean_rstd + c, make_float4(mu[0], mu[1], mu[2], mu[3]));
+    st4(mean_rstd + N + c, make_float4(rs[0], rs[1], rs[2], rs[3]));
+    if (running_mean) {
+      const float unb = M > 1 ? static_cast<float>(M) / static_cast<float>(M - 1) : 1.f;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        running_mean[c + u] = (1.f - momentum) * running_mean[c + u] + momentum * mu[u];
+        running_var[c + u] = (1.f - momentum) * running_var[c + u] + momentum * var[u] * unb;
       }
     }
-    s += __shfl_xor(s, 32, kWave);
-    const float mean_t = cnt_i > 0 ? s / static_cast<float>(cnt_i) : 0.f;
-    float q = 0.f;
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-      const int m = m0 + pos.row(reg);
-      const float d = v[reg] - mean_t;
-      if (m < M) q = fmaf(d, d, q);
-    }
-    q += __shfl_xor(q, 32, kWave);
-    if (pos.hf == 0 && okn && cnt_i > 0) {
-      const int t = (m0 + pos.wm) / 32;
-      st_agent(partial + (static_cast<int64_t>(t) * 2 + 0) * N + n, mean_t);
-      st_agent(partial + (static_cast<int64_t>(t) * 2 + 1) * N + n, q);
-    }
+    if (blockIdx.x == 0 && cl == 0 && num_batches) num_batches[0] += 1;
   }
-  if (!last_block_of(counters + tn, tiles_m)) return;
-  // ---- merge the tiles' (count, mean, M2) of this column tile: mean first, then M2 about it ----
-  float* red = &sm.a[0][0];
-  const int T = (M + 31) / 32;
-  const int c = threadIdx.x & (BN - 1), pl = threadIdx.x / BN;
-  const int n = n0 + c;
-  const bool ok = n < N;
-  float s = 0.f;
-  if (ok) {
-    for (int t = pl; t < T; t += kFinLanes) {
-      const int cnt = M - 32 * t < 32 ? M - 32 * t : 32;
-      s = fmaf(static_cast<float>(cnt), ld_agent(partial + (static_cast<int64_t>(t) * 2) * N + n), s);
-    }
-  }
-  const float mu = column_total(s, red, c, pl) / static_cast<float>(M);
-  float q = 0.f;
-  if (ok) {
-    for (int t = pl; t < T; t += kFinLanes) {
-      const int cnt = M - 32 * t < 32 ? M - 32 * t : 32;
-      const float d = ld_agent(partial + (static_cast<int64_t>(t) * 2) * N + n) - mu;
-      q += fmaf(static_cast<float>(cnt) * d, d, ld_agent(partial + (static_cast<int64_t>(t) * 2 + 1) * N + n));
-    }
-  }
-  const float var = column_total(q, red, c, pl) / static_cast<float>(M);   // biased, as BN normalises
-  if (pl == 0 && ok) {
-    mean_rstd[n] = mu;
-    mean_rstd[N + n] = rsqrtf(var + eps);
-    if (running_mean) {
-      const float unbiased = M > 1 ? var * static_cast<float>(M) / static_cast<float>(M - 1) : var;
-      running_mean[n] = (1.f - momentum) * running_mean[n] + momentum * mu;
-      running_var[n] = (1.f - momentum) * running_var[n] + momentum * unbiased;
-    }
-  }
-  if (tn == 0 && threadIdx.x == 0 && num_batches) num_batches[0] += 1;
-}
-
-// a = dropout(relu(gamma * (z - mean) * rstd + beta)), 4 elements per thread (N % 4 == 0)
-__global__ __launch_bounds__(256) void bn_relu_dropout_apply_kernel(
-    const float* __restrict__ z, int64_t total4, int N, const float* __restrict__ mean_rstd,
-    const float* __restrict__ gamma, const float* __restrict__ beta, uint32_t thresh, float inv_keep,
-    const int64_t* __restrict__ seed_ptr, int salt, float* __restrict__ out) {
-  const int64_t i4 = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
-  if (i4 >= total4) return;
-  const int64_t idx = i4 * 4;
+  if (!okc) return;
   const int64_t seed = seed_ptr ? seed_ptr[0] : 0;
-  const int c = static_cast<int>(idx % N);
-  const float4 zv = ld4(z + idx), mu = ld4(mean_rstd + c), rs = ld4(mean_rstd + N + c), ga = ld4(gamma + c),
-               be = ld4(beta + c);
-  float4 o;
-  o.x = fmaxf(fmaf(ga.x, (zv.x - mu.x) * rs.x, be.x), 0.f) * drop_scale(seed, salt, idx + 0, thresh, inv_keep);
-  o.y = fmaxf(fmaf(ga.y, (zv.y - mu.y) * rs.y, be.y), 0.f) * drop_scale(seed, salt, idx + 1, thresh, inv_keep);
-  o.z = fmaxf(fmaf(ga.z, (zv.z - mu.z) * rs.z, be.z), 0.f) * drop_scale(seed, salt, idx + 2, thresh, inv_keep);
-  o.w = fmaxf(fmaf(ga.w, (zv.w - mu.w) * rs.w, be.w), 0.f) * drop_scale(seed, salt, idx + 3, thresh, inv_keep);
-  st4(out + idx, o);
+  const float4 ga = ld4(gamma + c), be = ld4(beta + c);
+  const float gav[4] = {ga.x, ga.y, ga.z, ga.w}, bev[4] = {be.x, be.y, be.z, be.w};
+  const int r0 = blockIdx.y * kApRows;
+#pragma unroll
+  for (int i = 0; i < kApRows / kApRowLanes; ++i) {
+    const int m = r0 + rl + i * kApRowLanes;
+    if (m < M) {
+      const int64_t idx = static_cast<int64_t>(m) * N + c;
+      const float4 zv = ld4(z + idx);
+      const float zz[4] = {zv.x, zv.y, zv.z, zv.w};
+      float o[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        o[u] = fmaxf(fmaf(gav[u], (zz[u] - mu[u]) * rs[u], bev[u]), 0.f) * drop_scale(seed, salt, idx + u, thresh, inv_keep);
+      st4(out + idx, make_float4(o[0], o[1], o[2], o[3]));
+    }
+  }
 }
 
-// dz = gamma * rstd * (dy - mean(dy) - xhat * mean(dy * xhat)); dz may alias dy
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
-    const float* __restrict__ dy, const float* __restrict__ z, int64_t total4, int N,
-    const float* __restrict__ mean_rstd, const float* __restrict__ gamma, const float* __restrict__ means,
-    float* __restrict__ dz) {
-  const int64_t i4 = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
-  if (i4 >= total4) return;
-  const int64_t idx = i4 * 4;
-  const int c = static_cast<int>(idx % N);
-  const float4 d = ld4(dy + idx), zv = ld4(z + idx), mu = ld4(mean_rstd + c), rs = ld4(mean_rstd + N + c),
-               ga = ld4(gamma + c), m1 = ld4(means + c), m2 = ld4(means + N + c);
-  float4 o;
-  o.x = ga.x * rs.x * (d.x - m1.x - (zv.x - mu.x) * rs.x * m2.x);
-  o.y = ga.y * rs.y * (d.y - m1.y - (zv.y - mu.y) * rs.y * m2.y);
-  o.z = ga.z * rs.z * (d.z - m1.z - (zv.z - mu.z) * rs.z * m2.z);
-  o.w = ga.w * rs.w * (d.w - m1.w - (zv.w - mu.w) * rs.w * m2.w);
-  st4(dz + idx, o);
+// Sums the head's per-workgroup partials that bn_bwd_apply's column merge does not cover.
+struct HeadTail {
+  float* g_w;       // (K) += sum_b dlogit_b * a[b, :]
+  float* g_b;       // (1) += sum_b dlogit_b     (may be NULL)
+  float* loss;      // (1)  = mean BCE
+  int enabled;
+};
+
+// dz = gamma * rstd * (dy - mean(dy) - xhat * mean(dy * xhat)) for 64 columns x 64 rows per workgroup,
+// after merging the per-tile column sums of dy and dy*xhat: `partial` has T rows of `stride` floats,
+// the two planes at column offsets 0 and off1 (dx epilogue: [T][2][N]; head_bce: [blocks][3K+2]).
+// Row group 0 adds d gamma / d beta (and finishes the head's d w, d b, loss).  dz may alias dy.
+__global__ __launch_bounds__(kApThreads) void bn_bwd_apply_kernel(
+    const float* __restrict__ dy, const float* __restrict__ z, int M, int N, const float* __restrict__ mean_rstd,
+    const float* __restrict__ gamma, const float* __restrict__ partial, int T, int stride, int off1,
+    float* __restrict__ g_gamma, float* __restrict__ g_beta, HeadTail head, float* __restrict__ dz) {
+  __shared__ float red[2][kApRowLanes][kApCols];
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c = blockIdx.x * kApCols + cl * 4;
+  const bool okc = c < N;
+  const int cc = okc ? c : 0;
+  float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+  for (int t = rl; t < T; t += kApRowLanes) {
+    const float4 a = ld4(partial + static_cast<int64_t>(t) * stride + cc);
+    const float4 b = ld4(partial + static_cast<int64_t>(t) * stride + off1 + cc);
+    s1.x += a.x; s1.y += a.y; s1.z += a.z; s1.w += a.w;
+    s2.x += b.x; s2.y += b.y; s2.z += b.z; s2.w += b.w;
+  }
+  row_lane_totals(s1, s2, red);
+  if (blockIdx.y == 0) {
+    if (rl == 0 && okc) {
+      const float4 gb = ld4(g_beta + c), gg = ld4(g_gamma + c);
+      st4(g_beta + c, make_float4(gb.x + s1.x, gb.y + s1.y, gb.z + s1.z, gb.w + s1.w));
+      st4(g_gamma + c, make_float4(gg.x + s2.x, gg.y + s2.y, gg.z + s2.z, gg.w + s2.w));
+    }
+    if (head.enabled) {     // third plane (d logit * a) for these columns; the two scalars from column tile 0
+      float4 s3 = make_float4(0.f, 0.f, 0.f, 0.f), s4 = s3;
+      for (int t = rl; t < T; t += kApRowLanes) {
+        const float4 a = ld4(partial + static_cast<int64_t>(t) * stride + 2 * off1 + cc);
+        s3.x += a.x; s3.y += a.y; s3.z += a.z; s3.w += a.w;
+        if (cl == 0) {      // loss and d logit sums sit behind the three planes
+          s4.x += partial[static_cast<int64_t>(t) * stride + 3 * off1];
+          s4.y += partial[static_cast<int64_t>(t) * stride + 3 * off1 + 1];
+        }
+      }
+      row_lane_totals(s3, s4, red);
+      if (rl == 0 && okc) {
+        const float4 gw = ld4(head.g_w + c);
+        st4(head.g_w + c, make_float4(gw.x + s3.x, gw.y + s3.y, gw.z + s3.z, gw.w + s3.w));
+      }
+      if (blockIdx.x == 0 && threadIdx.x == 0) {
+        head.loss[0] = s4.x / static_cast<float>(M);
+        if (head.g_b) head.g_b[0] += s4.y;
+      }
+    }
+  }
+  if (!okc) return;
+  const float invM = 1.f / static_cast<float>(M);
+  const float4 muv = ld4(mean_rstd + c), rsv = ld4(mean_rstd + N + c), gav = ld4(gamma + c);
+  const float mu[4] = {muv.x, muv.y, muv.z, muv.w}, rs[4] = {rsv.x, rsv.y, rsv.z, rsv.w};
+  const float ga[4] = {gav.x, gav.y, gav.z, gav.w};
+  const float m1[4] = {s1.x * invM, s1.y * invM, s1.z * invM, s1.w * invM};
+  const float m2[4] = {s2.x * invM, s2.y * invM, s2.z * invM, s2.w * invM};
+  const int r0 = blockIdx.y * kApRows;
+#pragma unroll
+  for (int i = 0; i < kApRows / kApRowLanes; ++i) {
+    const int m = r0 + rl + i * kApRowLanes;
+    if (m < M) {
+      const int64_t idx = static_cast<int64_t>(m) * N + c;
+      const float4 dv = ld4(dy + idx), zv = ld4(z + idx);
+      const float dd[4] = {dv.x, dv.y, dv.z, dv.w}, zz[4] = {zv.x, zv.y, zv.z, zv.w};
+      float o[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) o[u] = ga[u] * rs[u] * (dd[u] - m1[u] - (zz[u] - mu[u]) * rs[u] * m2[u]);
+      st4(dz + idx, make_float4(o[0], o[1], o[2], o[3]));
+    }
+  }
 }
 
 // =====================================================================================
@@ -286,16 +326,16 @@ constexpr int kHeadRows = kHeadThreads / kHeadLPR;       // 32 rows per workgrou
 constexpr int kHeadMaxChunks = 8;                        // K <= 256
 }  // namespace
 
-// partials per workgroup: [3][K] column sums (dy, dy*xhat, dlogit*a) + [2] (loss, dlogit)
+// partials per workgroup (merged by bn_bwd_apply): [3][K] column sums (dy, dy*xhat, dlogit*a),
+// then loss and dlogit sums, padded to 3K + 4 floats
 template <int CH>   // CH = K / 32 float4 chunks per lane
 __global__ __launch_bounds__(kHeadThreads) void head_bce_kernel(
     const float* __restrict__ a, int M, const float* __restrict__ w, const float* __restrict__ b,
     const float* __restrict__ fo, const float* __restrict__ fm, const float* __restrict__ labels,
-    float* __restrict__ logits, float* __restrict__ loss, float* __restrict__ dlogit, float* __restrict__ g_w,
-    float* __restrict__ g_b, float* __restrict__ g_a, BnBwd bn, int has_bn, float* __restrict__ hpart,
-    int* __restrict__ counter) {
+    float* __restrict__ logits, float* __restrict__ dlogit, float* __restrict__ g_a, BnBwd bn, int has_bn,
+    float* __restrict__ hpart) {
   constexpr int K = CH * 32;
-  constexpr int P = 3 * K + 2;
+  constexpr int P = 3 * K + 4;
   __shared__ float red[kHeadThreads / kWave][P];
   const int tid = threadIdx.x, l8 = tid & (kHeadLPR - 1), rl = tid / kHeadLPR;
   const int m = blockIdx.x * kHeadRows + rl;
@@ -376,36 +416,13 @@ __global__ __launch_bounds__(kHeadThreads) void head_bce_kernel(
     sl += __shfl_xor(sl, msk, kWave);
     sd += __shfl_xor(sd, msk, kWave);
   }
-  if (lane == 0) { red[wave][3 * K] = sl; red[wave][3 * K + 1] = sd; }
+  if (lane == 0) {
+    red[wave][3 * K] = sl; red[wave][3 * K + 1] = sd;
+    red[wave][3 * K + 2] = 0.f; red[wave][3 * K + 3] = 0.f;
+  }
   __syncthreads();
   for (int o = tid; o < P; o += kHeadThreads)
-    st_agent(hpart + static_cast<int64_t>(blockIdx.x) * P + o, (red[0][o] + red[1][o]) + (red[2][o] + red[3][o]));
-  if (!last_block_of(counter, gridDim.x)) return;
-  const int nb = gridDim.x;
-  for (int o = tid; o < P; o += kHeadThreads) {
-    // fixed order; loads issued 8 at a time so they overlap instead of chaining
-    float s = 0.f;
-    int i = 0;
-    for (; i + 8 <= nb; i += 8) {
-      float tq[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) tq[u] = ld_agent(hpart + static_cast<int64_t>(i + u) * P + o);
-#pragma unroll
-      for (int u = 0; u < 8; ++u) s += tq[u];
-    }
-    for (; i < nb; ++i) s += ld_agent(hpart + static_cast<int64_t>(i) * P + o);
-    if (o < K) {
-      if (has_bn) { bn.means[o] = s / static_cast<float>(M); bn.g_beta[o] += s; }
-    } else if (o < 2 * K) {
-      if (has_bn) { bn.means[K + (o - K)] = s / static_cast<float>(M); bn.g_gamma[o - K] += s; }
-    } else if (o < 3 * K) {
-      g_w[o - 2 * K] += s;
-    } else if (o == 3 * K) {
-      loss[0] = s / static_cast<float>(M);
-    } else {
-      if (g_b) g_b[0] += s;
-    }
-  }
+    hpart[static_cast<int64_t>(blockIdx.x) * P + o] = (red[0][o] + red[1][o]) + (red[2][o] + red[3][o]);
 }
 
 // =====================================================================================
@@ -422,13 +439,13 @@ struct FmBwd {
 template <bool FAST, int EPI>   // EPI 0: plain store, 1: BatchNorm mask of the lower layer, 2: + FM backward
 __global__ __launch_bounds__(kThreads) void linear_bwd_kernel(
     const float* __restrict__ dz, const float* __restrict__ x, const float* __restrict__ w,
-    float* __restrict__ g_w, float* __restrict__ g_x, int M, int N, int K, int dw_tiles_n, int dw_tiles, int splits,
-    int k_per_split, float* __restrict__ slabs, int* __restrict__ dw_counters, int dx_tiles_n, BnBwd bn, FmBwd fmb) {
+    float* __restrict__ g_x, int M, int N, int K, int dw_tiles_n, int dw_tiles, int splits,
+    int dw_blocks, int k_per_split, float* __restrict__ slabs, int dx_tiles_n, BnBwd bn, FmBwd fmb) {
   __shared__ Smem sm;
   const TilePos pos;
   f32x16 acc = {};
   const int bid = xcd_logical_index(blockIdx.x, gridDim.x);
-  if (bid < dw_tiles * splits) {
+  if (bid < dw_blocks) {
     // ---- dW (N x K) = sum over the batch: A = dz (k-strided), B = x (k-strided) ----
     const int tile = bid % dw_tiles, sp = bid / dw_tiles;
     const int m0 = (tile / dw_tiles_n) * BM, n0 = (tile % dw_tiles_n) * BN;
@@ -437,46 +454,24 @@ __global__ __launch_bounds__(kThreads) void linear_bwd_kernel(
     mainloop<false, false, FAST, FAST>(dz, N, x, K, N, K, m0, n0, kb, ke, sm, pos, acc);
     const int n = n0 + pos.col();
     if (pos.khalf == 0 && n < K) {
-      float* sl = slabs + static_cast<int64_t>(sp) * N * K;
+      float* sl = slabs + static_cast<int64_t>(sp) * N * K;      // summed by slab_reduce_kernel
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
         const int m = m0 + pos.row(reg);
-        if (m < N) st_agent(sl + static_cast<int64_t>(m) * K + n, acc[reg]);
-      }
-    }
-    if (!last_block_of(dw_counters + tile, splits)) return;
-    // the last split of this tile adds the slabs in order: 64 x 64 elements, 8 per thread
-    for (int i = threadIdx.x; i < BM * BN; i += kThreads) {
-      const int m = m0 + i / BN, nn = n0 + i % BN;
-      if (m < N && nn < K) {
-        const int64_t off = static_cast<int64_t>(m) * K + nn;
-        float s = 0.f;
-        int q = 0;
-        for (; q + 4 <= splits; q += 4) {
-          float tq[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) tq[u] = ld_agent(slabs + static_cast<int64_t>(q + u) * N * K + off);
-#pragma unroll
-          for (int u = 0; u < 4; ++u) s += tq[u];
-        }
-        for (; q < splits; ++q) s += ld_agent(slabs + static_cast<int64_t>(q) * N * K + off);
-        g_w[off] += s;
+        if (m < N) sl[static_cast<int64_t>(m) * K + n] = acc[reg];
       }
     }
     return;
   }
   // ---- dx (M x K) = dz W: A = dz (k-contiguous), B = W (k-strided) ----
-  const int t = bid - dw_tiles * splits;
+  const int t = bid - dw_blocks;
   const int m0 = (t / dx_tiles_n) * BM, n0 = (t % dx_tiles_n) * BN;
   mainloop<true, false, FAST, FAST>(dz, N, w, K, M, K, m0, n0, 0, N, sm, pos, acc);
+  if (pos.khalf == 1) return;
   if (EPI == 1) {
-    if (pos.khalf == 0) bn_mask_tile(bn, acc, pos, m0, n0, M, K);
-    const int tiles_m = (M + BM - 1) / BM;
-    if (!last_block_of(bn.counters + (t % dx_tiles_n), tiles_m)) return;
-    bn_mask_finalize(bn, n0, M, K, &sm.a[0][0]);
+    bn_mask_tile(bn, acc, pos, m0, n0, M, K);
     return;
   }
-  if (pos.khalf == 1) return;
   const int n = n0 + pos.col();
   if (n >= K) return;
 #pragma unroll
@@ -492,131 +487,173 @@ __global__ __launch_bounds__(kThreads) void linear_bwd_kernel(
   }
 }
 
+// g_w += sum_s slab_s (fixed order) for every Linear of the tower in ONE launch: the batch-split
+// partial products of all dfm_linear_backward calls of a step are finished together, so no GEMM
+// workgroup waits on an arrival counter or walks the slabs serially.
+constexpr int kMaxSlabRefs = 16;
+struct SlabRefs {
+  const float* slabs[kMaxSlabRefs];
+  float* g[kMaxSlabRefs];
+  int elems4[kMaxSlabRefs];        // elements / 4 (out*in is a multiple of 4 on this path)
+  int splits[kMaxSlabRefs];
+  int first_block[kMaxSlabRefs + 1];
+  int count;
+};
+__global__ __launch_bounds__(256) void slab_reduce_kernel(SlabRefs refs) {
+  int e = 0;
+  while (e + 1 < refs.count && static_cast<int>(blockIdx.x) >= refs.first_block[e + 1]) ++e;
+  const int i4 = (blockIdx.x - refs.first_block[e]) * 256 + threadIdx.x;
+  if (i4 >= refs.elems4[e]) return;
+  const float* sl = refs.slabs[e] + static_cast<int64_t>(i4) * 4;
+  const int64_t stride = static_cast<int64_t>(refs.elems4[e]) * 4;
+  const int splits = refs.splits[e];
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  int q = 0;
+  for (; q + 8 <= splits; q += 8) {      // 8 loads in flight, added in order
+    float4 t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = ld4(sl + (q + u) * stride);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { acc.x += t[u].x; acc.y += t[u].y; acc.z += t[u].z; acc.w += t[u].w; }
+  }
+  for (; q < splits; ++q) {
+    const float4 t = ld4(sl + q * stride);
+    acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+  }
+  float* g = refs.g[e] + static_cast<int64_t>(i4) * 4;
+  const float4 old = ld4(g);
+  st4(g, make_float4(old.x + acc.x, old.y + acc.y, old.z + acc.z, old.w + acc.w));
+}
+
 // =====================================================================================
 // host side
 // =====================================================================================
 namespace {
 inline int tiles(int n, int t) { return (n + t - 1) / t; }
 inline size_t align256(size_t b) { return (b + 255) / 256 * 256; }
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-// workspace of a BatchNorm column reduction over (m, n): partial [T][2][n] floats, then counters
-inline size_t bn_partial_bytes(int64_t m, int n) { return align256(sizeof(float) * 2 * static_cast<size_t>((m + 31) / 32) * n); }
-inline size_t bn_counter_bytes(int n) { return align256(sizeof(int) * static_cast<size_t>(tiles(n, BN))); }
+// per-tile column statistics of a (m, n) activation: [ceil(m/32)][2][n] floats
+inline size_t tile_partial_bytes(int64_t m, int n) { return align256(sizeof(float) * 2 * static_cast<size_t>((m + 31) / 32) * n); }
+inline size_t head_partial_bytes(int64_t m, int k) {
+  return align256(sizeof(float) * static_cast<size_t>((m + kHeadRows - 1) / kHeadRows) * (3 * static_cast<size_t>(k) + 4));
+}
 
 int dw_splits(int n_out, int k_in, int64_t m) {
   const int64_t t = static_cast<int64_t>(tiles(n_out, BM)) * tiles(k_in, BN);
-  int64_t s = (512 + t - 1) / t;                  // aim for ~2 workgroups per CU from the dW part
+  int64_t s = (512 + t - 1) / t;                  // aim for ~2 workgroups per CU
   const int64_t max_s = m / (4 * BK) > 0 ? m / (4 * BK) : 1;   // at least 4 k-slices per split
   if (s > max_s) s = max_s;
   return s < 1 ? 1 : static_cast<int>(s);
 }
 
-bool fill_bn(const dfm_bn_bwd* h, int64_t m, int n, BnBwd* d) {
-  if (!h->z || !h->mean_rstd || !h->gamma || !h->beta || !h->dy || !h->means || !h->g_gamma || !h->g_beta ||
-      !h->workspace)
+bool fill_bn(const dfm_bn_bwd* h, BnBwd* d) {
+  if (!h->z || !h->mean_rstd || !h->gamma || !h->beta || !h->dy || !h->g_gamma || !h->g_beta || !h->workspace)
     return false;
   if (!(h->p_drop >= 0.f && h->p_drop < 1.f) || (h->p_drop > 0.f && !h->seed)) return false;
   d->z = h->z; d->mean_rstd = h->mean_rstd; d->gamma = h->gamma; d->beta = h->beta;
-  d->dy = h->dy; d->means = h->means; d->g_gamma = h->g_gamma; d->g_beta = h->g_beta;
+  d->dy = h->dy; d->g_gamma = h->g_gamma; d->g_beta = h->g_beta;
   d->seed = h->seed;
   d->partial = static_cast<float*>(h->workspace);
-  d->counters = reinterpret_cast<int*>(static_cast<char*>(h->workspace) + bn_partial_bytes(m, n));
   d->thresh = dropout_thresh(h->p_drop);
   d->inv_keep = 1.f / (1.f - h->p_drop);
   d->salt = h->salt;
   return true;
 }
-inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 }  // namespace
 
 extern "C" size_t dfm_bn_bwd_workspace_bytes(int64_t batch, int features) {
-  return bn_partial_bytes(batch, features) + bn_counter_bytes(features);
+  const size_t a = tile_partial_bytes(batch, features), b = head_partial_bytes(batch, features);
+  return a > b ? a : b;
 }
 
 extern "C" size_t dfm_linear_bn_workspace_bytes(int64_t batch, int features) {
-  return bn_partial_bytes(batch, features) + bn_counter_bytes(features);
+  return tile_partial_bytes(batch, features);
 }
 
 extern "C" int dfm_linear_bn_forward(const float* d_x, int64_t ldx, const float* d_w, const float* d_bias,
                                      int64_t batch, int out_features, int in_features, float* d_z,
-                                     float* d_mean_rstd, float* d_running_mean, float* d_running_var,
-                                     int64_t* d_num_batches, float momentum, float eps, void* d_workspace,
-                                     dfm_stream_t stream) {
-  DFM_REQUIRE(d_x && d_w && d_z && d_mean_rstd && d_workspace, "null argument");
+                                     void* d_workspace, dfm_stream_t stream) {
+  DFM_REQUIRE(d_x && d_w && d_z && d_workspace, "null argument");
   DFM_REQUIRE(batch > 0 && batch < (1 << 30) && out_features > 0 && in_features > 0, "bad shape");
   const int M = static_cast<int>(batch), N = out_features, K = in_features;
   float* partial = static_cast<float*>(d_workspace);
-  int* counters = reinterpret_cast<int*>(static_cast<char*>(d_workspace) + bn_partial_bytes(M, N));
   const int tn = tiles(N, BN);
   const dim3 grid(static_cast<unsigned>(tn) * tiles(M, BM));
   const bool fast = operand_fast(d_x, ldx, true, M, K) && operand_fast(d_w, K, true, N, K);
   if (fast)
     hipLaunchKernelGGL(linear_bn_fwd_kernel<true>, grid, dim3(kThreads), 0, as_stream(stream), d_x, ldx, d_w, d_bias,
-                       d_z, M, N, K, tn, partial, counters, d_mean_rstd, d_running_mean, d_running_var,
-                       d_num_batches, momentum, eps);
+                       d_z, M, N, K, tn, partial);
   else
     hipLaunchKernelGGL(linear_bn_fwd_kernel<false>, grid, dim3(kThreads), 0, as_stream(stream), d_x, ldx, d_w, d_bias,
-                       d_z, M, N, K, tn, partial, counters, d_mean_rstd, d_running_mean, d_running_var,
-                       d_num_batches, momentum, eps);
+                       d_z, M, N, K, tn, partial);
   DFM_LAUNCH_CHECK();
   return DFM_OK;
 }
 
-extern "C" int dfm_bn_relu_dropout_apply(const float* d_z, int64_t batch, int features, const float* d_mean_rstd,
-                                         const float* d_gamma, const float* d_beta, float p_drop,
-                                         const int64_t* d_seed, int salt, float* d_out, dfm_stream_t stream) {
-  DFM_REQUIRE(d_z && d_mean_rstd && d_gamma && d_beta && d_out, "null argument");
-  DFM_REQUIRE(batch > 0 && features > 0 && features % 4 == 0, "features must be a positive multiple of 4");
-  DFM_REQUIRE(aligned16(d_z) && aligned16(d_mean_rstd) && aligned16(d_gamma) && aligned16(d_beta) && aligned16(d_out),
-              "pointers must be 16-byte aligned");
+extern "C" int dfm_bn_relu_dropout_apply(const float* d_z, int64_t batch, int features, const void* d_workspace,
+                                         const float* d_gamma, const float* d_beta, float* d_mean_rstd,
+                                         float* d_running_mean, float* d_running_var, int64_t* d_num_batches,
+                                         float momentum, float eps, float p_drop, const int64_t* d_seed, int salt,
+                                         float* d_out, dfm_stream_t stream) {
+  DFM_REQUIRE(d_z && d_workspace && d_gamma && d_beta && d_mean_rstd && d_out, "null argument");
+  DFM_REQUIRE(batch > 0 && batch < (1 << 30) && features > 0 && features % 4 == 0,
+              "features must be a positive multiple of 4");
+  DFM_REQUIRE(aligned16(d_z) && aligned16(d_workspace) && aligned16(d_mean_rstd) && aligned16(d_gamma) &&
+                  aligned16(d_beta) && aligned16(d_out), "pointers must be 16-byte aligned");
   DFM_REQUIRE(p_drop >= 0.f && p_drop < 1.f && (p_drop == 0.f || d_seed), "bad dropout arguments");
-  const int64_t total4 = batch * features / 4;
-  hipLaunchKernelGGL(bn_relu_dropout_apply_kernel, dim3(static_cast<unsigned>((total4 + 255) / 256)), dim3(256), 0,
-                     as_stream(stream), d_z, total4, features, d_mean_rstd, d_gamma, d_beta, dropout_thresh(p_drop),
-                     1.f / (1.f - p_drop), d_seed, salt, d_out);
+  const int M = static_cast<int>(batch);
+  const dim3 grid(tiles(features, kApCols), tiles(M, kApRows));
+  hipLaunchKernelGGL(bn_relu_dropout_apply_kernel, grid, dim3(kApThreads), 0, as_stream(stream), d_z, M, features,
+                     static_cast<const float*>(d_workspace), d_gamma, d_beta, d_mean_rstd, d_running_mean,
+                     d_running_var, d_num_batches, momentum, eps, dropout_thresh(p_drop), 1.f / (1.f - p_drop), d_seed,
+                     salt, d_out);
   DFM_LAUNCH_CHECK();
   return DFM_OK;
 }
 
-extern "C" int dfm_bn_backward_apply(const float* d_dy, const float* d_z, const float* d_mean_rstd,
-                                     const float* d_gamma, const float* d_means, int64_t batch, int features,
+extern "C" int dfm_bn_backward_apply(const dfm_bn_bwd* bn, int64_t batch, int features, const dfm_head_tail* head,
                                      float* d_dz, dfm_stream_t stream) {
-  DFM_REQUIRE(d_dy && d_z && d_mean_rstd && d_gamma && d_means && d_dz, "null argument");
-  DFM_REQUIRE(batch > 0 && features > 0 && features % 4 == 0, "features must be a positive multiple of 4");
-  DFM_REQUIRE(aligned16(d_dy) && aligned16(d_z) && aligned16(d_mean_rstd) && aligned16(d_gamma) &&
-                  aligned16(d_means) && aligned16(d_dz), "pointers must be 16-byte aligned");
-  const int64_t total4 = batch * features / 4;
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(static_cast<unsigned>((total4 + 255) / 256)), dim3(256), 0,
-                     as_stream(stream), d_dy, d_z, total4, features, d_mean_rstd, d_gamma, d_means, d_dz);
+  DFM_REQUIRE(bn && d_dz, "null argument");
+  DFM_REQUIRE(batch > 0 && batch < (1 << 30) && features > 0 && features % 4 == 0,
+              "features must be a positive multiple of 4");
+  BnBwd d = {};
+  DFM_REQUIRE(fill_bn(bn, &d), "incomplete dfm_bn_bwd");
+  DFM_REQUIRE(aligned16(d.dy) && aligned16(d.z) && aligned16(d.mean_rstd) && aligned16(d.gamma) &&
+                  aligned16(d.partial) && aligned16(d.g_gamma) && aligned16(d.g_beta) && aligned16(d_dz),
+              "pointers must be 16-byte aligned");
+  const int M = static_cast<int>(batch);
+  HeadTail ht = {};
+  int T = (M + 31) / 32, stride = 2 * features, off1 = features;
+  if (head) {       // the mask came from dfm_head_bce: its workgroup partials, not the dx epilogue's
+    DFM_REQUIRE(head->g_w && head->loss && aligned16(head->g_w), "incomplete dfm_head_tail");
+    ht.g_w = head->g_w; ht.g_b = head->g_b; ht.loss = head->loss; ht.enabled = 1;
+    T = (M + kHeadRows - 1) / kHeadRows;
+    stride = 3 * features + 4;
+  }
+  const dim3 grid(tiles(features, kApCols), tiles(M, kApRows));
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, grid, dim3(kApThreads), 0, as_stream(stream), d.dy, d.z, M, features,
+                     d.mean_rstd, d.gamma, d.partial, T, stride, off1, d.g_gamma, d.g_beta, ht, d_dz);
   DFM_LAUNCH_CHECK();
   return DFM_OK;
-}
-
-extern "C" size_t dfm_head_bce_workspace_bytes(int64_t batch, int features) {
-  const size_t blocks = static_cast<size_t>((batch + kHeadRows - 1) / kHeadRows);
-  return align256(sizeof(float) * blocks * (3 * static_cast<size_t>(features) + 2)) + 256;
 }
 
 extern "C" int dfm_head_bce(const float* d_a, int64_t batch, int features, const float* d_w, const float* d_b,
                             const float* d_first_order, const float* d_fm, const float* d_labels, float* d_logits,
-                            float* d_loss, float* d_g_logits, float* d_g_w, float* d_g_b, float* d_g_a,
-                            const dfm_bn_bwd* bn, void* d_workspace, dfm_stream_t stream) {
-  DFM_REQUIRE(d_a && d_w && d_labels && d_logits && d_loss && d_g_logits && d_g_w && d_workspace, "null argument");
+                            float* d_g_logits, const dfm_bn_bwd* bn, dfm_stream_t stream) {
+  DFM_REQUIRE(d_a && d_w && d_labels && d_logits && d_g_logits && bn, "null argument");
   DFM_REQUIRE(batch > 0 && batch < (1 << 30), "bad batch");
   DFM_REQUIRE(features > 0 && features % 32 == 0 && features <= 32 * kHeadMaxChunks,
               "head features must be a multiple of 32, at most 256");
   DFM_REQUIRE(aligned16(d_a) && aligned16(d_w), "pointers must be 16-byte aligned");
   BnBwd dbn = {};
-  if (bn) DFM_REQUIRE(fill_bn(bn, batch, features, &dbn), "incomplete dfm_bn_bwd");
+  DFM_REQUIRE(fill_bn(bn, &dbn), "incomplete dfm_bn_bwd");
   const int M = static_cast<int>(batch);
   const unsigned blocks = static_cast<unsigned>((batch + kHeadRows - 1) / kHeadRows);
-  float* hpart = static_cast<float*>(d_workspace);
-  int* counter = reinterpret_cast<int*>(static_cast<char*>(d_workspace) +
-                                        align256(sizeof(float) * blocks * (3 * static_cast<size_t>(features) + 2)));
 #define DFM_HEAD(CH)                                                                                              \
   hipLaunchKernelGGL(head_bce_kernel<CH>, dim3(blocks), dim3(kHeadThreads), 0, as_stream(stream), d_a, M, d_w, d_b, \
-                     d_first_order, d_fm, d_labels, d_logits, d_loss, d_g_logits, d_g_w, d_g_b, d_g_a, dbn,       \
-                     bn ? 1 : 0, hpart, counter)
+                     d_first_order, d_fm, d_labels, d_logits, d_g_logits, static_cast<float*>(nullptr), dbn, 1,     \
+                     dbn.partial)
   switch (features / 32) {
     case 1: DFM_HEAD(1); break;
     case 2: DFM_HEAD(2); break;
@@ -632,42 +669,49 @@ extern "C" int dfm_head_bce(const float* d_a, int64_t batch, int features, const
   return DFM_OK;
 }
 
+namespace {
+// the batch split actually launched for (out, in, batch): slices per split rounded to whole k-slices
+void dw_split_plan(int n_out, int k_in, int m, int* splits, int* k_per_split) {
+  const int s0 = dw_splits(n_out, k_in, m);
+  *k_per_split = ((m + s0 - 1) / s0 + BK - 1) / BK * BK;
+  *splits = (m + *k_per_split - 1) / *k_per_split;
+}
+}  // namespace
+
 extern "C" size_t dfm_linear_backward_workspace_bytes(int64_t batch, int out_features, int in_features) {
   const int s = dw_splits(out_features, in_features, batch);
-  return align256(sizeof(float) * static_cast<size_t>(s) * out_features * in_features) +
-         align256(sizeof(int) * static_cast<size_t>(tiles(out_features, BM)) * tiles(in_features, BN));
+  return align256(sizeof(float) * static_cast<size_t>(s) * out_features * in_features);
 }
 
 extern "C" int dfm_linear_backward(const float* d_dz, int64_t batch, int out_features, const float* d_x,
-                                   int in_features, const float* d_w, float* d_g_w, float* d_g_x,
-                                   const dfm_bn_bwd* bn_below, const dfm_fm_bwd* fm, void* d_workspace,
+                                   int in_features, const float* d_w, float* d_g_x,
+                                   const dfm_bn_bwd* bn_below, const dfm_fm_bwd* fm, int parts, void* d_workspace,
                                    dfm_stream_t stream) {
-  DFM_REQUIRE(d_dz && d_x && d_w && d_g_w && d_workspace, "null argument");
+  DFM_REQUIRE(d_dz && d_x && d_w && d_workspace, "null argument");
+  DFM_REQUIRE(parts >= 1 && parts <= 3, "parts: 1 = d weight, 2 = d input, 3 = both");
   DFM_REQUIRE(batch > 0 && batch < (1 << 30) && out_features > 0 && in_features > 0, "bad shape");
   DFM_REQUIRE(!(bn_below && fm), "bn_below and fm are exclusive");
-  DFM_REQUIRE(bn_below || d_g_x, "d_g_x is required without bn_below");
+  DFM_REQUIRE(!(parts & 2) || bn_below || d_g_x, "d_g_x is required without bn_below");
   const int M = static_cast<int>(batch), N = out_features, K = in_features;
   BnBwd dbn = {};
-  if (bn_below) DFM_REQUIRE(fill_bn(bn_below, batch, K, &dbn), "incomplete dfm_bn_bwd");
+  if (bn_below && (parts & 2)) DFM_REQUIRE(fill_bn(bn_below, &dbn), "incomplete dfm_bn_bwd");
   FmBwd dfm_ = {};
-  if (fm) {
+  if (fm && (parts & 2)) {
     DFM_REQUIRE(fm->g_fm && fm->fm_sum && fm->e && fm->dim > 0 && K % fm->dim == 0, "incomplete dfm_fm_bwd");
     dfm_.g_fm = fm->g_fm; dfm_.fm_sum = fm->fm_sum; dfm_.e = fm->e; dfm_.dim = fm->dim;
   }
-  const int splits0 = dw_splits(N, K, M);
-  const int k_per_split = ((M + splits0 - 1) / splits0 + BK - 1) / BK * BK;
-  const int splits = (M + k_per_split - 1) / k_per_split;
+  int splits, k_per_split;
+  dw_split_plan(N, K, M, &splits, &k_per_split);
   const int dw_tn = tiles(K, BN), dw_t = tiles(N, BM) * dw_tn;
   const int dx_tn = tiles(K, BN), dx_t = tiles(M, BM) * dx_tn;
   float* slabs = static_cast<float*>(d_workspace);
-  int* dw_counters = reinterpret_cast<int*>(static_cast<char*>(d_workspace) +
-                                            align256(sizeof(float) * static_cast<size_t>(splits0) * N * K));
   const bool fast = operand_fast(d_dz, N, false, N, M) && operand_fast(d_x, K, false, K, M) &&
                     operand_fast(d_dz, N, true, M, N) && operand_fast(d_w, K, false, K, N);
-  const dim3 grid(static_cast<unsigned>(dw_t * splits + dx_t));
+  const int dw_blocks = (parts & 1) ? dw_t * splits : 0;
+  const dim3 grid(static_cast<unsigned>(dw_blocks + ((parts & 2) ? dx_t : 0)));
 #define DFM_LBWD(F, E)                                                                                            \
-  hipLaunchKernelGGL((linear_bwd_kernel<F, E>), grid, dim3(kThreads), 0, as_stream(stream), d_dz, d_x, d_w, d_g_w, \
-                     d_g_x, M, N, K, dw_tn, dw_t, splits, k_per_split, slabs, dw_counters, dx_tn, dbn, dfm_)
+  hipLaunchKernelGGL((linear_bwd_kernel<F, E>), grid, dim3(kThreads), 0, as_stream(stream), d_dz, d_x, d_w,        \
+                     d_g_x, M, N, K, dw_tn, dw_t, splits, dw_blocks, k_per_split, slabs, dx_tn, dbn, dfm_)
   const int epi = bn_below ? 1 : (fm ? 2 : 0);
   if (fast) {
     if (epi == 0) DFM_LBWD(true, 0); else if (epi == 1) DFM_LBWD(true, 1); else DFM_LBWD(true, 2);
@@ -675,6 +719,32 @@ extern "C" int dfm_linear_backward(const float* d_dz, int64_t batch, int out_fea
     if (epi == 0) DFM_LBWD(false, 0); else if (epi == 1) DFM_LBWD(false, 1); else DFM_LBWD(false, 2);
   }
 #undef DFM_LBWD
+  DFM_LAUNCH_CHECK();
+  return DFM_OK;
+}
+
+extern "C" int dfm_linear_backward_finish(const dfm_slab_ref* refs, int count, dfm_stream_t stream) {
+  DFM_REQUIRE(refs && count > 0 && count <= kMaxSlabRefs, "1..%d slab references", kMaxSlabRefs);
+  SlabRefs r = {};
+  int blocks = 0;
+  for (int i = 0; i < count; ++i) {
+    const dfm_slab_ref& h = refs[i];
+    DFM_REQUIRE(h.workspace && h.g_w && h.batch > 0 && h.batch < (1 << 30) && h.out_features > 0 && h.in_features > 0,
+                "incomplete dfm_slab_ref");
+    const int64_t elems = static_cast<int64_t>(h.out_features) * h.in_features;
+    DFM_REQUIRE(elems % 4 == 0 && aligned16(h.g_w) && aligned16(h.workspace), "d weight must be float4-addressable");
+    int splits, kps;
+    dw_split_plan(h.out_features, h.in_features, static_cast<int>(h.batch), &splits, &kps);
+    r.slabs[i] = static_cast<const float*>(h.workspace);
+    r.g[i] = h.g_w;
+    r.elems4[i] = static_cast<int>(elems / 4);
+    r.splits[i] = splits;
+    r.first_block[i] = blocks;
+    blocks += (r.elems4[i] + 255) / 256;
+  }
+  r.first_block[count] = blocks;
+  r.count = count;
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), r);
   DFM_LAUNCH_CHECK();
   return DFM_OK;
 }

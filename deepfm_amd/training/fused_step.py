@@ -66,7 +66,7 @@ class FusedDeepFMStep(RowSparseTrainStep):
         self.logits = torch.empty(B, **f32)
         self.g_logits = torch.empty(B, 1, **f32)
         self.lin, self.bn, self.drop_p = [], [], []
-        self.z, self.a, self.stats, self.means, self.dy = [], [], [], [], []
+        self.z, self.a, self.stats, self.dy = [], [], [], []
         self.ws_fwd, self.ws_bn, self.ws_lin = [], [], []
         for i in range(self.L):
             lin, bn, _, drop = (dnn.mlp[4 * i + j] for j in range(4))
@@ -76,11 +76,9 @@ class FusedDeepFMStep(RowSparseTrainStep):
             self.a.append(torch.empty(B, n, **f32))
             self.dy.append(torch.empty(B, n, **f32))
             self.stats.append(torch.empty(2, n, **f32))
-            self.means.append(torch.empty(2, n, **f32))
             self.ws_fwd.append(_zeros_bytes(lib.dfm_linear_bn_workspace_bytes(B, n), dev))
             self.ws_bn.append(_zeros_bytes(lib.dfm_bn_bwd_workspace_bytes(B, n), dev))
             self.ws_lin.append(_zeros_bytes(lib.dfm_linear_backward_workspace_bytes(B, n, k), dev))
-        self.ws_head = _zeros_bytes(lib.dfm_head_bce_workspace_bytes(B, self.lin[-1].out_features), dev)
         self.seed = torch.randint(1, 2 ** 40, (1,), dtype=torch.int64, device=dev)
         for p in list(dnn.parameters()) + list(model.output_linear.parameters()):
             if p.grad is None or not p.grad.is_contiguous():
@@ -95,7 +93,7 @@ class FusedDeepFMStep(RowSparseTrainStep):
         c = _lib.BnBwd()
         c.z, c.mean_rstd = self.z[i].data_ptr(), self.stats[i].data_ptr()
         c.gamma, c.beta = bn.weight.data_ptr(), bn.bias.data_ptr()
-        c.dy, c.means = self.dy[i].data_ptr(), self.means[i].data_ptr()
+        c.dy = self.dy[i].data_ptr()
         c.g_gamma, c.g_beta = bn.weight.grad.data_ptr(), bn.bias.grad.data_ptr()
         c.seed = self.seed.data_ptr()
         c.workspace = self.ws_bn[i].data_ptr()
@@ -118,42 +116,49 @@ class FusedDeepFMStep(RowSparseTrainStep):
             track = bn.track_running_stats and bn.running_mean is not None
             _lib.check(lib.dfm_linear_bn_forward(
                 x.data_ptr(), k, lin.weight.data_ptr(), _lib.ptr(lin.bias), B, n, k, self.z[i].data_ptr(),
+                self.ws_fwd[i].data_ptr(), st))
+            _lib.check(lib.dfm_bn_relu_dropout_apply(
+                self.z[i].data_ptr(), B, n, self.ws_fwd[i].data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(),
                 self.stats[i].data_ptr(), bn.running_mean.data_ptr() if track else None,
                 bn.running_var.data_ptr() if track else None, bn.num_batches_tracked.data_ptr() if track else None,
-                float(bn.momentum), float(bn.eps), self.ws_fwd[i].data_ptr(), st))
-            _lib.check(lib.dfm_bn_relu_dropout_apply(
-                self.z[i].data_ptr(), B, n, self.stats[i].data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(),
-                self.drop_p[i], self.seed.data_ptr(), i, self.a[i].data_ptr(), st))
+                float(bn.momentum), float(bn.eps), self.drop_p[i], self.seed.data_ptr(), i, self.a[i].data_ptr(), st))
             x = self.a[i]
-        # ---- head: logits, loss, d logits, head gradients, mask of the last BatchNorm ----
+        # ---- head: logits, d logits, mask of the last BatchNorm (loss + head gradients: next launch) ----
         head = self.model.output_linear
-        top = self._bn_ctx(self.L - 1)
+        ctx = self._bn_ctx(self.L - 1)
         _lib.check(lib.dfm_head_bce(
             x.data_ptr(), B, head.in_features, head.weight.data_ptr(), _lib.ptr(head.bias), self.fo.data_ptr(),
-            self.fm.data_ptr(), self.labels.data_ptr(), self.logits.data_ptr(), self.loss.data_ptr(),
-            self.g_logits.data_ptr(), head.weight.grad.data_ptr(),
-            head.bias.grad.data_ptr() if head.bias is not None else None, None, C.byref(top),
-            self.ws_head.data_ptr(), st))
+            self.fm.data_ptr(), self.labels.data_ptr(), self.logits.data_ptr(), self.g_logits.data_ptr(),
+            C.byref(ctx), st))
+        tail = _lib.HeadTail()
+        tail.g_w = head.weight.grad.data_ptr()
+        tail.g_b = head.bias.grad.data_ptr() if head.bias is not None else None
+        tail.loss = self.loss.data_ptr()
         # ---- backward, top layer first ----
         for i in range(self.L - 1, -1, -1):
-            lin, bn = self.lin[i], self.bn[i]
+            lin = self.lin[i]
             n, k = lin.out_features, lin.in_features
-            _lib.check(lib.dfm_bn_backward_apply(
-                self.dy[i].data_ptr(), self.z[i].data_ptr(), self.stats[i].data_ptr(), bn.weight.data_ptr(),
-                self.means[i].data_ptr(), B, n, self.dy[i].data_ptr(), st))
+            _lib.check(lib.dfm_bn_backward_apply(C.byref(ctx), B, n, C.byref(tail) if i == self.L - 1 else None,
+                                                 self.dy[i].data_ptr(), st))
             xin = self.a[i - 1] if i > 0 else self.x0
             if i > 0:
-                below = self._bn_ctx(i - 1)
+                ctx = self._bn_ctx(i - 1)
                 _lib.check(lib.dfm_linear_backward(
-                    self.dy[i].data_ptr(), B, n, xin.data_ptr(), k, lin.weight.data_ptr(),
-                    lin.weight.grad.data_ptr(), None, C.byref(below), None, self.ws_lin[i].data_ptr(), st))
+                    self.dy[i].data_ptr(), B, n, xin.data_ptr(), k, lin.weight.data_ptr(), None, C.byref(ctx),
+                    None, 3, self.ws_lin[i].data_ptr(), st))
             else:
                 fmb = _lib.FmBwd()
                 fmb.g_fm, fmb.fm_sum, fmb.e = self.g_logits.data_ptr(), self.fm_sum.data_ptr(), self.x0.data_ptr()
                 fmb.dim = self.fe.shape[2]
                 _lib.check(lib.dfm_linear_backward(
-                    self.dy[i].data_ptr(), B, n, xin.data_ptr(), k, lin.weight.data_ptr(),
-                    lin.weight.grad.data_ptr(), self.g_fe.data_ptr(), None, C.byref(fmb),
-                    self.ws_lin[i].data_ptr(), st))
+                    self.dy[i].data_ptr(), B, n, xin.data_ptr(), k, lin.weight.data_ptr(), self.g_fe.data_ptr(),
+                    None, C.byref(fmb), 3, self.ws_lin[i].data_ptr(), st))
+        # the batch-split d weight products of all layers -> the flat gradient buffer, one launch
+        refs = (_lib.SlabRef * self.L)()
+        for i in range(self.L):
+            r, lin = refs[i], self.lin[i]
+            r.workspace, r.g_w = self.ws_lin[i].data_ptr(), lin.weight.grad.data_ptr()
+            r.batch, r.out_features, r.in_features = B, lin.out_features, lin.in_features
+        _lib.check(lib.dfm_linear_backward_finish(refs, self.L, st))
         cur.wait_stream(self.side)
         self.emb.backward_rowsparse(self.inputs, self.g_logits, self.g_fe, self.dense_grads)

@@ -309,24 +309,26 @@ int dfm_bce_with_logits(const float* d_logits, const float* d_labels, int64_t n,
 /* ---------------------------------------------------------------------------------
  * Fused DNN tower + head of the training step (reference dnn.py:45-55 [Linear -> BatchNorm1d ->
  * ReLU -> Dropout] * n; deepfm.py:30-42 first_order + fm + output_linear(dnn); trainer.py:59,221
- * BCEWithLogitsLoss).  Few launches instead of many (csrc/tower.hip):
- *   forward, per layer : dfm_linear_bn_forward (GEMM + batch statistics), dfm_bn_relu_dropout_apply
- *   head               : dfm_head_bce (logits, loss, d logits, head gradients, last BN's mask)
- *   backward, per layer: dfm_bn_backward_apply, dfm_linear_backward (dW and dx in one launch; the
- *                        dx epilogue is the lower layer's BatchNorm mask or the FM backward)
- * Workspaces must be zero-filled once after allocation; the kernels leave their counters at zero.
- * All reductions have a fixed order (no floating-point atomics).
+ * BCEWithLogitsLoss).  Few launches, none with a serial tail (csrc/tower.hip):
+ *   forward, per layer : dfm_linear_bn_forward (GEMM + per-tile column statistics),
+ *                        dfm_bn_relu_dropout_apply (merges the statistics, then normalises)
+ *   head               : dfm_head_bce (logits, d logits, the last BN's mask, partial sums)
+ *   backward, per layer: dfm_bn_backward_apply (merges the partial sums, then dz),
+ *                        dfm_linear_backward (dW and dx in one launch; the dx epilogue is the lower
+ *                        layer's BatchNorm mask or the FM backward)
+ * All reductions have a fixed order (no floating-point atomics, no arrival counters).
  * ------------------------------------------------------------------------------- */
 
-/* BatchNorm -> ReLU -> Dropout backward, first half: dy = g * [y > 0] * dropout mask/(1-p) with
- * y = gamma*(z-mean)*rstd + beta, its column means, and the affine gradients. */
+/* One BatchNorm -> ReLU -> Dropout block as the backward sees it.  Producer (dfm_head_bce or
+ * dfm_linear_backward's bn_below): dy = g * [y > 0] * dropout mask/(1-p), y = gamma*(z-mean)*rstd
+ * + beta, plus partial column sums of dy and dy*xhat in `workspace`.  Consumer
+ * (dfm_bn_backward_apply): merges them, adds the affine gradients, writes dz. */
 typedef struct dfm_bn_bwd {
   const float* z;          /* (batch, features) pre-activations saved by the forward */
-  const float* mean_rstd;  /* (2, features) batch mean, 1/sqrt(var+eps) */
+  const float* mean_rstd;  /* (2, features) batch mean, 1/sqrt(var+eps) from dfm_bn_relu_dropout_apply */
   const float* gamma;      /* (features) BatchNorm weight */
   const float* beta;       /* (features) BatchNorm bias */
-  float* dy;               /* out (batch, features) */
-  float* means;            /* out (2, features): mean(dy), mean(dy * xhat) */
+  float* dy;               /* (batch, features) masked upstream gradient */
   float* g_gamma;          /* (features), ADDED: sum dy * xhat */
   float* g_beta;           /* (features), ADDED: sum dy */
   const int64_t* seed;     /* device dropout seed (NULL when p_drop == 0) */
@@ -343,41 +345,64 @@ typedef struct dfm_fm_bwd {
   int32_t dim;
 } dfm_fm_bwd;
 
+/* What dfm_head_bce leaves for the dfm_bn_backward_apply that follows it to finish. */
+typedef struct dfm_head_tail {
+  float* g_w;              /* (features) head weight gradient, ADDED */
+  float* g_b;              /* (1) head bias gradient, ADDED (may be NULL) */
+  float* loss;             /* (1) mean BCE-with-logits, written */
+} dfm_head_tail;
+
 size_t dfm_linear_bn_workspace_bytes(int64_t batch, int features);
-/* z (batch, out) = x W^T + b; d_mean_rstd (2, out) = batch mean and 1/sqrt(biased var + eps);
- * running_mean / running_var / num_batches_tracked updated like nn.BatchNorm1d when non-NULL. */
+/* z (batch, out) = x W^T + b; per-column (mean, M2) of every 32-row tile go to d_workspace for
+ * dfm_bn_relu_dropout_apply. */
 int dfm_linear_bn_forward(const float* d_x, int64_t ldx, const float* d_w, const float* d_bias,
                           int64_t batch, int out_features, int in_features, float* d_z,
-                          float* d_mean_rstd, float* d_running_mean, float* d_running_var,
-                          int64_t* d_num_batches, float momentum, float eps, void* d_workspace,
-                          dfm_stream_t stream);
-/* out = dropout_p(relu(gamma * (z - mean) * rstd + beta)); features % 4 == 0. */
-int dfm_bn_relu_dropout_apply(const float* d_z, int64_t batch, int features, const float* d_mean_rstd,
-                              const float* d_gamma, const float* d_beta, float p_drop,
-                              const int64_t* d_seed, int salt, float* d_out, dfm_stream_t stream);
+                          void* d_workspace, dfm_stream_t stream);
+/* Batch statistics from dfm_linear_bn_forward's workspace -> d_mean_rstd (2, features) = mean and
+ * 1/sqrt(biased var + eps); running_mean / running_var / num_batches_tracked updated like
+ * nn.BatchNorm1d when non-NULL; out = dropout_p(relu(gamma * (z - mean) * rstd + beta)).
+ * features % 4 == 0. */
+int dfm_bn_relu_dropout_apply(const float* d_z, int64_t batch, int features, const void* d_workspace,
+                              const float* d_gamma, const float* d_beta, float* d_mean_rstd,
+                              float* d_running_mean, float* d_running_var, int64_t* d_num_batches,
+                              float momentum, float eps, float p_drop, const int64_t* d_seed, int salt,
+                              float* d_out, dfm_stream_t stream);
 size_t dfm_bn_bwd_workspace_bytes(int64_t batch, int features);
-/* dz = gamma * rstd * (dy - mean(dy) - xhat * mean(dy * xhat)); d_dz may alias d_dy. */
-int dfm_bn_backward_apply(const float* d_dy, const float* d_z, const float* d_mean_rstd,
-                          const float* d_gamma, const float* d_means, int64_t batch, int features,
-                          float* d_dz, dfm_stream_t stream);
-size_t dfm_head_bce_workspace_bytes(int64_t batch, int features);
 /* logits = (first_order + fm) + (a w^T + b)   (NULL first_order / fm / b count as 0);
- * *d_loss = mean BCE-with-logits; d_g_logits = (sigmoid - y) / batch; d_g_w (features) and d_g_b (1)
- * are ADDED; the gradient w.r.t. a goes through `bn` (the BatchNorm block that produced a) when
- * given, else it is written to d_g_a (batch, features).  features % 32 == 0, <= 256. */
+ * d_g_logits = (sigmoid - y) / batch; the gradient w.r.t. a goes through `bn` (the BatchNorm block
+ * that produced a): bn->dy and partial sums in bn->workspace.  The loss and the head's own
+ * gradients are finished by dfm_bn_backward_apply(bn, ..., head).  features % 32 == 0, <= 256. */
 int dfm_head_bce(const float* d_a, int64_t batch, int features, const float* d_w, const float* d_b,
                  const float* d_first_order, const float* d_fm, const float* d_labels, float* d_logits,
-                 float* d_loss, float* d_g_logits, float* d_g_w, float* d_g_b, float* d_g_a,
-                 const dfm_bn_bwd* bn, void* d_workspace, dfm_stream_t stream);
+                 float* d_g_logits, const dfm_bn_bwd* bn, dfm_stream_t stream);
+/* dz = gamma * rstd * (dy - mean(dy) - xhat * mean(dy * xhat)), d gamma / d beta ADDED; d_dz may be
+ * bn->dy.  `head` non-NULL iff bn was filled by dfm_head_bce (it then also receives the loss and
+ * the head gradients). */
+int dfm_bn_backward_apply(const dfm_bn_bwd* bn, int64_t batch, int features, const dfm_head_tail* head,
+                          float* d_dz, dfm_stream_t stream);
 size_t dfm_linear_backward_workspace_bytes(int64_t batch, int out_features, int in_features);
-/* Backward of z = x W^T + b given dz (batch, out): d_g_w (out, in) += dz^T x, and the gradient
+/* Backward of z = x W^T + b given dz (batch, out): the d weight product dz^T x, split over the
+ * batch into partial products left in d_workspace (dfm_linear_backward_finish adds them into the
+ * gradient buffers of all layers in one launch), and the gradient
  * w.r.t. x (batch, in) either stored to d_g_x (plus the FM backward when `fm` is given), or pushed
  * through the BatchNorm block that produced x (`bn_below`; d_g_x unused).  The bias gradient is
- * not computed: in front of a training-mode BatchNorm it is identically zero. */
+ * not computed: in front of a training-mode BatchNorm it is identically zero.
+ * parts: 1 = d weight only, 2 = d input only, 3 = both in one launch.  The two halves are
+ * independent given dz, so a caller may put the d weight half on a side stream: only d input is on
+ * the backward's critical path. */
 int dfm_linear_backward(const float* d_dz, int64_t batch, int out_features, const float* d_x,
-                        int in_features, const float* d_w, float* d_g_w, float* d_g_x,
-                        const dfm_bn_bwd* bn_below, const dfm_fm_bwd* fm, void* d_workspace,
+                        int in_features, const float* d_w, float* d_g_x,
+                        const dfm_bn_bwd* bn_below, const dfm_fm_bwd* fm, int parts, void* d_workspace,
                         dfm_stream_t stream);
+/* d_g_w (out, in) += sum of the batch-split partial products of one dfm_linear_backward call. */
+typedef struct dfm_slab_ref {
+  const void* workspace;   /* the d_workspace that call was given */
+  float* g_w;              /* (out, in) gradient buffer, ADDED */
+  int64_t batch;
+  int32_t out_features;
+  int32_t in_features;
+} dfm_slab_ref;
+int dfm_linear_backward_finish(const dfm_slab_ref* refs, int count, dfm_stream_t stream);
 
 /* ---------------------------------------------------------------------------------
  * Exact-fp32 GEMM on the matrix cores (v_mfma_f32_32x32x2_f32) for the DNN tower's Linear
