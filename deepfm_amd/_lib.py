@@ -90,8 +90,8 @@ SIGNATURES = {
     "dfm_rowadam_apply": (_I, [C.POINTER(Table), _I, _I, _I, _P, _P, _P, _P, _P, _P, _F, _F, _F, _F, _P, _P]),
     "dfm_dense_num_partials": (_L, [_L]),
     "dfm_dense_grad_prepare": (_I, [_P, _P, _L, _L, _F, _P, _P]),
-    "dfm_grad_norm_finalize": (_I, [_P, _L, _F, _P, _P, _P]),
-    "dfm_dense_adam": (_I, [_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _P, _P]),
+    "dfm_grad_norm_finalize": (_I, [_P, _L, _F, _P, _P, _P, _P, _P]),
+    "dfm_dense_adam": (_I, [_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _P, _I, _P]),
     "dfm_cin_output_dim": (_I, [C.POINTER(C.c_int32), _I, _I]),
     "dfm_cin_saved_bytes": (_SZ, [C.POINTER(C.c_int32), _I, _I, _L, _I, _I]),
     "dfm_cin_backward_workspace_bytes": (_SZ, [C.POINTER(C.c_int32), _I, _I, _L, _I, _I]),

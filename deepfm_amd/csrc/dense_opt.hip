@@ -42,7 +42,9 @@ __global__ __launch_bounds__(kPrepBlock) void dense_prepare_kernel(
 
 __global__ __launch_bounds__(1024) void norm_finalize_kernel(const float* __restrict__ partial, int n,
                                                              float max_norm, float* __restrict__ sq_out,
-                                                             float* __restrict__ clip_out) {
+                                                             float* __restrict__ clip_out,
+                                                             int32_t* __restrict__ step_tick,
+                                                             int64_t* __restrict__ seed_tick) {
   __shared__ float wsum[16];
   float acc = 0.f;
   for (int i = threadIdx.x; i < n; i += 1024) acc += partial[i];
@@ -59,6 +61,10 @@ __global__ __launch_bounds__(1024) void norm_finalize_kernel(const float* __rest
       if (max_norm > 0.f) c = fminf(1.f, max_norm / (sqrtf(tot) + 1e-6f));
       clip_out[0] = c;
     }
+    // the step's single-workgroup kernel doubles as its clock: Adam's step count (read by the
+    // update kernels that follow) and the dropout seed (read by the next step) advance here
+    if (step_tick) step_tick[0] += 1;
+    if (seed_tick) seed_tick[0] += 1;
   }
 }
 
@@ -66,7 +72,7 @@ __global__ __launch_bounds__(256) void dense_adam_kernel(float* __restrict__ p, 
                                                          float* __restrict__ v, const float* __restrict__ g,
                                                          int64_t n, const float* __restrict__ clip_coef,
                                                          float lr, float b1, float b2, float eps,
-                                                         const int32_t* __restrict__ step_ptr) {
+                                                         const int32_t* __restrict__ step_ptr, float* __restrict__ g_zero) {
   const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
   if (i >= n) return;
   const float clip = clip_coef ? clip_coef[0] : 1.f;
@@ -79,6 +85,7 @@ __global__ __launch_bounds__(256) void dense_adam_kernel(float* __restrict__ p, 
   m[i] = mi;
   v[i] = vi;
   p[i] -= step_size * (mi / (sqrtf(vi) * inv_bc2_sqrt + eps));
+  if (g_zero) g_zero[i] = 0.f;       // the gradient buffer is ready for the next step's accumulation
 }
 
 extern "C" int64_t dfm_dense_num_partials(int64_t n) { return n > 0 ? prep_blocks(n) : 0; }
@@ -95,23 +102,25 @@ extern "C" int dfm_dense_grad_prepare(float* d_g, const float* d_p, int64_t n, i
 }
 
 extern "C" int dfm_grad_norm_finalize(const float* d_partials, int64_t num_partials, float max_norm,
-                                      float* d_sq_norm, float* d_clip_coef, dfm_stream_t stream) {
+                                      float* d_sq_norm, float* d_clip_coef, int32_t* d_step_tick,
+                                      int64_t* d_seed_tick, dfm_stream_t stream) {
   DFM_REQUIRE(d_partials && d_sq_norm, "null argument");
   DFM_REQUIRE(num_partials >= 0 && num_partials < (int64_t(1) << 31), "bad partial count");
   hipLaunchKernelGGL(norm_finalize_kernel, dim3(1), dim3(1024), 0, as_stream(stream), d_partials,
-                     static_cast<int>(num_partials), max_norm, d_sq_norm, d_clip_coef);
+                     static_cast<int>(num_partials), max_norm, d_sq_norm, d_clip_coef, d_step_tick, d_seed_tick);
   DFM_LAUNCH_CHECK();
   return DFM_OK;
 }
 
-extern "C" int dfm_dense_adam(float* d_p, float* d_m, float* d_v, const float* d_g, int64_t n,
+extern "C" int dfm_dense_adam(float* d_p, float* d_m, float* d_v, float* d_g, int64_t n,
                               const float* d_clip_coef, float lr, float beta1, float beta2, float eps,
-                              const int32_t* d_step, dfm_stream_t stream) {
+                              const int32_t* d_step, int zero_grad, dfm_stream_t stream) {
   DFM_REQUIRE(n >= 0, "bad size");
   if (n == 0) return DFM_OK;
   DFM_REQUIRE(d_p && d_m && d_v && d_g && d_step, "null argument");
   hipLaunchKernelGGL(dense_adam_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0,
-                     as_stream(stream), d_p, d_m, d_v, d_g, n, d_clip_coef, lr, beta1, beta2, eps, d_step);
+                     as_stream(stream), d_p, d_m, d_v, d_g, n, d_clip_coef, lr, beta1, beta2, eps, d_step,
+                     zero_grad ? d_g : static_cast<float*>(nullptr));
   DFM_LAUNCH_CHECK();
   return DFM_OK;
 }

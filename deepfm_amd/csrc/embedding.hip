@@ -409,6 +409,47 @@ __global__ __launch_bounds__(256) void emb_bwd_dense_fields(
   }
 }
 
+// Uniform plans (dim == fm_dim, no projection, g_flat folded into g_field): block (i, jq) sums 4
+// columns of field i's gradient with 16-byte loads — the 4 column groups of a field walk the same
+// 64-byte segments, so the second to fourth hit L2 — instead of one 4-byte load per line and column.
+// jq == dim/4 handles the first-order Linear(1,1).
+__global__ __launch_bounds__(256) void emb_bwd_dense_fields_uniform(
+    const int32_t* __restrict__ dense_list, PtrTable in, GradTable gt, int64_t B, int F, int D,
+    const float* __restrict__ g_first, const float* __restrict__ g_field) {
+  const int f = dense_list[blockIdx.x];
+  const int jq = blockIdx.y;
+  const float* x = static_cast<const float*>(in.p[f]);
+  float sw[4] = {0.f, 0.f, 0.f, 0.f}, sb[4] = {0.f, 0.f, 0.f, 0.f};
+  if (jq * 4 < D) {
+    const float* g = g_field + static_cast<int64_t>(f) * D + jq * 4;
+#pragma unroll 4
+    for (int64_t b = threadIdx.x; b < B; b += 256) {
+      const float4 v = ld4(g + b * F * D);
+      const float xb = x[b];
+      sw[0] = fmaf(xb, v.x, sw[0]); sw[1] = fmaf(xb, v.y, sw[1]);
+      sw[2] = fmaf(xb, v.z, sw[2]); sw[3] = fmaf(xb, v.w, sw[3]);
+      sb[0] += v.x; sb[1] += v.y; sb[2] += v.z; sb[3] += v.w;
+    }
+  } else {
+    for (int64_t b = threadIdx.x; b < B; b += 256) {
+      const float v = g_first[b];
+      sw[0] = fmaf(x[b], v, sw[0]);
+      sb[0] += v;
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) block_sum2(sw[u], sb[u]);
+  if (threadIdx.x == 0) {
+    const dfm_field_grad g = gt.g[f];
+    if (jq * 4 < D) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { g.w2[jq * 4 + u] += sw[u]; g.b2[jq * 4 + u] += sb[u]; }
+    } else {
+      g.w1[0] += sw[0]; g.b1[0] += sb[0];
+    }
+  }
+}
+
 // Projection gradient dP[k,j] = sum_b g_field[b,f,k] * raw[b,j]; block (i, k*max_dim + j).
 __global__ __launch_bounds__(256) void emb_bwd_proj(
     const dfm_field* __restrict__ fields, const int32_t* __restrict__ proj_list, GradTable gt,
@@ -655,6 +696,12 @@ static int launch_dense_fields(const dfm_embedding_plan* plan, const PtrTable& i
                                const float* g_flat, hipStream_t st) {
   const int nd = static_cast<int>(plan->h_dense.size());
   if (nd == 0) return DFM_OK;
+  if (plan->uniform && g_flat == nullptr && (reinterpret_cast<uintptr_t>(g_field) & 15) == 0) {
+    hipLaunchKernelGGL(emb_bwd_dense_fields_uniform, dim3(nd, plan->fm_dim / 4 + 1), dim3(256), 0, st, plan->d_dense,
+                       in, gt, batch, plan->num_fields, plan->fm_dim, g_first, g_field);
+    DFM_LAUNCH_CHECK();
+    return DFM_OK;
+  }
   hipLaunchKernelGGL(emb_bwd_dense_fields, dim3(nd, plan->max_dim + 1), dim3(256), 0, st,
                      plan->d_fields, plan->d_dense, in, gt, batch, plan->num_fields, plan->fm_dim,
                      plan->total_dim, g_first, g_field, g_flat);

@@ -80,6 +80,7 @@ class FusedDeepFMStep(RowSparseTrainStep):
             self.ws_bn.append(_zeros_bytes(lib.dfm_bn_bwd_workspace_bytes(B, n), dev))
             self.ws_lin.append(_zeros_bytes(lib.dfm_linear_backward_workspace_bytes(B, n, k), dev))
         self.seed = torch.randint(1, 2 ** 40, (1,), dtype=torch.int64, device=dev)
+        optimizer.seed_tick = self.seed          # advanced by the optimizer's norm-finalize kernel
         for p in list(dnn.parameters()) + list(model.output_linear.parameters()):
             if p.grad is None or not p.grad.is_contiguous():
                 raise RuntimeError("FusedDeepFMStep needs RowSparseAdam's flat gradient views on every dense parameter")
@@ -107,7 +108,6 @@ class FusedDeepFMStep(RowSparseTrainStep):
         self.side.wait_stream(cur)
         with torch.cuda.stream(self.side):
             self.emb.build_rowplan(self.inputs, B)
-        self.seed.add_(1)
         # ---- forward ----
         x = self.x0
         for i in range(self.L):

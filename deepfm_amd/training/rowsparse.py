@@ -105,10 +105,15 @@ class RowSparseAdam:
         self._gathered = None
         self._partials = None
         self._cur = None
+        self.seed_tick: Optional[torch.Tensor] = None    # int64 device counter advanced once per apply()
 
     # ------------------------------------------------------------------ helpers
-    def zero_grad(self) -> None:
-        self.flat_grad.zero_()
+    def zero_grad(self, force: bool = False) -> None:
+        """``optimizer.zero_grad()`` (trainer.py:219).  The buffer starts zeroed and ``apply()``
+        leaves it zeroed (the Adam kernel clears what it consumed), so no fill is launched; pass
+        ``force=True`` to discard gradients accumulated by a backward pass that was not applied."""
+        if force:
+            self.flat_grad.zero_()
         if self.emb.rowsparse is not None:
             self.emb.rowsparse.has_grad = False
 
@@ -162,7 +167,6 @@ class RowSparseAdam:
         if self.world > 1:
             self.flat_grad.mul_(grad_scale)          # mean over ranks (loss is a per-rank mean)
         tabs = self._table_struct()
-        self.step_count.add_(1)
         _lib.check(lib.dfm_rowadam_merge(tabs, self.num_sparse, self.dim, lists, uniq.data_ptr(),
                                          num.data_ptr(), g2.data_ptr(), g1.data_ptr(),
                                          self._owner.data_ptr(), grad_scale, self.l2,
@@ -172,7 +176,8 @@ class RowSparseAdam:
                                               self._partials.data_ptr() + 4 * np_sparse, stream))
         _lib.check(lib.dfm_grad_norm_finalize(self._partials.data_ptr(), np_sparse + np_dense,
                                               self.max_grad_norm or 0.0, self.sq_norm.data_ptr(),
-                                              self.clip_coef.data_ptr(), stream))
+                                              self.clip_coef.data_ptr(), self.step_count.data_ptr(),
+                                              _lib.ptr(self.seed_tick), stream))
         _lib.check(lib.dfm_rowadam_apply(tabs, self.num_sparse, self.dim, lists, uniq.data_ptr(),
                                          num.data_ptr(), g2.data_ptr(), g1.data_ptr(),
                                          self._owner.data_ptr(), self.clip_coef.data_ptr(), self.lr,
@@ -181,7 +186,7 @@ class RowSparseAdam:
         _lib.check(lib.dfm_dense_adam(self.flat_param.data_ptr(), self.flat_m.data_ptr(),
                                       self.flat_v.data_ptr(), self.flat_grad.data_ptr(), n_dense,
                                       self.clip_coef.data_ptr(), self.lr, self.betas[0], self.betas[1],
-                                      self.eps, self.step_count.data_ptr(), stream))
+                                      self.eps, self.step_count.data_ptr(), 1, stream))
         self.emb.rowsparse.has_grad = False
 
     def step(self) -> None:

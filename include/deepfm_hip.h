@@ -189,13 +189,17 @@ int64_t dfm_dense_num_partials(int64_t n);
 int dfm_dense_grad_prepare(float* d_g, const float* d_p, int64_t n, int64_t n_l2, float l2,
                            float* d_partials, dfm_stream_t stream);
 /* *d_sq_norm = sum(partials) in a fixed order; *d_clip_coef = min(1, max_norm/(sqrt+1e-6))
- * (clip_grad_norm_, trainer.py:232-235; max_norm <= 0 disables clipping: coef 1). */
+ * (clip_grad_norm_, trainer.py:232-235; max_norm <= 0 disables clipping: coef 1).
+ * Optional "tick": *d_step_tick += 1 (Adam's step count, read by the update kernels enqueued after
+ * this call) and *d_seed_tick += 1 (dropout seed of the next step) — saves two launches. */
 int dfm_grad_norm_finalize(const float* d_partials, int64_t num_partials, float max_norm,
-                           float* d_sq_norm, float* d_clip_coef, dfm_stream_t stream);
-/* torch.optim.Adam (trainer.py:67-70) on flat buffers with g scaled by *d_clip_coef. */
-int dfm_dense_adam(float* d_p, float* d_m, float* d_v, const float* d_g, int64_t n,
+                           float* d_sq_norm, float* d_clip_coef, int32_t* d_step_tick,
+                           int64_t* d_seed_tick, dfm_stream_t stream);
+/* torch.optim.Adam (trainer.py:67-70) on flat buffers with g scaled by *d_clip_coef;
+ * zero_grad != 0 also clears d_g (optimizer.zero_grad() of the next step, trainer.py:219). */
+int dfm_dense_adam(float* d_p, float* d_m, float* d_v, float* d_g, int64_t n,
                    const float* d_clip_coef, float lr, float beta1, float beta2, float eps,
-                   const int32_t* d_step, dfm_stream_t stream);
+                   const int32_t* d_step, int zero_grad, dfm_stream_t stream);
 
 /* ---------------------------------------------------------------------------------
  * FMInteraction  (reference deepfm/models/layers/fm.py:18-23)
