@@ -159,14 +159,19 @@ def main():
         step.load_packed(records[i])                      # one D2D copy per step
         step.run(time_gather=timed)
 
+    import ctypes as C
+    from deepfm_amd import _lib
+    lib = _lib.load()
     for i in range(args.warmup):
         run(i, False)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    # every gather launch of the timed region carries HIP start/stop events around the dispatch
+    _lib.check(lib.dfm_gather_timing_begin(args.steps))
     t0 = time.perf_counter()
     for i in range(args.warmup, total):
-        run(i, True)
+        run(i, False)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -177,21 +182,11 @@ def main():
         elapsed = float(t.item())
     loss = float(step.loss.item())
 
-    # calibration, outside the timed region: the same event bracket around an EMPTY kernel
-    from deepfm_amd import _lib
-    lib = _lib.load()
-    empty_ms = []
-    for _ in range(30):
-        s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s0.record()
-        lib.dfm_debug_empty_launch(_lib.stream_handle())
-        s1.record()
-        empty_ms.append((s0, s1))
-    torch.cuda.synchronize()
-    empty_us = sum(a.elapsed_time(b) for a, b in empty_ms) / len(empty_ms) * 1e3
-
-    gather_ms = [s.elapsed_time(e) for s, e in (step.gather_events or [])]
-    gather_avg_s = (sum(gather_ms) / len(gather_ms)) * 1e-3 if gather_ms else float("nan")
+    us = (C.c_float * args.steps)()
+    n_timed = C.c_int(0)
+    _lib.check(lib.dfm_gather_timing_end(us, args.steps, C.byref(n_timed)))
+    gather_us = [float(us[i]) for i in range(n_timed.value)]
+    gather_avg_s = (sum(gather_us) / len(gather_us)) * 1e-6 if gather_us else float("nan")
     algo_bytes = gather_bytes_per_sample(n_sparse, n_dense, D) * B
     achieved = algo_bytes / gather_avg_s / 1e9
 
@@ -236,9 +231,10 @@ def main():
                 "traffic": pmc["traffic_bytes_per_launch"] if pmc else None,
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "avg_launch_us": gather_avg_s * 1e6,
-                "launches_timed": len(gather_ms),
-                "timer": "HIP events around each launch on the launch stream, inside the timed region",
-                "event_bracket_of_empty_kernel_us": empty_us,
+                "min_launch_us": min(gather_us) if gather_us else None,
+                "launches_timed": len(gather_us),
+                "timer": "HIP start/stop events attached to every gather dispatch of the timed region "
+                         "(hipExtLaunchKernelGGL, on the launch stream)",
                 "rocprof": pmc,
             },
         }

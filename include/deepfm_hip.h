@@ -105,6 +105,14 @@ int dfm_embedding_forward(const dfm_embedding_plan* plan, const void* const* inp
                           float* d_fm_out, float* d_fm_sum, void* d_workspace, int32_t* d_error_flag,
                           dfm_stream_t stream);
 
+/* Kernel-accurate timing of the uniform gather (measurement aid, bench.py): after
+ * dfm_gather_timing_begin(n) the next n dfm_embedding_forward launches of a uniform plan carry HIP
+ * start/stop events recorded around the dispatch itself (hipExtLaunchKernelGGL), on the stream the
+ * kernel is launched on; dfm_gather_timing_end synchronises them, writes up to `capacity` durations
+ * in microseconds to the HOST array h_us, the number written to *h_count, and disarms. */
+int dfm_gather_timing_begin(int launches);
+int dfm_gather_timing_end(float* h_us, int capacity, int* h_count);
+
 /* Autograd of the forward w.r.t. every parameter as DENSE gradients — the reference
  * semantics (nn.Embedding(sparse=False), embedding.py:35-40).  Gradients are ADDED
  * into the buffers of `grads` (caller zero-fills them); row 0 receives none.
