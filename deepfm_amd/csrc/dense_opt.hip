@@ -4,13 +4,13 @@
 //   prepare : g[i] += 2*l2*p[i] for i < n_l2 (the embedding parameters);  partial |g|^2
 //   finalize: total = sum(partials) in fixed order;  clip = min(1, max_norm/(sqrt(total)+1e-6))
 //   adam    : torch.optim.Adam update with g*clip
-#include "common.h"
+#include "tail_bodies.h"
 
 using namespace dfm;
 
 namespace {
 constexpr int kPrepBlock = 256;
-constexpr int kPrepPerThread = 16;  // elements per thread (4 x float4)
+constexpr int kPrepPerThread = tail::kPrepPerThread;  // elements per thread
 inline int64_t prep_blocks(int64_t n) {
   const int64_t per_block = static_cast<int64_t>(kPrepBlock) * kPrepPerThread;
   return (n + per_block - 1) / per_block;
@@ -20,24 +20,7 @@ inline int64_t prep_blocks(int64_t n) {
 __global__ __launch_bounds__(kPrepBlock) void dense_prepare_kernel(
     float* __restrict__ g, const float* __restrict__ p, int64_t n, int64_t n_l2, float l2,
     float* __restrict__ partial) {
-  const int64_t base = (static_cast<int64_t>(blockIdx.x) * kPrepBlock + threadIdx.x) * kPrepPerThread;
-  float sq = 0.f;
-  const float k = 2.f * l2;
-#pragma unroll 4
-  for (int j = 0; j < kPrepPerThread; ++j) {
-    const int64_t i = base + j;
-    if (i < n) {
-      float gi = g[i];
-      if (i < n_l2) { gi = fmaf(k, p[i], gi); g[i] = gi; }
-      sq = fmaf(gi, gi, sq);
-    }
-  }
-  __shared__ float wsum[kPrepBlock / kWave];
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) sq += __shfl_xor(sq, m, kWave);
-  if (lane_id() == 0) wsum[threadIdx.x >> 6] = sq;
-  __syncthreads();
-  if (threadIdx.x == 0) partial[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+  tail::dense_prepare_body(blockIdx.x, g, p, n, n_l2, l2, partial);
 }
 
 __global__ __launch_bounds__(1024) void norm_finalize_kernel(const float* __restrict__ partial, int n,
@@ -73,19 +56,7 @@ __global__ __launch_bounds__(256) void dense_adam_kernel(float* __restrict__ p, 
                                                          int64_t n, const float* __restrict__ clip_coef,
                                                          float lr, float b1, float b2, float eps,
                                                          const int32_t* __restrict__ step_ptr, float* __restrict__ g_zero) {
-  const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
-  if (i >= n) return;
-  const float clip = clip_coef ? clip_coef[0] : 1.f;
-  const float step = static_cast<float>(step_ptr[0]);
-  const float step_size = lr / (1.f - powf(b1, step));
-  const float inv_bc2_sqrt = 1.f / sqrtf(1.f - powf(b2, step));
-  const float gi = g[i] * clip;
-  const float mi = fmaf(b1, m[i], (1.f - b1) * gi);
-  const float vi = fmaf(b2, v[i], (1.f - b2) * gi * gi);
-  m[i] = mi;
-  v[i] = vi;
-  p[i] -= step_size * (mi / (sqrtf(vi) * inv_bc2_sqrt + eps));
-  if (g_zero) g_zero[i] = 0.f;       // the gradient buffer is ready for the next step's accumulation
+  tail::dense_adam_body(blockIdx.x, p, m, v, g, n, clip_coef, lr, b1, b2, eps, step_ptr, g_zero);
 }
 
 extern "C" int64_t dfm_dense_num_partials(int64_t n) { return n > 0 ? prep_blocks(n) : 0; }

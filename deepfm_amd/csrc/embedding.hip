@@ -11,7 +11,7 @@
 //     FM value are reduced across the block's waves through LDS in a fixed order.
 //   * emb_fwd_general — any schema (mixed dims, projections, SEQUENCE bags): one thread
 //     per (sample, field).  Correctness path for MovieLens-shaped schemas.
-#include "common.h"
+#include "tail_bodies.h"
 
 #include <hip/hip_ext.h>
 
@@ -370,20 +370,7 @@ __global__ void emb_bwd_scatter(const dfm_field* __restrict__ fields, PtrTable i
 }
 
 // Block-wide fixed-order sum of two values (256 threads).
-__device__ __forceinline__ void block_sum2(float& a, float& b2) {
-  __shared__ float sa[4], sb[4];
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) {
-    a += __shfl_xor(a, m, kWave);
-    b2 += __shfl_xor(b2, m, kWave);
-  }
-  const int w = threadIdx.x >> 6;
-  __syncthreads();
-  if (lane_id() == 0) { sa[w] = a; sb[w] = b2; }
-  __syncthreads();
-  a = sa[0] + sa[1] + sa[2] + sa[3];
-  b2 = sb[0] + sb[1] + sb[2] + sb[3];
-}
+using tail::block_sum2;
 
 // DENSE fields: dW2[j] = sum_b x_b * g_raw[b,j], db2[j] = sum_b g_raw[b,j]; block (i, j);
 // j == dim handles the first-order Linear(1,1).
@@ -418,38 +405,7 @@ __global__ __launch_bounds__(256) void emb_bwd_dense_fields(
 __global__ __launch_bounds__(256) void emb_bwd_dense_fields_uniform(
     const int32_t* __restrict__ dense_list, PtrTable in, GradTable gt, int64_t B, int F, int D,
     const float* __restrict__ g_first, const float* __restrict__ g_field) {
-  const int f = dense_list[blockIdx.x];
-  const int jq = blockIdx.y;
-  const float* x = static_cast<const float*>(in.p[f]);
-  float sw[4] = {0.f, 0.f, 0.f, 0.f}, sb[4] = {0.f, 0.f, 0.f, 0.f};
-  if (jq * 4 < D) {
-    const float* g = g_field + static_cast<int64_t>(f) * D + jq * 4;
-#pragma unroll 4
-    for (int64_t b = threadIdx.x; b < B; b += 256) {
-      const float4 v = ld4(g + b * F * D);
-      const float xb = x[b];
-      sw[0] = fmaf(xb, v.x, sw[0]); sw[1] = fmaf(xb, v.y, sw[1]);
-      sw[2] = fmaf(xb, v.z, sw[2]); sw[3] = fmaf(xb, v.w, sw[3]);
-      sb[0] += v.x; sb[1] += v.y; sb[2] += v.z; sb[3] += v.w;
-    }
-  } else {
-    for (int64_t b = threadIdx.x; b < B; b += 256) {
-      const float v = g_first[b];
-      sw[0] = fmaf(x[b], v, sw[0]);
-      sb[0] += v;
-    }
-  }
-#pragma unroll
-  for (int u = 0; u < 4; ++u) block_sum2(sw[u], sb[u]);
-  if (threadIdx.x == 0) {
-    const dfm_field_grad g = gt.g[f];
-    if (jq * 4 < D) {
-#pragma unroll
-      for (int u = 0; u < 4; ++u) { g.w2[jq * 4 + u] += sw[u]; g.b2[jq * 4 + u] += sb[u]; }
-    } else {
-      g.w1[0] += sw[0]; g.b1[0] += sb[0];
-    }
-  }
+  tail::dense_fields_uniform_body(blockIdx.x, dense_list, in, gt, B, F, D, g_first, g_field);
 }
 
 // Projection gradient dP[k,j] = sum_b g_field[b,f,k] * raw[b,j]; block (i, k*max_dim + j).
@@ -719,7 +675,7 @@ static int launch_dense_fields(const dfm_embedding_plan* plan, const PtrTable& i
   const int nd = static_cast<int>(plan->h_dense.size());
   if (nd == 0) return DFM_OK;
   if (plan->uniform && g_flat == nullptr && (reinterpret_cast<uintptr_t>(g_field) & 15) == 0) {
-    hipLaunchKernelGGL(emb_bwd_dense_fields_uniform, dim3(nd, plan->fm_dim / 4 + 1), dim3(256), 0, st, plan->d_dense,
+    hipLaunchKernelGGL(emb_bwd_dense_fields_uniform, dim3(nd * (plan->fm_dim / 4 + 1)), dim3(256), 0, st, plan->d_dense,
                        in, gt, batch, plan->num_fields, plan->fm_dim, g_first, g_field);
     DFM_LAUNCH_CHECK();
     return DFM_OK;

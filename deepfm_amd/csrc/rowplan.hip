@@ -11,12 +11,12 @@
 //
 // rowgrad: D/4 lanes per distinct id add that id's contributions in sorted (= sample)
 // order and write one gradient row: plain 16-byte stores, bitwise reproducible.
-#include "common.h"
+#include "tail_bodies.h"
 
 using namespace dfm;
 
 namespace {
-constexpr int CH = DFM_ROWPLAN_CHUNK;  // 4096
+using tail::CH;
 constexpr int SORT_THREADS = 1024;
 constexpr int PER_THREAD = CH / SORT_THREADS;  // 4
 constexpr unsigned long long SENTINEL = ~0ull;
@@ -25,9 +25,7 @@ struct IdTable {
   const int64_t* p[DFM_MAX_FIELDS];
   int32_t vocab[DFM_MAX_FIELDS];
 };
-struct FieldMap {
-  int32_t f[DFM_MAX_FIELDS];
-};
+using tail::FieldMap;
 }  // namespace
 
 __global__ __launch_bounds__(SORT_THREADS) void rowplan_sort(
@@ -132,35 +130,12 @@ __global__ __launch_bounds__(SORT_THREADS) void rowplan_sort(
   }
 }
 
-// One row gradient per distinct id: sum of its contributions in sample order.
 __global__ __launch_bounds__(256) void rowgrad_kernel(
     FieldMap fmap, int S, int F, int D, int lists, const float* __restrict__ g_first,
     const float* __restrict__ g_field, const int32_t* __restrict__ sorted_pos,
     const int32_t* __restrict__ seg_start, const int32_t* __restrict__ num_uniq,
     float* __restrict__ row_g2, float* __restrict__ row_g1) {
-  const int lpr = D / 4;
-  const int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  const int q = static_cast<int>(t % lpr);
-  const int64_t entry = t / lpr;  // (list, u)
-  const int64_t list = entry / CH;
-  const int u = static_cast<int>(entry % CH);
-  if (list >= lists) return;
-  if (u >= num_uniq[list]) return;
-  const int s = static_cast<int>(list % S);
-  const int f = fmap.f[s];
-  const int32_t* seg = seg_start + list * (CH + 1);
-  const int32_t* pos = sorted_pos + list * CH;
-  const int p0 = seg[u], p1 = seg[u + 1];
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  float acc1 = 0.f;
-  for (int p = p0; p < p1; ++p) {
-    const int64_t b = pos[p];
-    const float4 g = ld4(g_field + (b * F + f) * D + q * 4);
-    acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
-    if (q == 0) acc1 += g_first[b];
-  }
-  st4(row_g2 + (list * CH + u) * D + q * 4, acc);
-  if (q == 0) row_g1[list * CH + u] = acc1;
+  tail::rowgrad_body(blockIdx.x, fmap, S, F, D, lists, g_first, g_field, sorted_pos, seg_start, num_uniq, row_g2, row_g1);
 }
 
 extern "C" {

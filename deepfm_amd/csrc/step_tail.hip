@@ -1,0 +1,251 @@
+// Grouped launches for the tail of the training step (reference trainer.py:224-237 + the embedding
+// backward of embedding.py:76-126): kernels that do not depend on each other share one dispatch,
+// because on an MI355X a dependent launch costs ~4.5 us whatever it does.
+//
+//   dfm_step_embedding_backward : [DENSE-field Linear gradients | one gradient row per distinct id]
+//   dfm_step_prepare            : [row lists: ownership merge + lazy L2 + |g|^2 |
+//                                  dense buffer: + batch-split d-weight slabs, + L2, |g|^2]
+//   (dfm_grad_norm_finalize     : clip coefficient, step / dropout-seed tick — one workgroup)
+//   dfm_step_apply              : [row-wise Adam on the owned rows | Adam on the dense buffer]
+//
+// The bodies are the ones of the stand-alone kernels (tail_bodies.h): identical arithmetic and
+// reduction order, so grouped and stand-alone launches give bit-identical results.
+#include "tail_bodies.h"
+
+using namespace dfm;
+using namespace dfm::tail;
+
+extern "C" int dfm_linear_backward_splits(int64_t batch, int out_features, int in_features);
+
+namespace {
+constexpr int kMaxSlabs = 16;
+struct SlabTable {
+  const float* slabs[kMaxSlabs];
+  float* g[kMaxSlabs];
+  int64_t elems[kMaxSlabs];
+  int splits[kMaxSlabs];
+  int count;
+};
+
+// dense_prepare_body with the batch-split d-weight products folded in, ONE float4 per thread (the
+// slab sums want many threads with few dependent loads each): parameters start on 64-byte
+// boundaries and weights have a multiple of 4 elements, so a float4 belongs to at most one
+// slab-backed weight; its slabs are added in order (8 loads in flight) before the L2 term.
+constexpr int kStepPrepPerThread = 4;
+__device__ __forceinline__ void dense_prepare_slabs_body(int blk, float* __restrict__ g, const float* __restrict__ p,
+                                                         int64_t n, int64_t n_l2, float l2, const SlabTable& st,
+                                                         float* __restrict__ partial) {
+  const int64_t i = (static_cast<int64_t>(blk) * kTailThreads + threadIdx.x) * kStepPrepPerThread;
+  float sq = 0.f;
+  const float k = 2.f * l2;
+  if (i + 3 < n) {
+    float4 gi = ld4(g + i);
+    bool dirty = false;
+    for (int r = 0; r < st.count; ++r) {
+      const int64_t off = (g + i) - st.g[r];
+      if (off >= 0 && off < st.elems[r]) {
+        const float* sl = st.slabs[r] + off;
+        const int64_t stride = st.elems[r];
+        const int splits = st.splits[r];
+        int q = 0;
+        for (; q + 8 <= splits; q += 8) {
+          float4 t[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) t[u] = ld4(sl + (q + u) * stride);
+#pragma unroll
+          for (int u = 0; u < 8; ++u) { gi.x += t[u].x; gi.y += t[u].y; gi.z += t[u].z; gi.w += t[u].w; }
+        }
+        for (; q < splits; ++q) {
+          const float4 t = ld4(sl + q * stride);
+          gi.x += t.x; gi.y += t.y; gi.z += t.z; gi.w += t.w;
+        }
+        dirty = true;
+      }
+    }
+    if (i < n_l2) {                          // n_l2 is a multiple of 16 (padded parameters)
+      const float4 pi = ld4(p + i);
+      gi.x = fmaf(k, pi.x, gi.x); gi.y = fmaf(k, pi.y, gi.y); gi.z = fmaf(k, pi.z, gi.z); gi.w = fmaf(k, pi.w, gi.w);
+      dirty = true;
+    }
+    if (dirty) st4(g + i, gi);
+    sq = fmaf(gi.x, gi.x, sq); sq = fmaf(gi.y, gi.y, sq); sq = fmaf(gi.z, gi.z, sq); sq = fmaf(gi.w, gi.w, sq);
+  } else {
+    for (int64_t e = i; e < n; ++e) {
+      float ge = g[e];
+      if (e < n_l2) { ge = fmaf(k, p[e], ge); g[e] = ge; }
+      sq = fmaf(ge, ge, sq);
+    }
+  }
+  block_partial(sq, partial, blk);
+}
+}  // namespace
+
+__global__ __launch_bounds__(kTailThreads) void step_embedding_backward_kernel(
+    int dense_blocks, const int32_t* __restrict__ dense_list, PtrTable in, GradTable gt, int64_t B, int F, int D,
+    const float* __restrict__ g_first, const float* __restrict__ g_field, FieldMap fmap, int S, int lists,
+    const int32_t* __restrict__ sorted_pos, const int32_t* __restrict__ seg_start,
+    const int32_t* __restrict__ num_uniq, float* __restrict__ row_g2, float* __restrict__ row_g1) {
+  const int blk = blockIdx.x;
+  if (blk < dense_blocks)
+    dense_fields_uniform_body(blk, dense_list, in, gt, B, F, D, g_first, g_field);
+  else
+    rowgrad_body(blk - dense_blocks, fmap, S, F, D, lists, g_first, g_field, sorted_pos, seg_start, num_uniq, row_g2,
+                 row_g1);
+}
+
+__global__ __launch_bounds__(kTailThreads) void step_prepare_kernel(
+    int merge_blocks, TableArgs tabs, int S, int D, int L, const int32_t* __restrict__ uniq_rows,
+    const int32_t* __restrict__ num_uniq, float* __restrict__ row_g2, float* __restrict__ row_g1,
+    int32_t* __restrict__ owner_flag, float grad_scale, float l2, float* __restrict__ g, const float* __restrict__ p,
+    int64_t n, int64_t n_l2, SlabTable slabs, float* __restrict__ partial) {
+  const int blk = blockIdx.x;
+  if (blk < merge_blocks)
+    rowadam_merge_body(blk, tabs, S, D, L, uniq_rows, num_uniq, row_g2, row_g1, owner_flag, grad_scale, l2, partial);
+  else
+    dense_prepare_slabs_body(blk - merge_blocks, g, p, n, n_l2, l2, slabs, partial + merge_blocks);
+}
+
+__global__ __launch_bounds__(kTailThreads) void step_apply_kernel(
+    int row_blocks, TableArgs tabs, int S, int D, int L, const int32_t* __restrict__ uniq_rows,
+    const int32_t* __restrict__ num_uniq, const float* __restrict__ row_g2, const float* __restrict__ row_g1,
+    const int32_t* __restrict__ owner_flag, const float* __restrict__ clip_coef, float lr, float b1, float b2,
+    float eps, const int32_t* __restrict__ step_ptr, float* __restrict__ p, float* __restrict__ m,
+    float* __restrict__ v, float* __restrict__ g, int64_t n, int zero_grad) {
+  const int blk = blockIdx.x;
+  if (blk < row_blocks)
+    rowadam_apply_body(blk, tabs, S, D, L, uniq_rows, num_uniq, row_g2, row_g1, owner_flag, clip_coef, lr, b1, b2, eps,
+                       step_ptr);
+  else
+    dense_adam_body(blk - row_blocks, p, m, v, g, n, clip_coef, lr, b1, b2, eps, step_ptr, zero_grad ? g : nullptr);
+}
+
+namespace {
+int fill_tables(const dfm_table* tables, int S, int D, TableArgs* out, bool need_state) {
+  memset(out, 0, sizeof(*out));
+  for (int s = 0; s < S; ++s) {
+    DFM_REQUIRE(tables[s].w2 && tables[s].w1, "table %d: null weights", s);
+    if (need_state)
+      DFM_REQUIRE(tables[s].m2 && tables[s].v2 && tables[s].m1 && tables[s].v1, "table %d: null Adam state", s);
+    out->t[s] = tables[s];
+    if (out->t[s].stride2 == 0) out->t[s].stride2 = D;
+    if (out->t[s].stride1 == 0) out->t[s].stride1 = 1;
+    DFM_REQUIRE(out->t[s].stride2 >= D && out->t[s].stride2 % 4 == 0 && out->t[s].stride1 >= 1,
+                "table %d: bad row strides", s);
+  }
+  return DFM_OK;
+}
+inline int64_t row_blocks(int S, int D, int L) {
+  return (static_cast<int64_t>(L) * S * CH * (D / 4) + kTailThreads - 1) / kTailThreads;
+}
+inline int64_t prep_blocks(int64_t n) {
+  const int64_t per = static_cast<int64_t>(kTailThreads) * kStepPrepPerThread;
+  return (n + per - 1) / per;
+}
+}  // namespace
+
+extern "C" int dfm_step_embedding_backward(const int32_t* d_dense_list, int num_dense, const void* const* dense_x,
+                                           const dfm_field_grad* dense_grads, const int32_t* field_of_sparse,
+                                           int num_sparse, int num_fields, int dim, int64_t batch,
+                                           const float* d_g_first, const float* d_g_field,
+                                           const int32_t* d_sorted_pos, const int32_t* d_seg_start,
+                                           const int32_t* d_num_uniq, float* d_row_g2, float* d_row_g1,
+                                           dfm_stream_t stream) {
+  DFM_REQUIRE(d_g_first && d_g_field, "null argument");
+  DFM_REQUIRE(num_dense >= 0 && num_sparse >= 0 && num_dense + num_sparse > 0 && num_fields <= DFM_MAX_FIELDS &&
+                  num_dense + num_sparse <= num_fields, "bad field counts");
+  DFM_REQUIRE(dim > 0 && dim % 4 == 0 && batch > 0 && batch < (int64_t(1) << 31), "bad shape");
+  DFM_REQUIRE((reinterpret_cast<uintptr_t>(d_g_field) & 15) == 0, "d_g_field must be 16-byte aligned");
+  PtrTable in;
+  GradTable gt;
+  memset(&in, 0, sizeof(in));
+  memset(&gt, 0, sizeof(gt));
+  if (num_dense > 0) {
+    // dense_x / dense_grads are indexed by SCHEMA position (like dfm_embedding_forward's inputs);
+    // d_dense_list holds the schema positions of the DENSE fields on the device
+    DFM_REQUIRE(d_dense_list && dense_x && dense_grads, "null argument");
+    for (int f = 0; f < num_fields; ++f) {
+      in.p[f] = dense_x[f];
+      gt.g[f] = dense_grads[f];
+    }
+  }
+  FieldMap fm;
+  memset(&fm, 0, sizeof(fm));
+  int lists = 0;
+  int64_t rg_blocks = 0;
+  if (num_sparse > 0) {
+    DFM_REQUIRE(field_of_sparse && d_sorted_pos && d_seg_start && d_num_uniq && d_row_g2 && d_row_g1, "null argument");
+    for (int s = 0; s < num_sparse; ++s) {
+      DFM_REQUIRE(field_of_sparse[s] >= 0 && field_of_sparse[s] < num_fields, "field_of_sparse[%d] out of range", s);
+      fm.f[s] = field_of_sparse[s];
+    }
+    lists = static_cast<int>((batch + CH - 1) / CH) * num_sparse;
+    rg_blocks = (static_cast<int64_t>(lists) * CH * (dim / 4) + kTailThreads - 1) / kTailThreads;
+  }
+  const int dense_blocks = num_dense * (dim / 4 + 1);
+  hipLaunchKernelGGL(step_embedding_backward_kernel, dim3(static_cast<unsigned>(dense_blocks + rg_blocks)),
+                     dim3(kTailThreads), 0, as_stream(stream), dense_blocks, d_dense_list, in, gt, batch, num_fields, dim,
+                     d_g_first, d_g_field, fm, num_sparse, lists, d_sorted_pos, d_seg_start, d_num_uniq, d_row_g2,
+                     d_row_g1);
+  DFM_LAUNCH_CHECK();
+  return DFM_OK;
+}
+
+extern "C" int64_t dfm_step_prepare_num_partials(int num_sparse, int dim, int num_lists, int64_t n) {
+  return row_blocks(num_sparse, dim, num_lists) + prep_blocks(n);
+}
+
+extern "C" int dfm_step_prepare(const dfm_table* tables, int num_sparse, int dim, int num_lists,
+                                const int32_t* d_uniq_rows, const int32_t* d_num_uniq, float* d_row_g2,
+                                float* d_row_g1, int32_t* d_owner_flag, float grad_scale, float l2, float* d_g,
+                                const float* d_p, int64_t n, int64_t n_l2, const dfm_slab_ref* slabs, int num_slabs,
+                                float* d_partials, dfm_stream_t stream) {
+  DFM_REQUIRE(tables && d_uniq_rows && d_num_uniq && d_row_g2 && d_row_g1 && d_owner_flag && d_partials && d_g && d_p,
+              "null argument");
+  DFM_REQUIRE(num_sparse > 0 && num_sparse <= DFM_MAX_FIELDS && num_lists > 0, "bad sizes");
+  DFM_REQUIRE(dim > 0 && dim % 4 == 0 && dim <= 256, "dim must be a multiple of 4 and <= 256");
+  DFM_REQUIRE(n > 0 && n_l2 >= 0 && n_l2 <= n && n_l2 % 16 == 0, "bad dense sizes (n_l2 must be a multiple of 16)");
+  DFM_REQUIRE((reinterpret_cast<uintptr_t>(d_g) & 63) == 0 && (reinterpret_cast<uintptr_t>(d_p) & 15) == 0,
+              "dense buffers must be 64-byte aligned");
+  DFM_REQUIRE(num_slabs >= 0 && num_slabs <= kMaxSlabs && (num_slabs == 0 || slabs), "0..%d slab references", kMaxSlabs);
+  TableArgs ta;
+  if (int rc = fill_tables(tables, num_sparse, dim, &ta, false)) return rc;
+  SlabTable st = {};
+  for (int i = 0; i < num_slabs; ++i) {
+    const dfm_slab_ref& h = slabs[i];
+    DFM_REQUIRE(h.workspace && h.g_w && h.batch > 0 && h.out_features > 0 && h.in_features > 0, "incomplete dfm_slab_ref");
+    const int64_t elems = static_cast<int64_t>(h.out_features) * h.in_features;
+    DFM_REQUIRE(elems % 4 == 0 && (reinterpret_cast<uintptr_t>(h.workspace) & 15) == 0 && h.g_w >= d_g &&
+                    h.g_w + elems <= d_g + n && ((h.g_w - d_g) % 16) == 0,
+                "slab-backed weights must be 64-byte aligned views of the dense gradient buffer");
+    st.slabs[i] = static_cast<const float*>(h.workspace);
+    st.g[i] = h.g_w;
+    st.elems[i] = elems;
+    st.splits[i] = dfm_linear_backward_splits(h.batch, h.out_features, h.in_features);
+  }
+  st.count = num_slabs;
+  const int64_t mb = row_blocks(num_sparse, dim, num_lists), pb = prep_blocks(n);
+  hipLaunchKernelGGL(step_prepare_kernel, dim3(static_cast<unsigned>(mb + pb)), dim3(kTailThreads), 0,
+                     as_stream(stream), static_cast<int>(mb), ta, num_sparse, dim, num_lists, d_uniq_rows, d_num_uniq,
+                     d_row_g2, d_row_g1, d_owner_flag, grad_scale, l2, d_g, d_p, n, n_l2, st, d_partials);
+  DFM_LAUNCH_CHECK();
+  return DFM_OK;
+}
+
+extern "C" int dfm_step_apply(const dfm_table* tables, int num_sparse, int dim, int num_lists,
+                              const int32_t* d_uniq_rows, const int32_t* d_num_uniq, const float* d_row_g2,
+                              const float* d_row_g1, const int32_t* d_owner_flag, const float* d_clip_coef, float lr,
+                              float beta1, float beta2, float eps, const int32_t* d_step, float* d_p, float* d_m,
+                              float* d_v, float* d_g, int64_t n, int zero_grad, dfm_stream_t stream) {
+  DFM_REQUIRE(tables && d_uniq_rows && d_num_uniq && d_row_g2 && d_row_g1 && d_owner_flag && d_step && d_p && d_m &&
+                  d_v && d_g, "null argument");
+  DFM_REQUIRE(num_sparse > 0 && num_sparse <= DFM_MAX_FIELDS && num_lists > 0 && n > 0, "bad sizes");
+  DFM_REQUIRE(dim > 0 && dim % 4 == 0 && dim <= 256, "dim must be a multiple of 4 and <= 256");
+  TableArgs ta;
+  if (int rc = fill_tables(tables, num_sparse, dim, &ta, true)) return rc;
+  const int64_t rb = row_blocks(num_sparse, dim, num_lists), ab = (n + kTailThreads - 1) / kTailThreads;
+  hipLaunchKernelGGL(step_apply_kernel, dim3(static_cast<unsigned>(rb + ab)), dim3(kTailThreads), 0, as_stream(stream),
+                     static_cast<int>(rb), ta, num_sparse, dim, num_lists, d_uniq_rows, d_num_uniq, d_row_g2, d_row_g1,
+                     d_owner_flag, d_clip_coef, lr, beta1, beta2, eps, d_step, d_p, d_m, d_v, d_g, n, zero_grad);
+  DFM_LAUNCH_CHECK();
+  return DFM_OK;
+}

@@ -1,0 +1,266 @@
+// Device bodies of the training step's tail kernels (row gradients, DENSE-field gradients, row-wise
+// and dense Adam), shared by their stand-alone launches (rowplan.hip, embedding.hip, rowadam.hip,
+// dense_opt.hip) and by the grouped launches of step_tail.hip, where independent kernels of the step
+// share one dispatch (a dependent launch costs ~4.5 us on an MI355X whatever it does).
+// Every body is written for 256-thread workgroups and takes its logical workgroup index `blk`.
+#pragma once
+
+#include "common.h"
+
+namespace dfm {
+namespace tail {
+
+constexpr int CH = DFM_ROWPLAN_CHUNK;  // 4096
+constexpr int kTailThreads = 256;
+
+struct FieldMap {
+  int32_t f[DFM_MAX_FIELDS];
+};
+struct TableArgs {
+  dfm_table t[DFM_MAX_FIELDS];
+};
+
+// fixed-order sum of `sq` over the workgroup's 4 waves -> partial[blk]
+__device__ __forceinline__ void block_partial(float sq, float* __restrict__ partial, int blk) {
+  __shared__ float wsum[4];
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) sq += __shfl_xor(sq, m, kWave);
+  if (lane_id() == 0) wsum[threadIdx.x >> 6] = sq;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blk] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+}
+
+__device__ __forceinline__ void block_sum2(float& a, float& b2) {
+  __shared__ float sa[4], sb[4];
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    a += __shfl_xor(a, m, kWave);
+    b2 += __shfl_xor(b2, m, kWave);
+  }
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane_id() == 0) { sa[w] = a; sb[w] = b2; }
+  __syncthreads();
+  a = sa[0] + sa[1] + sa[2] + sa[3];
+  b2 = sb[0] + sb[1] + sb[2] + sb[3];
+}
+
+// DENSE fields of a uniform plan: workgroup (field i, column group jq) sums 4 columns of the field's
+// gradient over the batch with 16-byte loads; jq == D/4 handles the first-order Linear(1,1).
+__device__ __forceinline__ void dense_fields_uniform_body(int blk, const int32_t* __restrict__ dense_list, PtrTable in, GradTable gt, int64_t B, int F, int D, const float* __restrict__ g_first, const float* __restrict__ g_field) {
+  const int groups = D / 4 + 1;      // column groups per field (+ the first-order Linear)
+  const int f = dense_list[blk / groups];
+  const int jq = blk % groups;
+  const float* x = static_cast<const float*>(in.p[f]);
+  float sw[4] = {0.f, 0.f, 0.f, 0.f}, sb[4] = {0.f, 0.f, 0.f, 0.f};
+  if (jq * 4 < D) {
+    const float* g = g_field + static_cast<int64_t>(f) * D + jq * 4;
+#pragma unroll 4
+    for (int64_t b = threadIdx.x; b < B; b += 256) {
+      const float4 v = ld4(g + b * F * D);
+      const float xb = x[b];
+      sw[0] = fmaf(xb, v.x, sw[0]); sw[1] = fmaf(xb, v.y, sw[1]);
+      sw[2] = fmaf(xb, v.z, sw[2]); sw[3] = fmaf(xb, v.w, sw[3]);
+      sb[0] += v.x; sb[1] += v.y; sb[2] += v.z; sb[3] += v.w;
+    }
+  } else {
+    for (int64_t b = threadIdx.x; b < B; b += 256) {
+      const float v = g_first[b];
+      sw[0] = fmaf(x[b], v, sw[0]);
+      sb[0] += v;
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) block_sum2(sw[u], sb[u]);
+  if (threadIdx.x == 0) {
+    const dfm_field_grad g = gt.g[f];
+    if (jq * 4 < D) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { g.w2[jq * 4 + u] += sw[u]; g.b2[jq * 4 + u] += sb[u]; }
+    } else {
+      g.w1[0] += sw[0]; g.b1[0] += sb[0];
+    }
+  }
+}
+
+// One row gradient per distinct id: sum of its contributions in sample order.
+__device__ __forceinline__ void rowgrad_body(int blk, FieldMap fmap, int S, int F, int D, int lists, const float* __restrict__ g_first,
+    const float* __restrict__ g_field, const int32_t* __restrict__ sorted_pos,
+    const int32_t* __restrict__ seg_start, const int32_t* __restrict__ num_uniq,
+    float* __restrict__ row_g2, float* __restrict__ row_g1) {
+  const int lpr = D / 4;
+  const int64_t t = static_cast<int64_t>(blk) * kTailThreads + threadIdx.x;
+  const int q = static_cast<int>(t % lpr);
+  const int64_t entry = t / lpr;  // (list, u)
+  const int64_t list = entry / CH;
+  const int u = static_cast<int>(entry % CH);
+  if (list >= lists) return;
+  if (u >= num_uniq[list]) return;
+  const int s = static_cast<int>(list % S);
+  const int f = fmap.f[s];
+  const int32_t* seg = seg_start + list * (CH + 1);
+  const int32_t* pos = sorted_pos + list * CH;
+  const int p0 = seg[u], p1 = seg[u + 1];
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  float acc1 = 0.f;
+  for (int p = p0; p < p1; ++p) {
+    const int64_t b = pos[p];
+    const float4 g = ld4(g_field + (b * F + f) * D + q * 4);
+    acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
+    if (q == 0) acc1 += g_first[b];
+  }
+  st4(row_g2 + (list * CH + u) * D + q * 4, acc);
+  if (q == 0) row_g1[list * CH + u] = acc1;
+}
+
+__device__ __forceinline__ int find_row(const int32_t* __restrict__ rows, int n, int32_t row) {
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    const int32_t v = rows[mid];
+    if (v < row) lo = mid + 1; else hi = mid;
+  }
+  return (lo < n && rows[lo] == row) ? lo : -1;
+}
+
+// pass A of the row-wise Adam: ownership merge of the L lists, lazy L2, |g|^2 partial per workgroup
+__device__ __forceinline__ void rowadam_merge_body(int blk, TableArgs tabs, int S, int D, int L, const int32_t* __restrict__ uniq_rows,
+    const int32_t* __restrict__ num_uniq, float* __restrict__ row_g2, float* __restrict__ row_g1,
+    int32_t* __restrict__ owner_flag, float grad_scale, float l2, float* __restrict__ partial) {
+  const int lpr = D / 4;
+  const int64_t t = static_cast<int64_t>(blk) * kTailThreads + threadIdx.x;
+  const int q = static_cast<int>(t % lpr);
+  const int64_t entry = t / lpr;
+  const int64_t list = entry / CH;  // l * S + s
+  const int u = static_cast<int>(entry % CH);
+  float sq = 0.f;
+  if (list < static_cast<int64_t>(L) * S && u < num_uniq[list]) {
+    const int l = static_cast<int>(list / S), s = static_cast<int>(list % S);
+    const int32_t row = uniq_rows[list * CH + u];
+    bool owner = true;
+    for (int lp = 0; lp < l && owner; ++lp) {
+      const int64_t other = static_cast<int64_t>(lp) * S + s;
+      if (find_row(uniq_rows + other * CH, num_uniq[other], row) >= 0) owner = false;
+    }
+    if (q == 0) owner_flag[list * CH + u] = owner ? 1 : 0;
+    if (owner) {
+      float4 g = ld4(row_g2 + (list * CH + u) * D + q * 4);
+      float g1 = q == 0 ? row_g1[list * CH + u] : 0.f;
+      for (int ln = l + 1; ln < L; ++ln) {
+        const int64_t other = static_cast<int64_t>(ln) * S + s;
+        const int pos = find_row(uniq_rows + other * CH, num_uniq[other], row);
+        if (pos >= 0) {
+          const float4 o = ld4(row_g2 + (other * CH + pos) * D + q * 4);
+          g.x += o.x; g.y += o.y; g.z += o.z; g.w += o.w;
+          if (q == 0) g1 += row_g1[other * CH + pos];
+        }
+      }
+      const dfm_table tb = tabs.t[s];
+      const float4 w = ld4(tb.w2 + static_cast<int64_t>(row) * tb.stride2 + q * 4);
+      const float k = 2.f * l2;
+      g.x = fmaf(k, w.x, grad_scale * g.x); g.y = fmaf(k, w.y, grad_scale * g.y);
+      g.z = fmaf(k, w.z, grad_scale * g.z); g.w = fmaf(k, w.w, grad_scale * g.w);
+      st4(row_g2 + (list * CH + u) * D + q * 4, g);
+      sq = g.x * g.x + g.y * g.y + g.z * g.z + g.w * g.w;
+      if (q == 0) {
+        g1 = fmaf(k, tb.w1[static_cast<int64_t>(row) * tb.stride1], grad_scale * g1);
+        row_g1[list * CH + u] = g1;
+        sq = fmaf(g1, g1, sq);
+      }
+    }
+  }
+  block_partial(sq, partial, blk);
+}
+
+__device__ __forceinline__ void adam1(float& w, float& m, float& v, float g, float b1, float b2,
+                                      float step_size, float inv_bc2_sqrt, float eps) {
+  m = fmaf(b1, m, (1.f - b1) * g);
+  v = fmaf(b2, v, (1.f - b2) * g * g);
+  const float denom = sqrtf(v) * inv_bc2_sqrt + eps;
+  w -= step_size * (m / denom);
+}
+
+// pass B: Adam on the rows this list owns
+__device__ __forceinline__ void rowadam_apply_body(int blk, TableArgs tabs, int S, int D, int L, const int32_t* __restrict__ uniq_rows,
+    const int32_t* __restrict__ num_uniq, const float* __restrict__ row_g2,
+    const float* __restrict__ row_g1, const int32_t* __restrict__ owner_flag,
+    const float* __restrict__ clip_coef, float lr, float b1, float b2, float eps,
+    const int32_t* __restrict__ step_ptr) {
+  const int lpr = D / 4;
+  const int64_t t = static_cast<int64_t>(blk) * kTailThreads + threadIdx.x;
+  const int q = static_cast<int>(t % lpr);
+  const int64_t entry = t / lpr;
+  const int64_t list = entry / CH;
+  const int u = static_cast<int>(entry % CH);
+  if (list >= static_cast<int64_t>(L) * S || u >= num_uniq[list]) return;
+  if (!owner_flag[list * CH + u]) return;
+  const int s = static_cast<int>(list % S);
+  const int64_t row = uniq_rows[list * CH + u];
+  const float clip = clip_coef ? clip_coef[0] : 1.f;
+  const float step = static_cast<float>(step_ptr[0]);
+  const float bc1 = 1.f - powf(b1, step);
+  const float bc2 = 1.f - powf(b2, step);
+  const float step_size = lr / bc1;
+  const float inv_bc2_sqrt = 1.f / sqrtf(bc2);
+  const dfm_table tb = tabs.t[s];
+  float4 g = ld4(row_g2 + (list * CH + u) * D + q * 4);
+  const int64_t o2 = row * tb.stride2 + q * 4, o1 = row * tb.stride1;
+  float4 w = ld4(tb.w2 + o2);
+  float4 m = ld4(tb.m2 + o2);
+  float4 v = ld4(tb.v2 + o2);
+  adam1(w.x, m.x, v.x, g.x * clip, b1, b2, step_size, inv_bc2_sqrt, eps);
+  adam1(w.y, m.y, v.y, g.y * clip, b1, b2, step_size, inv_bc2_sqrt, eps);
+  adam1(w.z, m.z, v.z, g.z * clip, b1, b2, step_size, inv_bc2_sqrt, eps);
+  adam1(w.w, m.w, v.w, g.w * clip, b1, b2, step_size, inv_bc2_sqrt, eps);
+  st4(tb.w2 + o2, w);
+  st4(tb.m2 + o2, m);
+  st4(tb.v2 + o2, v);
+  if (q == 0) {
+    float w1 = tb.w1[o1], m1 = tb.m1[o1], v1 = tb.v1[o1];
+    adam1(w1, m1, v1, row_g1[list * CH + u] * clip, b1, b2, step_size, inv_bc2_sqrt, eps);
+    tb.w1[o1] = w1; tb.m1[o1] = m1; tb.v1[o1] = v1;
+  }
+}
+
+// dense parameters: g[i] += 2*l2*p[i] for i < n_l2; |g|^2 partial per workgroup (16 elements per thread)
+constexpr int kPrepPerThread = 16;
+__device__ __forceinline__ void dense_prepare_body(int blk, float* __restrict__ g, const float* __restrict__ p,
+                                                   int64_t n, int64_t n_l2, float l2, float* __restrict__ partial) {
+  const int64_t base = (static_cast<int64_t>(blk) * kTailThreads + threadIdx.x) * kPrepPerThread;
+  float sq = 0.f;
+  const float k = 2.f * l2;
+#pragma unroll 4
+  for (int j = 0; j < kPrepPerThread; ++j) {
+    const int64_t i = base + j;
+    if (i < n) {
+      float gi = g[i];
+      if (i < n_l2) { gi = fmaf(k, p[i], gi); g[i] = gi; }
+      sq = fmaf(gi, gi, sq);
+    }
+  }
+  block_partial(sq, partial, blk);
+}
+
+// torch.optim.Adam on one element per thread; g_zero != NULL also clears the gradient
+__device__ __forceinline__ void dense_adam_body(int blk, float* __restrict__ p, float* __restrict__ m,
+                                                float* __restrict__ v, const float* __restrict__ g, int64_t n,
+                                                const float* __restrict__ clip_coef, float lr, float b1, float b2,
+                                                float eps, const int32_t* __restrict__ step_ptr,
+                                                float* __restrict__ g_zero) {
+  const int64_t i = static_cast<int64_t>(blk) * kTailThreads + threadIdx.x;
+  if (i >= n) return;
+  const float clip = clip_coef ? clip_coef[0] : 1.f;
+  const float step = static_cast<float>(step_ptr[0]);
+  const float step_size = lr / (1.f - powf(b1, step));
+  const float inv_bc2_sqrt = 1.f / sqrtf(1.f - powf(b2, step));
+  const float gi = g[i] * clip;
+  const float mi = fmaf(b1, m[i], (1.f - b1) * gi);
+  const float vi = fmaf(b2, v[i], (1.f - b2) * gi * gi);
+  m[i] = mi;
+  v[i] = vi;
+  p[i] -= step_size * (mi / (sqrtf(vi) * inv_bc2_sqrt + eps));
+  if (g_zero) g_zero[i] = 0.f;       // the gradient buffer is ready for the next step's accumulation
+}
+
+}  // namespace tail
+}  // namespace dfm

@@ -678,6 +678,12 @@ void dw_split_plan(int n_out, int k_in, int m, int* splits, int* k_per_split) {
 }
 }  // namespace
 
+extern "C" int dfm_linear_backward_splits(int64_t batch, int out_features, int in_features) {
+  int splits, kps;
+  dw_split_plan(out_features, in_features, static_cast<int>(batch), &splits, &kps);
+  return splits;
+}
+
 extern "C" size_t dfm_linear_backward_workspace_bytes(int64_t batch, int out_features, int in_features) {
   const int s = dw_splits(out_features, in_features, batch);
   return align256(sizeof(float) * static_cast<size_t>(s) * out_features * in_features);

@@ -89,6 +89,7 @@ class FeatureEmbedding(nn.Module):
         self._plan_uniform = False
         self._err: Optional[torch.Tensor] = None
         self._anchor: Optional[torch.Tensor] = None
+        self._dense_list: Optional[torch.Tensor] = None
         self._sparse_pos = [i for i, s in enumerate(schema.fields.values())
                             if s.feature_type is FeatureType.SPARSE]
 
@@ -297,14 +298,28 @@ class FeatureEmbedding(nn.Module):
             return
         lib = _lib.load()
         plan = self._ensure_plan(g_fe.device)
+        S = len(self._sparse_pos)
+        rs = self.rowsparse
+        fmap = (C.c_int32 * max(S, 1))(*self._sparse_pos)
+        if dense_grads and self._plan_uniform and g_fe.data_ptr() % 16 == 0:
+            # DENSE-field gradients and row gradients in ONE launch (csrc/step_tail.hip)
+            if self._dense_list is None or self._dense_list.device != g_fe.device:
+                pos = [i for i, sp in enumerate(self.schema.fields.values()) if sp.feature_type is FeatureType.DENSE]
+                self._dense_list = torch.tensor(pos, dtype=torch.int32, device=g_fe.device)
+            nd = self._dense_list.numel()
+            _lib.check(lib.dfm_step_embedding_backward(
+                self._dense_list.data_ptr(), nd, self._ptr_array(inputs), self._grad_struct(dense_grads), fmap, S, F, D,
+                B, g_fo.data_ptr(), g_fe.data_ptr(), rs.sorted_pos.data_ptr() if S else None,
+                rs.seg_start.data_ptr() if S else None, rs.num_uniq.data_ptr() if S else None,
+                rs.row_g2.data_ptr() if S else None, rs.row_g1.data_ptr() if S else None, _lib.stream_handle()))
+            if S:
+                rs.has_grad = True
+            return
         if dense_grads:
             _lib.check(lib.dfm_embedding_backward_dense_fields(
                 plan, self._ptr_array(inputs), B, g_fo.data_ptr(), g_fe.data_ptr(), None,
                 self._grad_struct(dense_grads), _lib.stream_handle()))
-        S = len(self._sparse_pos)
         if S:
-            rs = self.rowsparse
-            fmap = (C.c_int32 * S)(*self._sparse_pos)
             _lib.check(lib.dfm_rowgrad_build(
                 fmap, S, F, D, B, g_fo.data_ptr(), g_fe.data_ptr(), rs.sorted_pos.data_ptr(),
                 rs.seg_start.data_ptr(), rs.num_uniq.data_ptr(), rs.row_g2.data_ptr(),

@@ -106,6 +106,9 @@ class RowSparseAdam:
         self._partials = None
         self._cur = None
         self.seed_tick: Optional[torch.Tensor] = None    # int64 device counter advanced once per apply()
+        # (dfm_slab_ref[], count): d-weight slabs of dfm_linear_backward that apply() folds into the flat
+        # gradient (single rank only: under data parallelism they must be in before the all-reduce)
+        self.slab_refs = None
 
     # ------------------------------------------------------------------ helpers
     def zero_grad(self, force: bool = False) -> None:
@@ -159,34 +162,29 @@ class RowSparseAdam:
         grad_scale = 1.0 / self.world
         uniq, num, g2, g1, lists = self._cur
         n_dense = self.flat_param.numel()
-        np_sparse = lib.dfm_rowadam_num_partials(self.num_sparse, self.dim, lists)
-        np_dense = lib.dfm_dense_num_partials(n_dense)
+        n_partials = lib.dfm_step_prepare_num_partials(self.num_sparse, self.dim, lists, n_dense)
         if self._owner is None or self._owner.shape != uniq.shape:
             self._owner = torch.empty_like(uniq)
-            self._partials = torch.zeros(np_sparse + np_dense, dtype=torch.float32, device=self.device)
+            self._partials = torch.zeros(n_partials, dtype=torch.float32, device=self.device)
         if self.world > 1:
             self.flat_grad.mul_(grad_scale)          # mean over ranks (loss is a per-rank mean)
         tabs = self._table_struct()
-        _lib.check(lib.dfm_rowadam_merge(tabs, self.num_sparse, self.dim, lists, uniq.data_ptr(),
-                                         num.data_ptr(), g2.data_ptr(), g1.data_ptr(),
-                                         self._owner.data_ptr(), grad_scale, self.l2,
-                                         self._partials.data_ptr(), stream))
-        _lib.check(lib.dfm_dense_grad_prepare(self.flat_grad.data_ptr(), self.flat_param.data_ptr(), n_dense,
-                                              self.n_l2, self.l2,
-                                              self._partials.data_ptr() + 4 * np_sparse, stream))
-        _lib.check(lib.dfm_grad_norm_finalize(self._partials.data_ptr(), np_sparse + np_dense,
+        refs, n_refs = self.slab_refs if (self.slab_refs is not None and self.world == 1) else (None, 0)
+        # three launches: [row-list merge | dense L2 (+ d-weight slabs) + norm partials] -> clip coefficient
+        # (+ step / seed tick) -> [row-wise Adam | dense Adam (+ clears the gradient buffer)]
+        _lib.check(lib.dfm_step_prepare(tabs, self.num_sparse, self.dim, lists, uniq.data_ptr(), num.data_ptr(),
+                                        g2.data_ptr(), g1.data_ptr(), self._owner.data_ptr(), grad_scale, self.l2,
+                                        self.flat_grad.data_ptr(), self.flat_param.data_ptr(), n_dense, self.n_l2,
+                                        refs, n_refs, self._partials.data_ptr(), stream))
+        _lib.check(lib.dfm_grad_norm_finalize(self._partials.data_ptr(), n_partials,
                                               self.max_grad_norm or 0.0, self.sq_norm.data_ptr(),
                                               self.clip_coef.data_ptr(), self.step_count.data_ptr(),
                                               _lib.ptr(self.seed_tick), stream))
-        _lib.check(lib.dfm_rowadam_apply(tabs, self.num_sparse, self.dim, lists, uniq.data_ptr(),
-                                         num.data_ptr(), g2.data_ptr(), g1.data_ptr(),
-                                         self._owner.data_ptr(), self.clip_coef.data_ptr(), self.lr,
-                                         self.betas[0], self.betas[1], self.eps,
-                                         self.step_count.data_ptr(), stream))
-        _lib.check(lib.dfm_dense_adam(self.flat_param.data_ptr(), self.flat_m.data_ptr(),
-                                      self.flat_v.data_ptr(), self.flat_grad.data_ptr(), n_dense,
-                                      self.clip_coef.data_ptr(), self.lr, self.betas[0], self.betas[1],
-                                      self.eps, self.step_count.data_ptr(), 1, stream))
+        _lib.check(lib.dfm_step_apply(tabs, self.num_sparse, self.dim, lists, uniq.data_ptr(), num.data_ptr(),
+                                      g2.data_ptr(), g1.data_ptr(), self._owner.data_ptr(), self.clip_coef.data_ptr(),
+                                      self.lr, self.betas[0], self.betas[1], self.eps, self.step_count.data_ptr(),
+                                      self.flat_param.data_ptr(), self.flat_m.data_ptr(), self.flat_v.data_ptr(),
+                                      self.flat_grad.data_ptr(), n_dense, 1, stream))
         self.emb.rowsparse.has_grad = False
 
     def step(self) -> None:

@@ -415,6 +415,41 @@ typedef struct dfm_slab_ref {
   int32_t in_features;
 } dfm_slab_ref;
 int dfm_linear_backward_finish(const dfm_slab_ref* refs, int count, dfm_stream_t stream);
+/* Number of batch splits (slabs) dfm_linear_backward leaves in its workspace for this shape. */
+int dfm_linear_backward_splits(int64_t batch, int out_features, int in_features);
+
+/* ---------------------------------------------------------------------------------
+ * Grouped launches for the tail of the training step (csrc/step_tail.hip): kernels of the step that
+ * do not depend on each other share one dispatch.  Same arithmetic and reduction order as the
+ * stand-alone entry points they combine (bit-identical results).
+ * ------------------------------------------------------------------------------- */
+/* dfm_embedding_backward_dense_fields + dfm_rowgrad_build for a uniform plan in one launch.
+ * d_dense_list: device array with the schema positions of the num_dense DENSE fields; dense_x and
+ * dense_grads: host arrays indexed by schema position (as dfm_embedding_forward's inputs and
+ * dfm_field_grad[]); the remaining arguments as in dfm_rowgrad_build. */
+int dfm_step_embedding_backward(const int32_t* d_dense_list, int num_dense, const void* const* dense_x,
+                                const dfm_field_grad* dense_grads, const int32_t* field_of_sparse,
+                                int num_sparse, int num_fields, int dim, int64_t batch,
+                                const float* d_g_first, const float* d_g_field,
+                                const int32_t* d_sorted_pos, const int32_t* d_seg_start,
+                                const int32_t* d_num_uniq, float* d_row_g2, float* d_row_g1,
+                                dfm_stream_t stream);
+/* dfm_rowadam_merge + dfm_dense_grad_prepare in one launch; `slabs` (optional) are dfm_linear_backward
+ * workspaces whose batch-split products are added into their d_g views first (replaces
+ * dfm_linear_backward_finish).  d_partials: dfm_step_prepare_num_partials floats, to be summed by
+ * dfm_grad_norm_finalize. */
+int64_t dfm_step_prepare_num_partials(int num_sparse, int dim, int num_lists, int64_t n);
+int dfm_step_prepare(const dfm_table* tables, int num_sparse, int dim, int num_lists,
+                     const int32_t* d_uniq_rows, const int32_t* d_num_uniq, float* d_row_g2,
+                     float* d_row_g1, int32_t* d_owner_flag, float grad_scale, float l2, float* d_g,
+                     const float* d_p, int64_t n, int64_t n_l2, const dfm_slab_ref* slabs, int num_slabs,
+                     float* d_partials, dfm_stream_t stream);
+/* dfm_rowadam_apply + dfm_dense_adam in one launch. */
+int dfm_step_apply(const dfm_table* tables, int num_sparse, int dim, int num_lists,
+                   const int32_t* d_uniq_rows, const int32_t* d_num_uniq, const float* d_row_g2,
+                   const float* d_row_g1, const int32_t* d_owner_flag, const float* d_clip_coef, float lr,
+                   float beta1, float beta2, float eps, const int32_t* d_step, float* d_p, float* d_m,
+                   float* d_v, float* d_g, int64_t n, int zero_grad, dfm_stream_t stream);
 
 /* ---------------------------------------------------------------------------------
  * Exact-fp32 GEMM on the matrix cores (v_mfma_f32_32x32x2_f32) for the DNN tower's Linear
