@@ -93,14 +93,21 @@ __global__ __launch_bounds__(kTailThreads) void step_embedding_backward_kernel(
                  row_g1);
 }
 
+__global__ __launch_bounds__(kTailThreads) void step_match_kernel(int S, int L, const int32_t* __restrict__ uniq_rows,
+                                                                  const int32_t* __restrict__ num_uniq,
+                                                                  uint8_t* __restrict__ match) {
+  rowadam_match_body(blockIdx.x, S, L, uniq_rows, num_uniq, match);
+}
+
 __global__ __launch_bounds__(kTailThreads) void step_prepare_kernel(
     int merge_blocks, TableArgs tabs, int S, int D, int L, const int32_t* __restrict__ uniq_rows,
     const int32_t* __restrict__ num_uniq, float* __restrict__ row_g2, float* __restrict__ row_g1,
     int32_t* __restrict__ owner_flag, float grad_scale, float l2, float* __restrict__ g, const float* __restrict__ p,
-    int64_t n, int64_t n_l2, SlabTable slabs, float* __restrict__ partial) {
+    int64_t n, int64_t n_l2, SlabTable slabs, float* __restrict__ partial, const uint8_t* __restrict__ match) {
   const int blk = blockIdx.x;
   if (blk < merge_blocks)
-    rowadam_merge_body(blk, tabs, S, D, L, uniq_rows, num_uniq, row_g2, row_g1, owner_flag, grad_scale, l2, partial);
+    rowadam_merge_body(blk, tabs, S, D, L, uniq_rows, num_uniq, row_g2, row_g1, owner_flag, grad_scale, l2, partial,
+                       match);
   else
     dense_prepare_slabs_body(blk - merge_blocks, g, p, n, n_l2, l2, slabs, partial + merge_blocks);
 }
@@ -190,6 +197,10 @@ extern "C" int dfm_step_embedding_backward(const int32_t* d_dense_list, int num_
   return DFM_OK;
 }
 
+extern "C" size_t dfm_step_match_bytes(int num_sparse, int num_lists) {
+  return num_lists > 2 ? static_cast<size_t>(num_lists) * num_sparse * CH * num_lists : 0;
+}
+
 extern "C" int64_t dfm_step_prepare_num_partials(int num_sparse, int dim, int num_lists, int64_t n) {
   return row_blocks(num_sparse, dim, num_lists) + prep_blocks(n);
 }
@@ -198,7 +209,7 @@ extern "C" int dfm_step_prepare(const dfm_table* tables, int num_sparse, int dim
                                 const int32_t* d_uniq_rows, const int32_t* d_num_uniq, float* d_row_g2,
                                 float* d_row_g1, int32_t* d_owner_flag, float grad_scale, float l2, float* d_g,
                                 const float* d_p, int64_t n, int64_t n_l2, const dfm_slab_ref* slabs, int num_slabs,
-                                float* d_partials, dfm_stream_t stream) {
+                                float* d_partials, void* d_match, dfm_stream_t stream) {
   DFM_REQUIRE(tables && d_uniq_rows && d_num_uniq && d_row_g2 && d_row_g1 && d_owner_flag && d_partials && d_g && d_p,
               "null argument");
   DFM_REQUIRE(num_sparse > 0 && num_sparse <= DFM_MAX_FIELDS && num_lists > 0, "bad sizes");
@@ -224,9 +235,18 @@ extern "C" int dfm_step_prepare(const dfm_table* tables, int num_sparse, int dim
   }
   st.count = num_slabs;
   const int64_t mb = row_blocks(num_sparse, dim, num_lists), pb = prep_blocks(n);
+  // with three or more lists (data-parallel ranks x chunks) the list memberships are resolved once,
+  // through LDS, instead of by L-1 global binary searches per entry inside the merge
+  uint8_t* match = (d_match && num_lists > 2) ? static_cast<uint8_t*>(d_match) : nullptr;
+  if (match) {
+    DFM_REQUIRE(num_lists <= 255, "at most 255 lists");
+    hipLaunchKernelGGL(step_match_kernel, dim3(static_cast<unsigned>(num_sparse * num_lists * num_lists)),
+                       dim3(kTailThreads), 0, as_stream(stream), num_sparse, num_lists, d_uniq_rows, d_num_uniq, match);
+    DFM_LAUNCH_CHECK();
+  }
   hipLaunchKernelGGL(step_prepare_kernel, dim3(static_cast<unsigned>(mb + pb)), dim3(kTailThreads), 0,
                      as_stream(stream), static_cast<int>(mb), ta, num_sparse, dim, num_lists, d_uniq_rows, d_num_uniq,
-                     d_row_g2, d_row_g1, d_owner_flag, grad_scale, l2, d_g, d_p, n, n_l2, st, d_partials);
+                     d_row_g2, d_row_g1, d_owner_flag, grad_scale, l2, d_g, d_p, n, n_l2, st, d_partials, match);
   DFM_LAUNCH_CHECK();
   return DFM_OK;
 }

@@ -123,10 +123,38 @@ __device__ __forceinline__ int find_row(const int32_t* __restrict__ rows, int n,
   return (lo < n && rows[lo] == row) ? lo : -1;
 }
 
+// Membership of every entry of list lq in list ln (same field), for all ordered pairs lq != ln:
+// workgroup (s, ln, lq) holds list ln's sorted rows in LDS (16 KB) and answers list lq's <= 4096
+// queries with LDS binary searches; match[(lq*S+s)*CH + u][ln] = 1 iff found.  Replaces the
+// O(L^2) global-memory binary searches of the merge when many lists (data-parallel ranks) meet.
+__device__ __forceinline__ void rowadam_match_body(int blk, int S, int L, const int32_t* __restrict__ uniq_rows,
+                                                   const int32_t* __restrict__ num_uniq,
+                                                   uint8_t* __restrict__ match) {
+  __shared__ int32_t rows[CH];
+  const int s = blk % S;
+  const int pair = blk / S;
+  const int ln = pair / L, lq = pair % L;
+  if (ln == lq) return;
+  const int64_t lt = static_cast<int64_t>(ln) * S + s, lqs = static_cast<int64_t>(lq) * S + s;
+  const int nt = num_uniq[lt], nq = num_uniq[lqs];
+  for (int i = threadIdx.x; i < nt; i += kTailThreads) rows[i] = uniq_rows[lt * CH + i];
+  __syncthreads();
+  for (int u = threadIdx.x; u < nq; u += kTailThreads) {
+    const int32_t row = uniq_rows[lqs * CH + u];
+    int lo = 0, hi = nt;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (rows[mid] < row) lo = mid + 1; else hi = mid;
+    }
+    match[(lqs * CH + u) * L + ln] = (lo < nt && rows[lo] == row) ? 1 : 0;
+  }
+}
+
 // pass A of the row-wise Adam: ownership merge of the L lists, lazy L2, |g|^2 partial per workgroup
 __device__ __forceinline__ void rowadam_merge_body(int blk, TableArgs tabs, int S, int D, int L, const int32_t* __restrict__ uniq_rows,
     const int32_t* __restrict__ num_uniq, float* __restrict__ row_g2, float* __restrict__ row_g1,
-    int32_t* __restrict__ owner_flag, float grad_scale, float l2, float* __restrict__ partial) {
+    int32_t* __restrict__ owner_flag, float grad_scale, float l2, float* __restrict__ partial,
+    const uint8_t* __restrict__ match = nullptr) {
   const int lpr = D / 4;
   const int64_t t = static_cast<int64_t>(blk) * kTailThreads + threadIdx.x;
   const int q = static_cast<int>(t % lpr);
@@ -137,16 +165,21 @@ __device__ __forceinline__ void rowadam_merge_body(int blk, TableArgs tabs, int 
   if (list < static_cast<int64_t>(L) * S && u < num_uniq[list]) {
     const int l = static_cast<int>(list / S), s = static_cast<int>(list % S);
     const int32_t row = uniq_rows[list * CH + u];
+    // match (optional, from rowadam_match_body): byte [entry][ln] != 0 iff list ln of this field also
+    // holds the row — the L-1 binary searches per entry become L byte reads, and a search is only
+    // repeated for the (rare) lists that do hold it
+    const uint8_t* mt = match ? match + (list * CH + u) * L : nullptr;
     bool owner = true;
     for (int lp = 0; lp < l && owner; ++lp) {
       const int64_t other = static_cast<int64_t>(lp) * S + s;
-      if (find_row(uniq_rows + other * CH, num_uniq[other], row) >= 0) owner = false;
+      if (mt ? mt[lp] != 0 : find_row(uniq_rows + other * CH, num_uniq[other], row) >= 0) owner = false;
     }
     if (q == 0) owner_flag[list * CH + u] = owner ? 1 : 0;
     if (owner) {
       float4 g = ld4(row_g2 + (list * CH + u) * D + q * 4);
       float g1 = q == 0 ? row_g1[list * CH + u] : 0.f;
       for (int ln = l + 1; ln < L; ++ln) {
+        if (mt && mt[ln] == 0) continue;
         const int64_t other = static_cast<int64_t>(ln) * S + s;
         const int pos = find_row(uniq_rows + other * CH, num_uniq[other], row);
         if (pos >= 0) {

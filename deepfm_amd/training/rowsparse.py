@@ -104,6 +104,7 @@ class RowSparseAdam:
         self._owner = None
         self._gathered = None
         self._partials = None
+        self._match = None
         self._cur = None
         self.seed_tick: Optional[torch.Tensor] = None    # int64 device counter advanced once per apply()
         # (dfm_slab_ref[], count): d-weight slabs of dfm_linear_backward that apply() folds into the flat
@@ -166,6 +167,8 @@ class RowSparseAdam:
         if self._owner is None or self._owner.shape != uniq.shape:
             self._owner = torch.empty_like(uniq)
             self._partials = torch.zeros(n_partials, dtype=torch.float32, device=self.device)
+            mbytes = lib.dfm_step_match_bytes(self.num_sparse, lists)
+            self._match = torch.empty(mbytes, dtype=torch.uint8, device=self.device) if mbytes else None
         if self.world > 1:
             self.flat_grad.mul_(grad_scale)          # mean over ranks (loss is a per-rank mean)
         tabs = self._table_struct()
@@ -175,7 +178,7 @@ class RowSparseAdam:
         _lib.check(lib.dfm_step_prepare(tabs, self.num_sparse, self.dim, lists, uniq.data_ptr(), num.data_ptr(),
                                         g2.data_ptr(), g1.data_ptr(), self._owner.data_ptr(), grad_scale, self.l2,
                                         self.flat_grad.data_ptr(), self.flat_param.data_ptr(), n_dense, self.n_l2,
-                                        refs, n_refs, self._partials.data_ptr(), stream))
+                                        refs, n_refs, self._partials.data_ptr(), _lib.ptr(self._match), stream))
         _lib.check(lib.dfm_grad_norm_finalize(self._partials.data_ptr(), n_partials,
                                               self.max_grad_norm or 0.0, self.sq_norm.data_ptr(),
                                               self.clip_coef.data_ptr(), self.step_count.data_ptr(),
