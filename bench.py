@@ -156,8 +156,8 @@ def main():
     step.capture()
 
     def run(i, timed):
-        step.load_packed(records[i])                      # one D2D copy per step
-        step.run(time_gather=timed)
+        # the gather reads batch i from its record and refreshes the step's static inputs on the way
+        step.run_from(records[i])
 
     import ctypes as C
     from deepfm_amd import _lib

@@ -53,6 +53,7 @@ struct SparseSlot {
   int32_t field;
   int32_t stride2;  // floats between rows of w2 / w1 (packed row records: the record size)
   int32_t stride1;
+  int64_t* ids_out;  // optional: the ids are also copied here (staging of the step's static inputs)
 };
 struct DenseSlot {
   const float* x;
@@ -62,8 +63,9 @@ struct DenseSlot {
   const float* b1;
   int32_t field;
   int32_t pad;
+  float* x_out;      // optional: copy of x (staging)
 };
-constexpr int kMaxSparseSlots = 48, kMaxDenseSlots = 32;   // 48*40 + 32*48 B of kernel arguments
+constexpr int kMaxSparseSlots = 48, kMaxDenseSlots = 32;   // 48*48 + 32*56 B of kernel arguments
 struct UniformArgs {
   SparseSlot sp[kMaxSparseSlots];
   DenseSlot de[kMaxDenseSlots];
@@ -73,7 +75,7 @@ template <int D, int W, bool HAS_SPARSE, bool HAS_DENSE>
 __device__ __forceinline__ void emb_fwd_uniform_body(
     const UniformArgs& args, int ns, int nd, int64_t B, int F, float* __restrict__ first_order,
     float* __restrict__ fe, float* __restrict__ fm_out, float* __restrict__ fm_sum, int32_t* error_flag,
-    int ablate = 0) {
+    int ablate = 0, const float* __restrict__ extra_src = nullptr, float* __restrict__ extra_dst = nullptr) {
   constexpr int LPR = D / 4;        // lanes per row (16 B each)
   constexpr int SPW = kWave / LPR;  // samples per wave == samples per block
   constexpr int US = HAS_SPARSE ? 4 : 0;  // sparse slots in flight per wave
@@ -120,6 +122,13 @@ __device__ __forceinline__ void emb_fwd_uniform_body(
     for (int u = 0; u < US; ++u) id[u] = sl[u].ids[bc];
 #pragma unroll
     for (int u = 0; u < UD; ++u) x[u] = dl[u].x[bc];
+    // staging: the raw inputs also go to the step's static buffers (row plan, embedding backward)
+#pragma unroll
+    for (int u = 0; u < US; ++u)
+      if (sl[u].ids_out && live && q == 0 && oks[u]) sl[u].ids_out[b] = id[u];
+#pragma unroll
+    for (int u = 0; u < UD; ++u)
+      if (dl[u].x_out && live && q == 0 && okd[u]) dl[u].x_out[b] = x[u];
     float4 dw[UD + 1], db[UD + 1];
     float dw1[UD + 1], db1[UD + 1];
 #pragma unroll
@@ -196,6 +205,7 @@ __device__ __forceinline__ void emb_fwd_uniform_body(
     }
     // S[b, :] = sum_f e[b, f, :] for the FM backward g * (S - e)
     if (live && fm_sum) st4(fm_sum + b * D + q * 4, make_float4(acc[0], acc[1], acc[2], acc[3]));
+    if (live && q == 0 && extra_dst) extra_dst[b] = extra_src[b];      // per-sample payload (labels)
   }
 }
 
@@ -203,16 +213,20 @@ __device__ __forceinline__ void emb_fwd_uniform_body(
 template <int D, int W, bool HAS_SPARSE, bool HAS_DENSE>
 __global__ __launch_bounds__(W * 64) void emb_fwd_uniform(
     UniformArgs args, int ns, int nd, int64_t B, int F, float* __restrict__ first_order,
-    float* __restrict__ fe, float* __restrict__ fm_out, float* __restrict__ fm_sum, int32_t* error_flag, int ablate) {
-  emb_fwd_uniform_body<D, W, HAS_SPARSE, HAS_DENSE>(args, ns, nd, B, F, first_order, fe, fm_out, fm_sum, error_flag, ablate);
+    float* __restrict__ fe, float* __restrict__ fm_out, float* __restrict__ fm_sum, int32_t* error_flag, int ablate,
+    const float* __restrict__ extra_src, float* __restrict__ extra_dst) {
+  emb_fwd_uniform_body<D, W, HAS_SPARSE, HAS_DENSE>(args, ns, nd, B, F, first_order, fe, fm_out, fm_sum, error_flag, ablate,
+                                                    extra_src, extra_dst);
 }
 // ... or in device memory owned by the plan (refreshed only when a pointer changes)
 template <int D, int W, bool HAS_SPARSE, bool HAS_DENSE>
 __global__ __launch_bounds__(W * 64) void emb_fwd_uniform_mem(
     const UniformArgs* __restrict__ args, int ns, int nd, int64_t B, int F,
     float* __restrict__ first_order, float* __restrict__ fe, float* __restrict__ fm_out,
-    float* __restrict__ fm_sum, int32_t* error_flag, int ablate) {
-  emb_fwd_uniform_body<D, W, HAS_SPARSE, HAS_DENSE>(*args, ns, nd, B, F, first_order, fe, fm_out, fm_sum, error_flag, ablate);
+    float* __restrict__ fm_sum, int32_t* error_flag, int ablate, const float* __restrict__ extra_src,
+    float* __restrict__ extra_dst) {
+  emb_fwd_uniform_body<D, W, HAS_SPARSE, HAS_DENSE>(*args, ns, nd, B, F, first_order, fe, fm_out, fm_sum, error_flag, ablate,
+                                                    extra_src, extra_dst);
 }
 
 // ======================================================================================
@@ -545,7 +559,9 @@ static int gather_waves() {
 
 template <int D>
 static int launch_uniform(const dfm_embedding_plan* plan, const PtrTable& in, int64_t B,
-                          float* fo, float* fe, float* fm_out, float* fm_sum, int32_t* err, hipStream_t st) {
+                          float* fo, float* fe, float* fm_out, float* fm_sum, int32_t* err, hipStream_t st,
+                          void* const* stage_out = nullptr, const float* extra_src = nullptr,
+                          float* extra_dst = nullptr) {
   constexpr int SPW = kWave / (D / 4);
   UniformArgs args;
   memset(&args, 0, sizeof(args));
@@ -553,12 +569,14 @@ static int launch_uniform(const dfm_embedding_plan* plan, const PtrTable& in, in
   for (int i = 0; i < ns; ++i) {
     const int f = plan->h_sparse[i];
     const dfm_field& fd = plan->h_fields[f];
-    args.sp[i] = SparseSlot{static_cast<const int64_t*>(in.p[f]), fd.w2, fd.w1, fd.vocab, f, fd.stride2, fd.stride1};
+    args.sp[i] = SparseSlot{static_cast<const int64_t*>(in.p[f]), fd.w2, fd.w1, fd.vocab, f, fd.stride2, fd.stride1,
+                            stage_out ? static_cast<int64_t*>(stage_out[f]) : nullptr};
   }
   for (int i = 0; i < nd; ++i) {
     const int f = plan->h_dense[i];
     const dfm_field& fd = plan->h_fields[f];
-    args.de[i] = DenseSlot{static_cast<const float*>(in.p[f]), fd.w2, fd.b2, fd.w1, fd.b1, f, 0};
+    args.de[i] = DenseSlot{static_cast<const float*>(in.p[f]), fd.w2, fd.b2, fd.w1, fd.b1, f, 0,
+                           stage_out ? static_cast<float*>(stage_out[f]) : nullptr};
   }
   const dim3 grid(static_cast<unsigned>((B + SPW - 1) / SPW));
   const int F = plan->num_fields;
@@ -590,13 +608,14 @@ static int launch_uniform(const dfm_embedding_plan* plan, const PtrTable& in, in
   do {                                                                                                  \
     if (ev0 && !d_args)                                                                                 \
       hipExtLaunchKernelGGL((emb_fwd_uniform<D, WV, HS, HD>), grid, dim3(WV * 64), 0, st, ev0, ev1, 0,  \
-                            args, ns, nd, B, F, fo, fe, fm_out, fm_sum, err, g_ablate);                 \
+                            args, ns, nd, B, F, fo, fe, fm_out, fm_sum, err, g_ablate, extra_src,      \
+                            extra_dst);                                                                 \
     else if (d_args)                                                                                         \
       hipLaunchKernelGGL((emb_fwd_uniform_mem<D, WV, HS, HD>), grid, dim3(WV * 64), 0, st, d_args, ns,  \
-                         nd, B, F, fo, fe, fm_out, fm_sum, err, g_ablate);                                      \
+                         nd, B, F, fo, fe, fm_out, fm_sum, err, g_ablate, extra_src, extra_dst);                \
     else                                                                                                \
       hipLaunchKernelGGL((emb_fwd_uniform<D, WV, HS, HD>), grid, dim3(WV * 64), 0, st, args, ns, nd, B, \
-                         F, fo, fe, fm_out, fm_sum, err, g_ablate);                                             \
+                         F, fo, fe, fm_out, fm_sum, err, g_ablate, extra_src, extra_dst);                       \
   } while (0)
 #define DFM_GATHER_PICK(WV)                                    \
   do {                                                         \
@@ -730,6 +749,32 @@ extern "C" int dfm_embedding_backward_dense_fields(const dfm_embedding_plan* pla
   return launch_dense_fields(plan, in, gt, batch, d_g_first, d_g_field, d_g_flat, as_stream(stream));
 }
 
+
+extern "C" int dfm_embedding_forward_staged(const dfm_embedding_plan* plan, const void* const* inputs,
+                                           void* const* stage_out, const float* d_extra_src, float* d_extra_dst,
+                                           int64_t batch, float* d_first_order, float* d_field_emb, float* d_fm_out,
+                                           float* d_fm_sum, int32_t* d_error_flag, dfm_stream_t stream) {
+  DFM_REQUIRE(plan && inputs && stage_out && d_first_order && d_field_emb, "null argument");
+  DFM_REQUIRE(plan->uniform, "staged gather needs a uniform plan");
+  DFM_REQUIRE((d_extra_src == nullptr) == (d_extra_dst == nullptr), "extra source and destination go together");
+  DFM_REQUIRE(batch >= 0 && batch < (int64_t(1) << 31), "batch %lld out of range", (long long)batch);
+  if (batch == 0) return DFM_OK;
+  PtrTable in;
+  if (int rc = fill_ptrs(plan, inputs, &in)) return rc;
+  for (int f = 0; f < plan->num_fields; ++f)
+    DFM_REQUIRE(stage_out[f] != nullptr && stage_out[f] != inputs[f], "stage_out[%d] must be a distinct buffer", f);
+  hipStream_t st = as_stream(stream);
+#define DFM_STAGED(DD)                                                                                          \
+  case DD:                                                                                                      \
+    return launch_uniform<DD>(plan, in, batch, d_first_order, d_field_emb, d_fm_out, d_fm_sum, d_error_flag, st, \
+                              stage_out, d_extra_src, d_extra_dst)
+  switch (plan->fm_dim) {
+    DFM_STAGED(4); DFM_STAGED(8); DFM_STAGED(16); DFM_STAGED(32); DFM_STAGED(64); DFM_STAGED(128); DFM_STAGED(256);
+    default: break;
+  }
+#undef DFM_STAGED
+  return fail(DFM_ERR_UNSUPPORTED, "no uniform gather for fm_dim %d", plan->fm_dim);
+}
 
 extern "C" int dfm_gather_timing_begin(int launches) {
   DFM_REQUIRE(launches > 0 && launches <= (1 << 20), "bad launch count");

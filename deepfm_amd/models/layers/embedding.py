@@ -90,6 +90,7 @@ class FeatureEmbedding(nn.Module):
         self._err: Optional[torch.Tensor] = None
         self._anchor: Optional[torch.Tensor] = None
         self._dense_list: Optional[torch.Tensor] = None
+        self._plan_static = False
         self._sparse_pos = [i for i, s in enumerate(schema.fields.values())
                             if s.feature_type is FeatureType.SPARSE]
 
@@ -111,7 +112,16 @@ class FeatureEmbedding(nn.Module):
         except Exception:
             pass
 
+    def pin_plan(self, device: torch.device, pinned: bool = True) -> None:
+        """Promise that no parameter of this module will be re-homed (``.to()``, ``pack_tables_()``,
+        ``p.data = ...``) while ``pinned``: the kernel plan is then reused without re-validation."""
+        self._plan_static = False
+        if pinned:
+            self._ensure_plan(device)
+        self._plan_static = pinned
+
     def _drop_plan(self) -> None:
+        self._plan_static = False
         if self._plan is not None:
             _lib.load().dfm_embedding_plan_destroy(self._plan)
             self._plan = None
@@ -183,6 +193,11 @@ class FeatureEmbedding(nn.Module):
 
     # ------------------------------------------------------------------ plan
     def _ensure_plan(self, device: torch.device):
+        # a training step that has captured raw parameter pointers (HIP graph) pins the plan: walking
+        # ~100 parameters to re-validate it costs ~250 us of host time per call, more than the whole
+        # GPU step
+        if self._plan_static and self._plan is not None:
+            return self._plan
         params = list(self.parameters())
         key = (device, tuple((p.data_ptr(), p.stride(0)) for p in params))
         if self._plan is not None and key == self._plan_key:
@@ -270,6 +285,22 @@ class FeatureEmbedding(nn.Module):
             _lib.check(_lib.load().dfm_embedding_forward(
                 plan, self._ptr_array(inputs), B, fo.data_ptr(), fe.data_ptr(), _lib.ptr(flat),
                 _lib.ptr(fm_out), _lib.ptr(fm_sum), _lib.ptr(ws), self._err.data_ptr(), _lib.stream_handle()))
+
+    def forward_staged(self, src_ptrs: List[int], stage_out: List[torch.Tensor], B: int, fo: torch.Tensor,
+                       fe: torch.Tensor, fm_out: Optional[torch.Tensor] = None, fm_sum: Optional[torch.Tensor] = None,
+                       extra_src_ptr: int = 0, extra_dst: Optional[torch.Tensor] = None) -> None:
+        """The gather of ``forward_into`` reading every field's input from ``src_ptrs`` (device addresses
+        inside a batch record, schema order) and refreshing ``stage_out`` (the step's static input
+        buffers) plus one float per sample (``extra``: the labels) on the way — the per-step
+        "load the next batch" copy without a launch of its own.  Uniform plans only."""
+        plan = self._ensure_plan(fe.device)
+        if not self._plan_uniform:
+            raise NotImplementedError("staged gather needs a uniform schema")
+        if B > 0:
+            src = (C.c_void_p * len(src_ptrs))(*src_ptrs)
+            _lib.check(_lib.load().dfm_embedding_forward_staged(
+                plan, src, self._ptr_array(stage_out), extra_src_ptr or None, _lib.ptr(extra_dst), B, fo.data_ptr(),
+                fe.data_ptr(), _lib.ptr(fm_out), _lib.ptr(fm_sum), self._err.data_ptr(), _lib.stream_handle()))
 
     def _launch_forward(self, inputs: List[torch.Tensor], B: int, want_fm: bool = False):
         dev = inputs[0].device

@@ -86,8 +86,8 @@ class FusedDeepFMStep(RowSparseTrainStep):
                 raise RuntimeError("FusedDeepFMStep needs RowSparseAdam's flat gradient views on every dense parameter")
 
     # ------------------------------------------------------------------ pieces
-    def _gather(self) -> None:
-        self.emb.forward_into(self.inputs, self.B, self.fo, self.fe, fm_out=self.fm, fm_sum=self.fm_sum)
+    def _gather_args(self) -> dict:
+        return dict(fm_out=self.fm, fm_sum=self.fm_sum)
 
     def _bn_ctx(self, i: int) -> _lib.BnBwd:
         bn = self.bn[i]

@@ -46,12 +46,15 @@ class RowSparseTrainStep:
         self.dense = self.packed[o1:o2].view(torch.float32).view(nd, batch_size)
         self.labels = self.packed[o2:].view(torch.float32)
         self.inputs: List[torch.Tensor] = []
+        self._rec_offsets: List[int] = []          # byte offset of every field's input inside a batch record
         si = di = 0
         for s in specs:
             if s.feature_type is FeatureType.SPARSE:
-                self.inputs.append(self.ids[si]); si += 1
+                self.inputs.append(self.ids[si]); self._rec_offsets.append(si * batch_size * 8); si += 1
             else:
-                self.inputs.append(self.dense[di]); di += 1
+                self.inputs.append(self.dense[di]); self._rec_offsets.append(o1 + di * batch_size * 4); di += 1
+        self._rec_labels = o2
+        self._record: Optional[torch.Tensor] = None   # batch record the next gather reads (run_from)
         F, D = len(specs), self.emb.fm_embed_dim
         self.fo = torch.empty(batch_size, 1, dtype=torch.float32, device=dev)
         self.fe = torch.empty(batch_size, F, D, dtype=torch.float32, device=dev)
@@ -62,6 +65,7 @@ class RowSparseTrainStep:
         self.graph_b: Optional[torch.cuda.CUDAGraph] = None
         self.dense_grads = {id(p): p.grad for p in self.emb.non_table_parameters() if p.grad is not None}
         self.gather_events = None          # list of (start, end) torch.cuda.Event pairs when timing
+        self.emb.pin_plan(dev)             # the step holds raw parameter pointers from here on
 
     # ------------------------------------------------------------------ pieces
     def load_batch(self, ids: torch.Tensor, dense: torch.Tensor, labels: torch.Tensor) -> None:
@@ -92,8 +96,19 @@ class RowSparseTrainStep:
         """One device-to-device copy of a pack_batches() record into the static inputs."""
         self.packed.copy_(record, non_blocking=True)
 
+    def _gather_args(self) -> dict:
+        """Extra outputs of the gather (subclasses: the fused step adds the FM value and S)."""
+        return {}
+
     def _gather(self) -> None:
-        self.emb.forward_into(self.inputs, self.B, self.fo, self.fe)
+        rec = self._record
+        if rec is None:
+            self.emb.forward_into(self.inputs, self.B, self.fo, self.fe, **self._gather_args())
+            return
+        base = rec.data_ptr()
+        self.emb.forward_staged([base + o for o in self._rec_offsets], self.inputs, self.B, self.fo, self.fe,
+                                extra_src_ptr=base + self._rec_labels, extra_dst=self.labels, **self._gather_args())
+        self._record = None
 
     def _body_a(self) -> None:
         self.opt.zero_grad()
@@ -146,6 +161,17 @@ class RowSparseTrainStep:
             with torch.cuda.graph(self.graph_b, **mode):
                 self._body_b()
         torch.cuda.synchronize()
+
+    def run_from(self, record: torch.Tensor) -> None:
+        """One step on a ``pack_batches()`` record without the separate load: the (eager) gather reads
+        its inputs from the record and refreshes the static input buffers — ids, dense values,
+        labels — that the captured part of the step reads."""
+        if record.numel() != self.packed_bytes or record.dtype != torch.uint8 or not record.is_contiguous():
+            raise ValueError("run_from expects one contiguous pack_batches() record")
+        if record.data_ptr() % 16:
+            raise ValueError("batch records must be 16-byte aligned")
+        self._record = record
+        self.run()
 
     def run(self, time_gather: bool = False) -> None:
         if time_gather:

@@ -105,6 +105,16 @@ int dfm_embedding_forward(const dfm_embedding_plan* plan, const void* const* inp
                           float* d_fm_out, float* d_fm_sum, void* d_workspace, int32_t* d_error_flag,
                           dfm_stream_t stream);
 
+/* dfm_embedding_forward for a uniform plan whose inputs sit in a batch record that changes every
+ * step: the kernel also copies every field's raw input to stage_out[f] (host array of device
+ * pointers, schema order: int64 (B,) / float (B,)) and, optionally, one float per sample from
+ * d_extra_src to d_extra_dst (the labels) — the "load the next batch into the step's static
+ * buffers" copy (reference trainer.py:214-217) without a launch of its own. */
+int dfm_embedding_forward_staged(const dfm_embedding_plan* plan, const void* const* inputs,
+                                 void* const* stage_out, const float* d_extra_src, float* d_extra_dst,
+                                 int64_t batch, float* d_first_order, float* d_field_emb, float* d_fm_out,
+                                 float* d_fm_sum, int32_t* d_error_flag, dfm_stream_t stream);
+
 /* Kernel-accurate timing of the uniform gather (measurement aid, bench.py): after
  * dfm_gather_timing_begin(n) the next n dfm_embedding_forward launches of a uniform plan carry HIP
  * start/stop events recorded around the dispatch itself (hipExtLaunchKernelGGL), on the stream the

@@ -355,3 +355,38 @@ def test_match_kernel_is_bitwise_equivalent_for_many_lists():
         results[-1]["__sq"] = npy(opt.sq_norm).copy()
     for k in results[0]:
         assert np.array_equal(results[0][k], results[1][k]), k
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_run_from_record_equals_load_then_run(fused):
+    """run_from(record): the gather reads the batch from its record and refreshes the static inputs
+    itself — bit-identical to load_packed(record) + run(), including odd tails (B not a multiple of 16)."""
+    from deepfm_amd.training.fused_step import FusedDeepFMStep
+    from deepfm_amd.training.rowsparse import RowSparseAdam
+    from deepfm_amd.training.step import RowSparseTrainStep
+    B = 1000
+    rng = np.random.default_rng(12)
+    fields = criteo_fields(300, 16)
+    ids, dense, labels = _pool(fields, 3, B, rng)
+    results = []
+    for staged in (False, True):
+        _, _, model = _small_deepfm(seed=6)
+        opt = RowSparseAdam(model, lr=1e-3, l2=1e-5, max_grad_norm=1.0)
+        step = (FusedDeepFMStep if fused else RowSparseTrainStep)(model, opt, B, use_graph=False)
+        recs = step.pack_batches(torch.from_numpy(ids).cuda(), torch.from_numpy(dense).cuda(), torch.from_numpy(labels).cuda())
+        losses = []
+        for i in range(3):
+            if staged:
+                step.run_from(recs[i])
+            else:
+                step.load_packed(recs[i])
+                step.run()
+            losses.append(float(step.loss))
+        if staged:      # the static buffers hold the last batch
+            assert torch.equal(step.ids, torch.from_numpy(ids[2]).cuda())
+            assert torch.equal(step.dense, torch.from_numpy(dense[2]).cuda())
+            assert torch.equal(step.labels, torch.from_numpy(labels[2]).cuda())
+        results.append(({k: npy(v).copy() for k, v in model.state_dict().items()}, losses))
+    assert results[0][1] == results[1][1]
+    for k in results[0][0]:
+        assert np.array_equal(results[0][0][k], results[1][0][k]), k
