@@ -55,7 +55,7 @@ __device__ __forceinline__ void dense_fields_uniform_body(int blk, const int32_t
   float sw[4] = {0.f, 0.f, 0.f, 0.f}, sb[4] = {0.f, 0.f, 0.f, 0.f};
   if (jq * 4 < D) {
     const float* g = g_field + static_cast<int64_t>(f) * D + jq * 4;
-#pragma unroll 4
+#pragma unroll 8
     for (int64_t b = threadIdx.x; b < B; b += 256) {
       const float4 v = ld4(g + b * F * D);
       const float xb = x[b];

@@ -182,6 +182,7 @@ __global__ __launch_bounds__(kApThreads) void bn_relu_dropout_apply_kernel(
   const int T = (M + 31) / 32;
   const float4 m0v = ld4(partial + cc);         // tile 0's means: the shift
   float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+#pragma unroll 4
   for (int t = rl; t < T; t += kApRowLanes) {
     const float cnt = static_cast<float>(M - 32 * t < 32 ? M - 32 * t : 32);
     const float4 mt = ld4(partial + (static_cast<int64_t>(t) * 2 + 0) * N + cc);
@@ -259,6 +260,7 @@ __global__ __launch_bounds__(kApThreads) void bn_bwd_apply_kernel(
   const bool okc = c < N;
   const int cc = okc ? c : 0;
   float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+#pragma unroll 4
   for (int t = rl; t < T; t += kApRowLanes) {
     const float4 a = ld4(partial + static_cast<int64_t>(t) * stride + cc);
     const float4 b = ld4(partial + static_cast<int64_t>(t) * stride + off1 + cc);
@@ -274,6 +276,7 @@ __global__ __launch_bounds__(kApThreads) void bn_bwd_apply_kernel(
     }
     if (head.enabled) {     // third plane (d logit * a) for these columns; the two scalars from column tile 0
       float4 s3 = make_float4(0.f, 0.f, 0.f, 0.f), s4 = s3;
+#pragma unroll 4
       for (int t = rl; t < T; t += kApRowLanes) {
         const float4 a = ld4(partial + static_cast<int64_t>(t) * stride + 2 * off1 + cc);
         s3.x += a.x; s3.y += a.y; s3.z += a.z; s3.w += a.w;
