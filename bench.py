@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--unpacked", action="store_true", help="keep the tables as separate contiguous tensors")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--h2d", action="store_true",
+                    help="batches start in HOST memory and go through the packed H2D ring (PCIe-inclusive rate; "
+                         "reported in DESIGN.md, never the headline value)")
     return ap.parse_args()
 
 
@@ -155,9 +158,19 @@ def main():
     step.load_packed(records[0])
     step.capture()
 
+    feed = None
+    if args.h2d:
+        from deepfm_amd.data.packed import DeviceBatchRing, PackedBatchLoader, PackedColumns
+        names_s = [f["name"] for f in fields if f["type"] == "sparse"]
+        names_d = [f["name"] for f in fields if f["type"] == "dense"]
+        feats = {n: ids[:, j].reshape(-1).cpu().numpy() for j, n in enumerate(names_s)}
+        feats.update({n: dense[:, j].reshape(-1).cpu().numpy() for j, n in enumerate(names_d)})
+        loader = PackedBatchLoader(PackedColumns(model.schema, feats, labels.reshape(-1).cpu().numpy()), B)
+        feed = iter(DeviceBatchRing(loader, dev, depth=4))
+
     def run(i, timed):
         # the gather reads batch i from its record and refreshes the step's static inputs on the way
-        step.run_from(records[i])
+        step.run_from(next(feed) if feed is not None else records[i])
 
     import ctypes as C
     from deepfm_amd import _lib
@@ -216,6 +229,7 @@ def main():
                 "global_batch": B * world,
                 "parallelism": f"dp{world}",
                 "hip_graph": not args.no_graph,
+                "input": "host memory -> pinned staging -> H2D ring (PCIe-inclusive)" if args.h2d else "resident in HBM",
                 "step": "fused tower kernels (no autograd)" if fused else "torch.autograd over the HIP ops",
                 **({"rehearsal": "gloo, all ranks on cuda:0 (not a measurement)"} if rehearsal else {}),
                 "table_layout": "separate tensors" if args.unpacked else "packed 256-B row records",
