@@ -193,3 +193,42 @@ class RowSparseAdam:
     def step(self) -> None:
         self.exchange()
         self.apply()
+
+    # ------------------------------------------------------------------ checkpointing
+    def _named(self):
+        names = {id(p): n for n, p in self.model.named_parameters()}
+        return [(names[id(p)], p) for p in self._tables], [(names[id(p)], p) for p in self.dense_params]
+
+    def state_dict(self) -> dict:
+        """Adam state keyed by parameter NAME (``exp_avg`` / ``exp_avg_sq`` with the parameter's
+        shape, like ``torch.optim.Adam``'s per-parameter state) plus the shared step count."""
+        tables, dense = self._named()
+        state = {}
+        for (name, _), m, v in zip(tables, self.exp_avg, self.exp_avg_sq):
+            state[name] = {"exp_avg": m.detach().clone().contiguous(), "exp_avg_sq": v.detach().clone().contiguous()}
+        off = 0
+        for name, p in dense:
+            n = p.numel()
+            state[name] = {"exp_avg": self.flat_m[off:off + n].view_as(p).clone(),
+                           "exp_avg_sq": self.flat_v[off:off + n].view_as(p).clone()}
+            off += (n + 15) // 16 * 16
+        return {"step": int(self.step_count.item()), "state": state,
+                "hyper": {"lr": self.lr, "betas": list(self.betas), "eps": self.eps, "l2": self.l2,
+                          "max_grad_norm": self.max_grad_norm}}
+
+    def load_state_dict(self, sd: dict) -> None:
+        tables, dense = self._named()
+        want = {n for n, _ in tables} | {n for n, _ in dense}
+        if set(sd["state"]) != want:
+            raise KeyError(f"optimizer state keys differ: {sorted(set(sd['state']) ^ want)[:5]} ...")
+        with torch.no_grad():
+            for (name, _), m, v in zip(tables, self.exp_avg, self.exp_avg_sq):
+                m.copy_(sd["state"][name]["exp_avg"])
+                v.copy_(sd["state"][name]["exp_avg_sq"])
+            off = 0
+            for name, p in dense:
+                n = p.numel()
+                self.flat_m[off:off + n].copy_(sd["state"][name]["exp_avg"].reshape(-1))
+                self.flat_v[off:off + n].copy_(sd["state"][name]["exp_avg_sq"].reshape(-1))
+                off += (n + 15) // 16 * 16
+            self.step_count.fill_(int(sd["step"]))
