@@ -22,6 +22,7 @@ def digest(t: torch.Tensor) -> str:
 def main():
     use_graph = sys.argv[1] == "graph"
     steps = int(sys.argv[2])
+    fused = len(sys.argv) > 3 and sys.argv[3] == "fused"
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
@@ -43,7 +44,11 @@ def main():
     model.embedding.pack_tables_()
     model.embedding.set_grad_mode("rowsparse")
     opt = RowSparseAdam(model, lr=1e-2, l2=1e-5, max_grad_norm=1.0)
-    step = RowSparseTrainStep(model, opt, B, use_graph=use_graph)
+    if fused:
+        from deepfm_amd.training.fused_step import FusedDeepFMStep
+        step = FusedDeepFMStep(model, opt, B, use_graph=use_graph)        # what bench.py runs
+    else:
+        step = RowSparseTrainStep(model, opt, B, use_graph=use_graph)
     g = torch.Generator(device=dev).manual_seed(100 + rank)          # a different shard per rank
     ids = torch.randint(0, V, (steps + 1, 26, B), generator=g, device=dev, dtype=torch.int64)
     dense = torch.rand((steps + 1, 13, B), generator=g, device=dev)

@@ -20,11 +20,12 @@ def _free_port():
         return s.getsockname()[1]
 
 
+@pytest.mark.parametrize("kind", ["fused", "autograd"])
 @pytest.mark.parametrize("mode", ["graph", "eager"])
-def test_two_ranks_stay_bit_identical(mode):
+def test_two_ranks_stay_bit_identical(mode, kind):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-           os.path.join(ROOT, "tests", "dp_rehearsal_worker.py"), mode, "4"]
+           os.path.join(ROOT, "tests", "dp_rehearsal_worker.py"), mode, "4", kind]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-3000:]
