@@ -1,6 +1,6 @@
 // Fused BatchNorm1d(train) -> ReLU -> Dropout for the DNN tower
 // (reference deepfm/models/layers/dnn.py:45-55: Linear -> BatchNorm1d -> act -> Dropout).
-// The Linear GEMMs stay on rocBLAS; everything between them is three small launches forward
+// (autograd form of the tower; the Linear GEMMs are dfm_gemm_f32) — three small launches forward
 // and three backward instead of ~12 elementwise/reduction launches per layer:
 //   fwd : partial column sums over 16-row slices -> finalize (mean, rstd, running statistics
 //         like nn.BatchNorm1d: unbiased variance, momentum, num_batches_tracked) ->

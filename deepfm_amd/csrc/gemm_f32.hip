@@ -11,12 +11,10 @@
 // v_mfma_f32_32x32x2_f32: fp32 inputs, fp32 accumulate — bit-for-bit a k-ordered fmaf chain
 // (MI355X_MICROARCH.md, matrix cores), 64 FLOP/clk/SIMD = the fp32 vector peak, so nothing is
 // rounded to bf16 and the 1e-4 parity bar is untouched.  The shapes are small (batch 4096 x
-// <= 1024), so the tile is small too: a workgroup of 4 waves owns a 64 x 64 output tile (one
-// 32 x 32 MFMA tile per wave) — 1024 waves for the 4096 x 256 layer — and stages 64 x 32 slices
-// of A and B through LDS (coalesced 16-byte global loads in either layout, padded rows so the
-// per-lane fragment reads are conflict-free), double buffered.  Small outputs with a long
-// reduction (dW: reduce over the batch) are split over workgroup rows into slabs that are added
-// in a fixed order.
+// <= 1024), so the tile is small too: a workgroup of 8 waves owns a 64 x 64 output tile (four
+// 32 x 32 MFMA tiles x two k-halves; gemm_core.h has the tile loop, shared with the fused tower
+// kernels of tower.hip).  Small outputs with a long reduction (dW: reduce over the batch) are
+// split over workgroup rows into slabs that are added in a fixed order.
 #include "gemm_core.h"
 
 using namespace dfm;

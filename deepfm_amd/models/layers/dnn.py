@@ -1,12 +1,14 @@
 """DNN tower (reference ``deepfm/models/layers/dnn.py:9-59``).
 
-Not one of the four hot-path layers (SURVEY.md §2 keeps it on ``torch.nn``): same
-constructor, ``mlp`` ``nn.Sequential`` and ``dnn.mlp.<i>`` state_dict layout —
-``[Linear, (BatchNorm1d), activation, Dropout] * n``.  The Linear GEMMs of the fused path run on the exact-fp32
-MFMA kernel ``dfm_gemm_f32`` (no transposes, no precision loss); the fallback path uses torch.  On an MI355X, in training mode with BatchNorm + ReLU (the reference
-default), the BatchNorm -> ReLU -> Dropout chain between two GEMMs runs as the fused HIP
-kernels ``dfm_bn_relu_dropout_forward/backward`` (two launches each way
-instead of about a dozen); every other configuration uses the plain ``nn.Sequential``.
+Not one of the four hot-path layers (row f-2): same constructor, ``mlp``
+``nn.Sequential`` and ``dnn.mlp.<i>`` state_dict layout — ``[Linear, (BatchNorm1d), activation,
+Dropout] * n``.  Under autograd, on an MI355X in training mode with BatchNorm + ReLU (the reference
+default), a layer runs as ``_LinearBnReluDropoutFn``: the three Linear GEMMs on the exact-fp32 MFMA
+kernel ``dfm_gemm_f32`` (no transposes, no precision loss) and the BatchNorm -> ReLU -> Dropout chain
+on the fused HIP kernels ``dfm_bn_relu_dropout_forward/backward``; every other configuration
+(eval mode, other activations, no BatchNorm) uses the plain ``nn.Sequential``.  The training step of
+DeepFM does not come through here at all: ``deepfm_amd.training.fused_step`` drives the same
+parameters with the launch-fused tower kernels of ``csrc/tower.hip``.
 """
 
 from __future__ import annotations
@@ -37,7 +39,7 @@ def _grad_target(p: torch.Tensor):
 
 
 class _LinearBnReluDropoutFn(torch.autograd.Function):
-    """One DNN layer: Linear (rocBLAS) -> BatchNorm1d(train) -> ReLU -> Dropout (fused HIP).
+    """One DNN layer: Linear (dfm_gemm_f32) -> BatchNorm1d(train) -> ReLU -> Dropout (fused HIP).
 
     Backward writes parameter gradients straight into existing ``.grad`` buffers
     (``addmm_`` with beta = 1 for dW, ``+=`` inside the BN kernels) and returns ``None`` for

@@ -332,7 +332,7 @@ class FeatureEmbedding(nn.Module):
         S = len(self._sparse_pos)
         rs = self.rowsparse
         fmap = (C.c_int32 * max(S, 1))(*self._sparse_pos)
-        if dense_grads and self._plan_uniform and g_fe.data_ptr() % 16 == 0:
+        if dense_grads and self._plan_uniform and g_fe.data_ptr() % 16 == 0 and self._all_dense_grads(dense_grads):
             # DENSE-field gradients and row gradients in ONE launch (csrc/step_tail.hip)
             if self._dense_list is None or self._dense_list.device != g_fe.device:
                 pos = [i for i, sp in enumerate(self.schema.fields.values()) if sp.feature_type is FeatureType.DENSE]
@@ -356,6 +356,14 @@ class FeatureEmbedding(nn.Module):
                 rs.seg_start.data_ptr(), rs.num_uniq.data_ptr(), rs.row_g2.data_ptr(),
                 rs.row_g1.data_ptr(), _lib.stream_handle()))
             rs.has_grad = True
+
+    def _all_dense_grads(self, grads: Dict[int, torch.Tensor]) -> bool:
+        """Every DENSE field has all four gradient buffers (the grouped launch does not re-check)."""
+        for _, spec, second, first, _ in self._field_params():
+            if spec.feature_type is FeatureType.DENSE:
+                if any(id(p) not in grads for p in (second.weight, second.bias, first.weight, first.bias)):
+                    return False
+        return True
 
     def _grad_struct(self, grads: Dict[int, torch.Tensor]):
         """dfm_field_grad[] from {id(param): grad tensor}."""
