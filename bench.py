@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly")
     ap.add_argument("--autograd", action="store_true", help="torch.autograd step instead of the fused tower kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather-timing", action="store_true",
+                    help="do not attach HIP events to the gather dispatches (roofline fields become null)")
     ap.add_argument("--unpacked", action="store_true", help="keep the tables as separate contiguous tensors")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--h2d", action="store_true",
@@ -181,7 +183,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     # every gather launch of the timed region carries HIP start/stop events around the dispatch
-    _lib.check(lib.dfm_gather_timing_begin(args.steps))
+    if not args.no_gather_timing:
+        _lib.check(lib.dfm_gather_timing_begin(args.steps))
     t0 = time.perf_counter()
     for i in range(args.warmup, total):
         run(i, False)
@@ -197,11 +200,12 @@ def main():
 
     us = (C.c_float * args.steps)()
     n_timed = C.c_int(0)
-    _lib.check(lib.dfm_gather_timing_end(us, args.steps, C.byref(n_timed)))
+    if not args.no_gather_timing:
+        _lib.check(lib.dfm_gather_timing_end(us, args.steps, C.byref(n_timed)))
     gather_us = [float(us[i]) for i in range(n_timed.value)]
     gather_avg_s = (sum(gather_us) / len(gather_us)) * 1e-6 if gather_us else float("nan")
     algo_bytes = gather_bytes_per_sample(n_sparse, n_dense, D) * B
-    achieved = algo_bytes / gather_avg_s / 1e9
+    achieved = algo_bytes / gather_avg_s / 1e9 if gather_us else None
 
     pmc = None
     pmc_path = os.path.join(ROOT, "profiles", "r01_gather_pmc.json")
@@ -241,10 +245,10 @@ def main():
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
+                "frac": achieved / HBM_PEAK_GBS if achieved else None,
                 "traffic": pmc["traffic_bytes_per_launch"] if pmc else None,
                 "algorithmic_bytes_per_launch": algo_bytes,
-                "avg_launch_us": gather_avg_s * 1e6,
+                "avg_launch_us": gather_avg_s * 1e6 if gather_us else None,
                 "min_launch_us": min(gather_us) if gather_us else None,
                 "launches_timed": len(gather_us),
                 "timer": "HIP start/stop events attached to every gather dispatch of the timed region "
