@@ -128,6 +128,11 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+    elif os.environ.get("DFM_FORCE_DP_PATH") == "1":
+        # one rank, real RCCL: the N > 1 step structure (graph A -> eager collectives -> graph B) on one GPU
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
 
     from deepfm_amd.config import ExperimentConfig
     from deepfm_amd.models import create_model
@@ -260,7 +265,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(model, fields, cfg, hp, ids[:8], dense[:8], labels[:8],
                                                args.cpu_seconds)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

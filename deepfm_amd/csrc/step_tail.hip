@@ -32,8 +32,13 @@ struct SlabTable {
 // boundaries and weights have a multiple of 4 elements, so a float4 belongs to at most one
 // slab-backed weight; its slabs are added in order (8 loads in flight) before the L2 term.
 constexpr int kStepPrepPerThread = 4;
+//
+// Data parallel: `gathered` holds every rank's dense gradient buffer (world x n, rank-major, from the
+// step's single all-gather); the mean over ranks is formed here, in rank order — an all-reduce whose
+// summation order is fixed, at the cost of no extra launch.
 __device__ __forceinline__ void dense_prepare_slabs_body(int blk, float* __restrict__ g, const float* __restrict__ p,
                                                          int64_t n, int64_t n_l2, float l2, const SlabTable& st,
+                                                         const float* __restrict__ gathered, int world, float scale,
                                                          float* __restrict__ partial) {
   const int64_t i = (static_cast<int64_t>(blk) * kTailThreads + threadIdx.x) * kStepPrepPerThread;
   float sq = 0.f;
@@ -41,6 +46,15 @@ __device__ __forceinline__ void dense_prepare_slabs_body(int blk, float* __restr
   if (i + 3 < n) {
     float4 gi = ld4(g + i);
     bool dirty = false;
+    if (gathered) {
+      gi = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int r = 0; r < world; ++r) {
+        const float4 t = ld4(gathered + static_cast<int64_t>(r) * n + i);
+        gi.x += t.x; gi.y += t.y; gi.z += t.z; gi.w += t.w;
+      }
+      gi.x *= scale; gi.y *= scale; gi.z *= scale; gi.w *= scale;
+      dirty = true;
+    }
     for (int r = 0; r < st.count; ++r) {
       const int64_t off = (g + i) - st.g[r];
       if (off >= 0 && off < st.elems[r]) {
@@ -72,6 +86,12 @@ __device__ __forceinline__ void dense_prepare_slabs_body(int blk, float* __restr
   } else {
     for (int64_t e = i; e < n; ++e) {
       float ge = g[e];
+      if (gathered) {
+        ge = 0.f;
+        for (int r = 0; r < world; ++r) ge += gathered[static_cast<int64_t>(r) * n + e];
+        ge *= scale;
+        g[e] = ge;
+      }
       if (e < n_l2) { ge = fmaf(k, p[e], ge); g[e] = ge; }
       sq = fmaf(ge, ge, sq);
     }
@@ -103,13 +123,15 @@ __global__ __launch_bounds__(kTailThreads) void step_prepare_kernel(
     int merge_blocks, TableArgs tabs, int S, int D, int L, const int32_t* __restrict__ uniq_rows,
     const int32_t* __restrict__ num_uniq, float* __restrict__ row_g2, float* __restrict__ row_g1,
     int32_t* __restrict__ owner_flag, float grad_scale, float l2, float* __restrict__ g, const float* __restrict__ p,
-    int64_t n, int64_t n_l2, SlabTable slabs, float* __restrict__ partial, const uint8_t* __restrict__ match) {
+    int64_t n, int64_t n_l2, SlabTable slabs, const float* __restrict__ dense_gathered, int world,
+    float* __restrict__ partial, const uint8_t* __restrict__ match) {
   const int blk = blockIdx.x;
   if (blk < merge_blocks)
     rowadam_merge_body(blk, tabs, S, D, L, uniq_rows, num_uniq, row_g2, row_g1, owner_flag, grad_scale, l2, partial,
                        match);
   else
-    dense_prepare_slabs_body(blk - merge_blocks, g, p, n, n_l2, l2, slabs, partial + merge_blocks);
+    dense_prepare_slabs_body(blk - merge_blocks, g, p, n, n_l2, l2, slabs, dense_gathered, world, grad_scale,
+                             partial + merge_blocks);
 }
 
 __global__ __launch_bounds__(kTailThreads) void step_apply_kernel(
@@ -209,7 +231,8 @@ extern "C" int dfm_step_prepare(const dfm_table* tables, int num_sparse, int dim
                                 const int32_t* d_uniq_rows, const int32_t* d_num_uniq, float* d_row_g2,
                                 float* d_row_g1, int32_t* d_owner_flag, float grad_scale, float l2, float* d_g,
                                 const float* d_p, int64_t n, int64_t n_l2, const dfm_slab_ref* slabs, int num_slabs,
-                                float* d_partials, void* d_match, dfm_stream_t stream) {
+                                const float* d_dense_gathered, int world, float* d_partials, void* d_match,
+                                dfm_stream_t stream) {
   DFM_REQUIRE(tables && d_uniq_rows && d_num_uniq && d_row_g2 && d_row_g1 && d_owner_flag && d_partials && d_g && d_p,
               "null argument");
   DFM_REQUIRE(num_sparse > 0 && num_sparse <= DFM_MAX_FIELDS && num_lists > 0, "bad sizes");
@@ -218,6 +241,8 @@ extern "C" int dfm_step_prepare(const dfm_table* tables, int num_sparse, int dim
   DFM_REQUIRE((reinterpret_cast<uintptr_t>(d_g) & 63) == 0 && (reinterpret_cast<uintptr_t>(d_p) & 15) == 0,
               "dense buffers must be 64-byte aligned");
   DFM_REQUIRE(num_slabs >= 0 && num_slabs <= kMaxSlabs && (num_slabs == 0 || slabs), "0..%d slab references", kMaxSlabs);
+  DFM_REQUIRE(!d_dense_gathered || (world >= 1 && (reinterpret_cast<uintptr_t>(d_dense_gathered) & 15) == 0 && n % 4 == 0),
+              "gathered dense gradients: world >= 1, 16-byte aligned, n a multiple of 4");
   TableArgs ta;
   if (int rc = fill_tables(tables, num_sparse, dim, &ta, false)) return rc;
   SlabTable st = {};
@@ -246,7 +271,8 @@ extern "C" int dfm_step_prepare(const dfm_table* tables, int num_sparse, int dim
   }
   hipLaunchKernelGGL(step_prepare_kernel, dim3(static_cast<unsigned>(mb + pb)), dim3(kTailThreads), 0,
                      as_stream(stream), static_cast<int>(mb), ta, num_sparse, dim, num_lists, d_uniq_rows, d_num_uniq,
-                     d_row_g2, d_row_g1, d_owner_flag, grad_scale, l2, d_g, d_p, n, n_l2, st, d_partials, match);
+                     d_row_g2, d_row_g1, d_owner_flag, grad_scale, l2, d_g, d_p, n, n_l2, st, d_dense_gathered, world,
+                     d_partials, match);
   DFM_LAUNCH_CHECK();
   return DFM_OK;
 }

@@ -1,12 +1,14 @@
 """Data-parallel gradient exchange of the row-sparse step (one process per GPU, tables replicated).
 
-Two collectives per step, nothing else crosses ranks:
-  * ``allreduce_flat``     — one all-reduce(SUM) of the flat dense-gradient buffer;
-  * ``allgather_row_lists`` — all-gather of every rank's row lists (distinct ids, their count,
-    one gradient row + one first-order scalar per id).  The result is rank-major, so list
-    ``l = rank * chunks + chunk``; every rank then runs the same deterministic merge
-    (csrc/rowadam.hip: the first list holding a row owns it and adds the other lists'
-    rows in list order), which keeps the replicas bit-identical without atomics.
+ONE (coalesced) all-gather per step, nothing else crosses ranks:
+  * ``allgather_step`` — the flat dense-gradient buffer and every rank's row lists (distinct ids,
+    their count, one gradient row + one first-order scalar per id) in a single grouped launch.  The
+    results are rank-major, so list ``l = rank * chunks + chunk``; every rank then runs the same
+    deterministic merge (csrc/tail_bodies.h: the first list holding a row owns it and adds the other
+    lists' rows in list order) and the same rank-ordered sum of the dense gradients
+    (csrc/step_tail.hip), which keeps the replicas bit-identical without atomics.
+  * ``allreduce_flat`` / ``allgather_row_lists`` — the same exchange as separate collectives (kept
+    for backends without coalescing and for the CPU tests).
 On the GPU the backend is RCCL ("nccl") over xGMI; the same code runs on gloo/CPU in the tests.
 """
 
@@ -38,3 +40,19 @@ def allgather_row_lists(local: Sequence[torch.Tensor], out: Sequence[torch.Tenso
     """local[i] has shape (chunks, ...); out[i] (world*chunks, ...) receives rank-major copies."""
     for dst, src in zip(out, local):
         dist.all_gather_into_tensor(dst, src.contiguous(), group=group)
+
+
+def allgather_step(local: Sequence[torch.Tensor], out: Sequence[torch.Tensor],
+                   group: Optional[dist.ProcessGroup] = None) -> None:
+    """All tensors of ``local`` all-gathered into ``out`` (``out[i]`` is ``(world * local[i].shape[0], ...)``)
+    as ONE grouped collective launch where the backend supports it (RCCL: ncclGroupStart/End around the
+    all-gathers), else one collective per tensor.  Every tensor must be contiguous."""
+    from torch.distributed import distributed_c10d as c10d
+    try:
+        with c10d._coalescing_manager(group=group):
+            for dst, src in zip(out, local):
+                dist.all_gather_into_tensor(dst, src, group=group)
+    except (NotImplementedError, RuntimeError, AttributeError):
+        c10d._world.pg_coalesce_state.pop(group or c10d._get_default_group(), None)
+        for dst, src in zip(out, local):
+            dist.all_gather_into_tensor(dst, src, group=group)

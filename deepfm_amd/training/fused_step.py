@@ -159,7 +159,7 @@ class FusedDeepFMStep(RowSparseTrainStep):
             r, lin = refs[i], self.lin[i]
             r.workspace, r.g_w = self.ws_lin[i].data_ptr(), lin.weight.grad.data_ptr()
             r.batch, r.out_features, r.in_features = B, lin.out_features, lin.in_features
-        if self.opt.world == 1:
+        if not self.opt.split:
             self.opt.slab_refs = (refs, self.L)      # summed by the optimizer's prepare launch
         else:
             _lib.check(lib.dfm_linear_backward_finish(refs, self.L, st))    # must precede the all-reduce

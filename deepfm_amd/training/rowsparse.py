@@ -48,6 +48,12 @@ class RowSparseAdam:
         self.max_grad_norm = max_grad_norm
         self.group = process_group
         self.world = exchange.world_size(process_group)
+        # DFM_FORCE_DP_PATH=1 with an initialised (even single-rank) process group: take the N > 1 code
+        # path — two graphs around eager collectives — so that RCCL and its interplay with graph capture
+        # can be exercised on a one-GPU box
+        import os
+        self.split = self.world > 1 or (os.environ.get("DFM_FORCE_DP_PATH") == "1" and dist.is_available()
+                                        and dist.is_initialized())
 
         tables = emb.table_parameters()
         if not tables:
@@ -145,14 +151,17 @@ class RowSparseAdam:
         if rs is None or not rs.has_grad:
             raise RuntimeError("RowSparseAdam: no row gradients (run a backward pass first)")
         local = (rs.uniq_rows, rs.num_uniq, rs.row_g2, rs.row_g1)
-        if self.world == 1:
+        if not self.split:
             self._cur = local + (rs.chunks,)
             return
-        exchange.allreduce_flat(self.flat_grad, self.group)
-        if self._gathered is None or self._gathered[0].shape[0] != self.world * rs.chunks:
-            self._gathered = exchange.alloc_gathered(local, self.world)
-        exchange.allgather_row_lists(local, self._gathered, self.group)
-        self._cur = self._gathered + (self.world * rs.chunks,)
+        # one grouped all-gather: [dense gradient buffer | row lists]; the dense mean over ranks is formed
+        # by the optimizer's prepare launch in rank order (no all-reduce, no scaling launch)
+        world = max(self.world, 1)
+        full = (self.flat_grad.view(1, -1),) + local
+        if self._gathered is None or self._gathered[1].shape[0] != world * rs.chunks:
+            self._gathered = exchange.alloc_gathered(full, world)
+        exchange.allgather_step(full, self._gathered, self.group)
+        self._cur = self._gathered[1:] + (world * rs.chunks,)
 
     @torch.no_grad()
     def apply(self) -> None:
@@ -169,16 +178,17 @@ class RowSparseAdam:
             self._partials = torch.zeros(n_partials, dtype=torch.float32, device=self.device)
             mbytes = lib.dfm_step_match_bytes(self.num_sparse, lists)
             self._match = torch.empty(mbytes, dtype=torch.uint8, device=self.device) if mbytes else None
-        if self.world > 1:
-            self.flat_grad.mul_(grad_scale)          # mean over ranks (loss is a per-rank mean)
+        dense_gathered = self._gathered[0] if (self.split and self._gathered is not None and self._cur is not None
+                                               and self._cur[0] is self._gathered[1]) else None
         tabs = self._table_struct()
-        refs, n_refs = self.slab_refs if (self.slab_refs is not None and self.world == 1) else (None, 0)
+        refs, n_refs = self.slab_refs if (self.slab_refs is not None and not self.split) else (None, 0)
         # three launches: [row-list merge | dense L2 (+ d-weight slabs) + norm partials] -> clip coefficient
         # (+ step / seed tick) -> [row-wise Adam | dense Adam (+ clears the gradient buffer)]
         _lib.check(lib.dfm_step_prepare(tabs, self.num_sparse, self.dim, lists, uniq.data_ptr(), num.data_ptr(),
                                         g2.data_ptr(), g1.data_ptr(), self._owner.data_ptr(), grad_scale, self.l2,
                                         self.flat_grad.data_ptr(), self.flat_param.data_ptr(), n_dense, self.n_l2,
-                                        refs, n_refs, self._partials.data_ptr(), _lib.ptr(self._match), stream))
+                                        refs, n_refs, _lib.ptr(dense_gathered), max(self.world, 1),
+                                        self._partials.data_ptr(), _lib.ptr(self._match), stream))
         _lib.check(lib.dfm_grad_norm_finalize(self._partials.data_ptr(), n_partials,
                                               self.max_grad_norm or 0.0, self.sq_norm.data_ptr(),
                                               self.clip_coef.data_ptr(), self.step_count.data_ptr(),

@@ -145,7 +145,7 @@ class RowSparseTrainStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self._gather()
-        single = self.opt.world == 1
+        single = not self.opt.split
         # thread_local capture mode: another thread (the RCCL watchdog polling its events under
         # data parallelism) must not invalidate the capture
         mode = dict(capture_error_mode="thread_local")

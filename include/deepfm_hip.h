@@ -449,14 +449,18 @@ int dfm_step_embedding_backward(const int32_t* d_dense_list, int num_dense, cons
  * dfm_linear_backward_finish).  d_partials: dfm_step_prepare_num_partials floats, to be summed by
  * dfm_grad_norm_finalize.  d_match (optional, dfm_step_match_bytes): with three or more lists the
  * memberships of every row in the other lists are resolved first by one extra launch through LDS
- * (the merge then does byte reads instead of num_lists - 1 global binary searches per row). */
+ * (the merge then does byte reads instead of num_lists - 1 global binary searches per row).
+ * d_dense_gathered (optional, data parallel): (world, n) — every rank's dense gradient buffer from
+ * the step's all-gather; d_g is then REPLACED by grad_scale * their sum in rank order (an
+ * all-reduce with a fixed summation order and no launch of its own). */
 int64_t dfm_step_prepare_num_partials(int num_sparse, int dim, int num_lists, int64_t n);
 size_t dfm_step_match_bytes(int num_sparse, int num_lists);
 int dfm_step_prepare(const dfm_table* tables, int num_sparse, int dim, int num_lists,
                      const int32_t* d_uniq_rows, const int32_t* d_num_uniq, float* d_row_g2,
                      float* d_row_g1, int32_t* d_owner_flag, float grad_scale, float l2, float* d_g,
                      const float* d_p, int64_t n, int64_t n_l2, const dfm_slab_ref* slabs, int num_slabs,
-                     float* d_partials, void* d_match, dfm_stream_t stream);
+                     const float* d_dense_gathered, int world, float* d_partials, void* d_match,
+                     dfm_stream_t stream);
 /* dfm_rowadam_apply + dfm_dense_adam in one launch. */
 int dfm_step_apply(const dfm_table* tables, int num_sparse, int dim, int num_lists,
                    const int32_t* d_uniq_rows, const int32_t* d_num_uniq, const float* d_row_g2,

@@ -71,6 +71,13 @@ def _worker(rank, world, port, ids, g2, g1, flat, out_dir):
     fg = torch.from_numpy(flat[rank].copy())
     exchange.allreduce_flat(fg)
     assert exchange.world_size() == world
+    # the step's single grouped all-gather (dense buffer + row lists) must deliver the same bytes
+    full = (torch.from_numpy(flat[rank].copy()).view(1, -1),) + local
+    gathered2 = exchange.alloc_gathered(full, world)
+    exchange.allgather_step(full, gathered2)
+    for a, b in zip(gathered, gathered2[1:]):
+        assert torch.equal(a, b)
+    assert torch.equal(gathered2[0], torch.from_numpy(flat[:world]))
     merged = _merge(*(t.numpy() for t in gathered), 1.0 / world)
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), flat=fg.numpy() / world,
              **{f"u{s}": np.array(sorted(merged[s])) for s in range(S)},
