@@ -10,7 +10,7 @@
 //   forward, per layer   linear_bn_fwd        z = x W^T + b on the exact-fp32 MFMA tile loop
 //                                             (gemm_core.h); the epilogue leaves per-column
 //                                             (mean, M2) of each 32-row MFMA tile in a workspace
-//                        bn_relu_dropout_apply a workgroup owns 64 columns x 64 rows: it first merges
+//                        bn_relu_dropout_apply a workgroup owns 64 columns x 32 rows: it first merges
 //                                             the tile statistics of its columns (Chan, fixed order,
 //                                             L2-resident) -> mean, rstd (+ running statistics from
 //                                             the row-group-0 workgroups), then
@@ -99,7 +99,7 @@ __device__ __forceinline__ void bn_mask_tile(const BnBwd& bn, const f32x16& g, c
 
 // ---- column-tile workgroups of the apply kernels ------------------------------------------------
 // 256 threads = 16 column lanes (one float4 = 4 columns each: 64 columns) x 16 row lanes.
-constexpr int kApThreads = 256, kApCols = 64, kApRowLanes = 16, kApRows = 64;
+constexpr int kApThreads = 256, kApCols = 64, kApRowLanes = 16, kApRows = 32;
 
 // Per-column totals over the 16 row lanes of two float4 accumulators (fixed order), to every thread.
 __device__ __forceinline__ void row_lane_totals(float4& a, float4& b, float (*red)[kApRowLanes][kApCols]) {
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(kThreads) void linear_bn_fwd_kernel(
   }
 }
 
-// a = dropout(relu(gamma * (z - mean) * rstd + beta)) for 64 columns x 64 rows per workgroup, after
+// a = dropout(relu(gamma * (z - mean) * rstd + beta)) for 64 columns x 32 rows per workgroup, after
 // merging the (count, mean, M2) of the column's 32-row tiles (Chan's formula about tile 0's mean, so
 // nothing cancels).  grid (column tiles, row groups); row group 0 also publishes the statistics.
 __global__ __launch_bounds__(kApThreads) void bn_relu_dropout_apply_kernel(
@@ -246,7 +246,7 @@ struct HeadTail {
   int enabled;
 };
 
-// dz = gamma * rstd * (dy - mean(dy) - xhat * mean(dy * xhat)) for 64 columns x 64 rows per workgroup,
+// dz = gamma * rstd * (dy - mean(dy) - xhat * mean(dy * xhat)) for 64 columns x 32 rows per workgroup,
 // after merging the per-tile column sums of dy and dy*xhat: `partial` has T rows of `stride` floats,
 // the two planes at column offsets 0 and off1 (dx epilogue: [T][2][N]; head_bce: [blocks][3K+2]).
 // Row group 0 adds d gamma / d beta (and finishes the head's d w, d b, loss).  dz may alias dy.
