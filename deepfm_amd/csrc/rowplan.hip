@@ -13,13 +13,14 @@
 // order and write one gradient row: plain 16-byte stores, bitwise reproducible.
 #include "tail_bodies.h"
 
+#include <cstdlib>
+
 using namespace dfm;
 
 namespace {
 using tail::CH;
 constexpr int SORT_THREADS = 1024;
 constexpr int PER_THREAD = CH / SORT_THREADS;  // 4
-constexpr unsigned long long SENTINEL = ~0ull;
 
 struct IdTable {
   const int64_t* p[DFM_MAX_FIELDS];
@@ -28,10 +29,16 @@ struct IdTable {
 using tail::FieldMap;
 }  // namespace
 
+// KeyT = uint64 (id << 32 | pos) for any vocabulary, or uint32 (id << 12 | pos) when every id of the
+// launch fits 20 bits (vocabulary < 2^20 - 1: the 1M-row Criteo tables): the sort is LDS-bound
+// (78 compare-exchange sweeps over 4096 keys), so half the key bytes is close to half the time.
+template <typename KeyT, int SHIFT>
 __global__ __launch_bounds__(SORT_THREADS) void rowplan_sort(
     IdTable ids, int S, int64_t n, int32_t* __restrict__ sorted_pos, int32_t* __restrict__ uniq_rows,
-    int32_t* __restrict__ seg_start, int32_t* __restrict__ num_uniq, int32_t* error_flag) {
-  __shared__ unsigned long long keys[CH];
+    int32_t* __restrict__ seg_start, int32_t* __restrict__ num_uniq, int32_t* error_flag, int ablate) {
+  constexpr KeyT SENTINEL = static_cast<KeyT>(~static_cast<KeyT>(0));
+  constexpr KeyT POS_MASK = (static_cast<KeyT>(1) << SHIFT) - 1;
+  __shared__ KeyT keys[CH];
   __shared__ int wave_tot[SORT_THREADS / kWave];
   const int s = blockIdx.x, c = blockIdx.y;
   const int tid = threadIdx.x;
@@ -42,46 +49,72 @@ __global__ __launch_bounds__(SORT_THREADS) void rowplan_sort(
 
   // load (coalesced) and form keys
   for (int i = tid; i < CH; i += SORT_THREADS) {
-    unsigned long long k = SENTINEL;
+    KeyT k = SENTINEL;
     if (i < len) {
       const int64_t id = src[base + i];
       if (id < 0 || id >= vocab) {
         if (error_flag) atomicOr(error_flag, 1);
       } else if (id != 0) {
-        k = (static_cast<unsigned long long>(id) << 32) | static_cast<unsigned>(i);
+        k = (static_cast<KeyT>(id) << SHIFT) | static_cast<KeyT>(i);
       }
     }
     keys[i] = k;
   }
   __syncthreads();
 
-  // bitonic sort, ascending
-  for (int k = 2; k <= CH; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
+  // Bitonic sort, ascending.  Thread t holds keys [4t, 4t+4) in registers: compare-exchange partners
+  // at distance j < 4 are in the same thread, at 4 <= j <= 128 in the same wave (lane ^ j/4: one
+  // shuffle per key, no LDS traffic, no barrier), and only the 10 steps with j >= 256 (of 78) go
+  // through LDS with workgroup barriers.  (All-LDS: 36 us per chunk; this: see DESIGN.md.)
+  KeyT v[PER_THREAD];
 #pragma unroll
-      for (int r = 0; r < CH / 2 / SORT_THREADS; ++r) {
-        const int t = tid + r * SORT_THREADS;
-        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-        const int l = i | j;
-        const unsigned long long a = keys[i], b = keys[l];
-        const bool up = (i & k) == 0;
-        if ((a > b) == up) { keys[i] = b; keys[l] = a; }
+  for (int r = 0; r < PER_THREAD; ++r) v[r] = keys[tid * PER_THREAD + r];
+  static_assert(PER_THREAD == 4, "the register steps below are written for 4 keys per thread");
+  for (int k = 2; k <= ((ablate & 1) ? 0 : CH); k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      KeyT other[PER_THREAD];
+      if (j >= 256) {
+        __syncthreads();                                   // readers of the previous LDS step are done
+#pragma unroll
+        for (int r = 0; r < PER_THREAD; ++r) keys[tid * PER_THREAD + r] = v[r];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < PER_THREAD; ++r) other[r] = keys[(tid * PER_THREAD + r) ^ j];
+      } else if (j >= 4) {
+#pragma unroll
+        for (int r = 0; r < PER_THREAD; ++r) other[r] = __shfl_xor(v[r], j >> 2, kWave);
+      } else if (j == 2) {
+        other[0] = v[2]; other[1] = v[3]; other[2] = v[0]; other[3] = v[1];
+      } else {
+        other[0] = v[1]; other[1] = v[0]; other[2] = v[3]; other[3] = v[2];
       }
-      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < PER_THREAD; ++r) {
+        const int p = tid * PER_THREAD + r;
+        const bool lower = (p & j) == 0;                   // this element is the lower index of its pair
+        const bool up = (p & k) == 0;                      // ascending sub-sequence
+        const KeyT lo = v[r] < other[r] ? v[r] : other[r], hi = v[r] < other[r] ? other[r] : v[r];
+        v[r] = (lower == up) ? lo : hi;
+      }
     }
   }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < PER_THREAD; ++r) keys[tid * PER_THREAD + r] = v[r];
+  __syncthreads();
 
+  if (ablate & 2) return;
   // run heads over the valid prefix; thread owns PER_THREAD consecutive entries
   const int e0 = tid * PER_THREAD;
-  unsigned long long mine[PER_THREAD];
-  unsigned long long prev = e0 > 0 ? keys[e0 - 1] : SENTINEL;
+  KeyT mine[PER_THREAD];
+  KeyT prev = e0 > 0 ? keys[e0 - 1] : SENTINEL;
   int head[PER_THREAD];
   int cnt = 0, valid = 0;
 #pragma unroll
   for (int r = 0; r < PER_THREAD; ++r) {
     mine[r] = keys[e0 + r];
     const bool ok = mine[r] != SENTINEL;
-    const bool h = ok && (e0 + r == 0 || (mine[r] >> 32) != (prev >> 32));
+    const bool h = ok && (e0 + r == 0 || (mine[r] >> SHIFT) != (prev >> SHIFT));
     head[r] = h ? 1 : 0;
     cnt += head[r];
     valid += ok ? 1 : 0;
@@ -117,9 +150,9 @@ __global__ __launch_bounds__(SORT_THREADS) void rowplan_sort(
   for (int r = 0; r < PER_THREAD; ++r) {
     const int p = e0 + r;
     const bool ok = mine[r] != SENTINEL;
-    o_pos[p] = ok ? static_cast<int32_t>(base + (mine[r] & 0xffffffffu)) : -1;
+    o_pos[p] = ok ? static_cast<int32_t>(base + static_cast<int64_t>(mine[r] & POS_MASK)) : -1;
     if (head[r]) {
-      o_rows[slot] = static_cast<int32_t>(mine[r] >> 32);
+      o_rows[slot] = static_cast<int32_t>(mine[r] >> SHIFT);
       o_seg[slot] = p;
       ++slot;
     }
@@ -138,6 +171,9 @@ __global__ __launch_bounds__(256) void rowgrad_kernel(
   tail::rowgrad_body(blockIdx.x, fmap, S, F, D, lists, g_first, g_field, sorted_pos, seg_start, num_uniq, row_g2, row_g1);
 }
 
+// timing-only ablation (0 in every product call): 1 = skip the sort, 2 = skip the run-head / output phase
+static int g_rp_ablate = [] { const char* e = getenv("DFM_ROWPLAN_ABLATE"); return e ? atoi(e) : 0; }();
+
 extern "C" {
 
 int dfm_rowplan_build(const int64_t* const* ids, const int32_t* vocab, int num_sparse, int64_t n,
@@ -154,8 +190,16 @@ int dfm_rowplan_build(const int64_t* const* ids, const int32_t* vocab, int num_s
     t.vocab[s] = vocab[s];
   }
   const int chunks = static_cast<int>((n + CH - 1) / CH);
-  hipLaunchKernelGGL(rowplan_sort, dim3(num_sparse, chunks), dim3(SORT_THREADS), 0, as_stream(stream),
-                     t, num_sparse, n, d_sorted_pos, d_uniq_rows, d_seg_start, d_num_uniq, d_error_flag);
+  int max_vocab = 0;
+  for (int s = 0; s < num_sparse; ++s) max_vocab = vocab[s] > max_vocab ? vocab[s] : max_vocab;
+  static_assert(CH == 4096, "the 32-bit key packs the position into 12 bits");
+  if (max_vocab < (1 << 20) - 1)     // ids (< vocab) leave the all-ones key free for the sentinel
+    hipLaunchKernelGGL((rowplan_sort<uint32_t, 12>), dim3(num_sparse, chunks), dim3(SORT_THREADS), 0, as_stream(stream),
+                       t, num_sparse, n, d_sorted_pos, d_uniq_rows, d_seg_start, d_num_uniq, d_error_flag, g_rp_ablate);
+  else
+    hipLaunchKernelGGL((rowplan_sort<unsigned long long, 32>), dim3(num_sparse, chunks), dim3(SORT_THREADS), 0,
+                       as_stream(stream), t, num_sparse, n, d_sorted_pos, d_uniq_rows, d_seg_start, d_num_uniq,
+                       d_error_flag, g_rp_ablate);
   DFM_LAUNCH_CHECK();
   return DFM_OK;
 }

@@ -19,6 +19,7 @@ Eligible: DeepFM with the reference-default tower (BatchNorm + ReLU), hidden siz
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import List
 
 import torch
@@ -81,6 +82,7 @@ class FusedDeepFMStep(RowSparseTrainStep):
             self.ws_lin.append(_zeros_bytes(lib.dfm_linear_backward_workspace_bytes(B, n, k), dev))
         self.seed = torch.randint(1, 2 ** 40, (1,), dtype=torch.int64, device=dev)
         optimizer.seed_tick = self.seed          # advanced by the optimizer's norm-finalize kernel
+        self.rowplan_side_stream = os.environ.get("DFM_ROWPLAN_SIDE_STREAM") == "1"
         for p in list(dnn.parameters()) + list(model.output_linear.parameters()):
             if p.grad is None or not p.grad.is_contiguous():
                 raise RuntimeError("FusedDeepFMStep needs RowSparseAdam's flat gradient views on every dense parameter")
@@ -105,9 +107,17 @@ class FusedDeepFMStep(RowSparseTrainStep):
         lib, st, B = _lib.load(), _lib.stream_handle(), self.B
         self.opt.zero_grad()
         cur = torch.cuda.current_stream()
-        self.side.wait_stream(cur)
-        with torch.cuda.stream(self.side):
+        # The row plan (needs only the ids) runs IN LINE.  On a side stream it overlapped the forward
+        # "for free" — and cost more than its own 27 us: the concurrent sort slowed the widest GEMM by
+        # 7 us, and the fork/join put the graph on two hardware queues with ~10 us per cross-queue edge
+        # (measured 0.253 ms in line vs 0.255 overlapped when the sort still took 38 us).
+        inline = not self.rowplan_side_stream
+        if inline:
             self.emb.build_rowplan(self.inputs, B)
+        else:
+            self.side.wait_stream(cur)
+            with torch.cuda.stream(self.side):
+                self.emb.build_rowplan(self.inputs, B)
         # ---- forward ----
         x = self.x0
         for i in range(self.L):
@@ -163,5 +173,6 @@ class FusedDeepFMStep(RowSparseTrainStep):
             self.opt.slab_refs = (refs, self.L)      # summed by the optimizer's prepare launch
         else:
             _lib.check(lib.dfm_linear_backward_finish(refs, self.L, st))    # must precede the all-reduce
-        cur.wait_stream(self.side)
+        if not inline:
+            cur.wait_stream(self.side)
         self.emb.backward_rowsparse(self.inputs, self.g_logits, self.g_fe, self.dense_grads)

@@ -15,6 +15,7 @@ With one rank A and B are a single graph.  No host synchronisation inside a step
 
 from __future__ import annotations
 
+import os
 from typing import List, Optional
 
 import torch
@@ -113,8 +114,12 @@ class RowSparseTrainStep:
     def _body_a(self) -> None:
         self.opt.zero_grad()
         cur = torch.cuda.current_stream()
-        self.side.wait_stream(cur)
-        with torch.cuda.stream(self.side):
+        side = os.environ.get("DFM_ROWPLAN_SIDE_STREAM") == "1"    # see fused_step.py: in line is faster
+        if side:
+            self.side.wait_stream(cur)
+            with torch.cuda.stream(self.side):
+                self.emb.build_rowplan(self.inputs, self.B)
+        else:
             self.emb.build_rowplan(self.inputs, self.B)
         fo = self.fo.detach().requires_grad_()
         fe = self.fe.detach().requires_grad_()
@@ -123,7 +128,8 @@ class RowSparseTrainStep:
         loss = bce_with_logits_mean(logits.view(-1), self.labels)
         loss.backward()
         self.loss.copy_(loss.detach())
-        cur.wait_stream(self.side)
+        if side:
+            cur.wait_stream(self.side)
         self.emb.backward_rowsparse(self.inputs, fo.grad, fe.grad, self.dense_grads)
 
     def _body_b(self) -> None:

@@ -390,3 +390,45 @@ def test_run_from_record_equals_load_then_run(fused):
     assert results[0][1] == results[1][1]
     for k in results[0][0]:
         assert np.array_equal(results[0][0][k], results[1][0][k]), k
+
+
+@pytest.mark.parametrize("vocab", [1000, (1 << 20) - 2, (1 << 20) - 1, 3_000_000])
+def test_rowplan_key_widths_vs_oracle(vocab):
+    """dfm_rowplan_build sorts 32-bit keys (id << 12 | pos) when every vocabulary is below 2^20 - 1 and
+    64-bit keys otherwise: both against the oracle's ordered reduction, bit-exact, with duplicates,
+    padding ids, the largest id and an odd tail (two chunks)."""
+    from deepfm_amd import _lib
+    import ctypes as C
+    lib = _lib.load()
+    B, D, S, F = 5000, 16, 2, 3
+    rng = np.random.default_rng(vocab % 977)
+    ids = [rng.integers(1, vocab, size=B).astype(np.int64), rng.integers(1, min(vocab, 50), size=B).astype(np.int64)]
+    ids[0][:7] = [vocab - 1, vocab - 1, 0, 1, 0, vocab - 1, 1]
+    d_ids = [torch.from_numpy(a).cuda() for a in ids]
+    ch = _lib.ROWPLAN_CHUNK
+    chunks = (B + ch - 1) // ch
+    i32 = dict(dtype=torch.int32, device="cuda")
+    sorted_pos, uniq = torch.empty(chunks, S, ch, **i32), torch.empty(chunks, S, ch, **i32)
+    seg, num = torch.empty(chunks, S, ch + 1, **i32), torch.zeros(chunks, S, **i32)
+    err = torch.zeros(1, **i32)
+    ptrs = (C.c_void_p * S)(*[t.data_ptr() for t in d_ids])
+    voc = (C.c_int32 * S)(vocab, min(vocab, 50))
+    _lib.check(lib.dfm_rowplan_build(ptrs, voc, S, B, sorted_pos.data_ptr(), uniq.data_ptr(), seg.data_ptr(),
+                                     num.data_ptr(), err.data_ptr(), _lib.stream_handle()))
+    g_fe = rng.standard_normal((B, F, D)).astype(np.float32)
+    g_fo = rng.standard_normal((B, 1)).astype(np.float32)
+    row_g2 = torch.zeros(chunks, S, ch, D, device="cuda")
+    row_g1 = torch.zeros(chunks, S, ch, device="cuda")
+    fmap = (C.c_int32 * S)(0, 2)
+    _lib.check(lib.dfm_rowgrad_build(fmap, S, F, D, B, torch.from_numpy(g_fo).cuda().data_ptr(),
+                                     torch.from_numpy(g_fe).cuda().data_ptr(), sorted_pos.data_ptr(), seg.data_ptr(),
+                                     num.data_ptr(), row_g2.data_ptr(), row_g1.data_ptr(), _lib.stream_handle()))
+    assert int(err) == 0
+    for s, f in enumerate((0, 2)):
+        for c in range(chunks):
+            sl = slice(c * ch, min((c + 1) * ch, B))
+            u, r2, r1 = O.rowsparse_from_batch(ids[s][sl], g_fe[sl, f, :], g_fo[sl, 0])
+            n = int(num[c, s])
+            assert n == len(u)
+            assert np.array_equal(npy(uniq)[c, s, :n], u)
+            assert np.array_equal(npy(row_g2)[c, s, :n], r2) and np.array_equal(npy(row_g1)[c, s, :n], r1)
