@@ -62,6 +62,100 @@ __global__ __launch_bounds__(SORT_THREADS) void rowplan_sort(
   }
   __syncthreads();
 
+  // ---- fast path: counting sort over 4096 id buckets (32-bit keys only) -------------------------
+  // With ids spread over the vocabulary a bucket (id * 4096 / vocab: monotone in id, so bucket
+  // order is key order) holds about one key: histogram, exclusive scan, scatter into the bucket's
+  // range, then every key ranks itself among the handful of keys of its bucket.  LDS atomics decide
+  // only the transient slot inside a bucket; the final position depends on key comparisons alone, so
+  // the result is the same sorted array the bitonic network produces.  Skewed ids (any bucket with
+  // more than kMaxBucket keys) take the bitonic network below instead.
+  bool sorted = false;
+  if constexpr (sizeof(KeyT) == 4) {
+    constexpr int kMaxBucket = 16;
+    __shared__ int cnt[CH];        // keys per bucket, then the scatter cursor
+    __shared__ int start[CH];      // first output slot of every bucket
+    __shared__ KeyT tmp[CH];
+    __shared__ int wave_sum[SORT_THREADS / kWave];
+    __shared__ int s_max;
+#pragma unroll
+    for (int r = 0; r < PER_THREAD; ++r) cnt[tid * PER_THREAD + r] = 0;
+    if (tid == 0) s_max = 0;
+    __syncthreads();
+    KeyT mykey[PER_THREAD];
+    int mybucket[PER_THREAD];
+#pragma unroll
+    for (int r = 0; r < PER_THREAD; ++r) {
+      mykey[r] = keys[tid + r * SORT_THREADS];
+      mybucket[r] = -1;
+      if (mykey[r] != SENTINEL) {
+        const unsigned long long id = mykey[r] >> SHIFT;
+        mybucket[r] = static_cast<int>((id << 12) / static_cast<unsigned long long>(vocab));   // < 4096 since id < vocab
+        atomicAdd(&cnt[mybucket[r]], 1);
+      }
+    }
+    __syncthreads();
+    // exclusive scan of cnt over the block: thread t owns buckets [4t, 4t+4)
+    int c4[PER_THREAD], local = 0, mx = 0;
+#pragma unroll
+    for (int r = 0; r < PER_THREAD; ++r) {
+      c4[r] = cnt[tid * PER_THREAD + r];
+      local += c4[r];
+      mx = c4[r] > mx ? c4[r] : mx;
+    }
+    int incl = local;
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+      const int t = __shfl_up(incl, o, kWave);
+      if (lane_id() >= o) incl += t;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+      const int t = __shfl_xor(mx, m, kWave);
+      mx = t > mx ? t : mx;
+    }
+    if (lane_id() == kWave - 1) wave_sum[tid >> 6] = incl;
+    if (lane_id() == 0) atomicMax(&s_max, mx);
+    __syncthreads();
+    int woff = 0, total_valid = 0;
+    for (int i = 0; i < SORT_THREADS / kWave; ++i) {
+      if (i < (tid >> 6)) woff += wave_sum[i];
+      total_valid += wave_sum[i];
+    }
+    if (s_max <= kMaxBucket && !(ablate & 1)) {
+      int run = woff + incl - local;
+#pragma unroll
+      for (int r = 0; r < PER_THREAD; ++r) {
+        start[tid * PER_THREAD + r] = run;
+        cnt[tid * PER_THREAD + r] = 0;           // becomes the scatter cursor
+        run += c4[r];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < PER_THREAD; ++r)
+        if (mybucket[r] >= 0) tmp[start[mybucket[r]] + atomicAdd(&cnt[mybucket[r]], 1)] = mykey[r];
+      __syncthreads();
+      // every key places itself: rank among the keys of its bucket
+#pragma unroll
+      for (int r = 0; r < PER_THREAD; ++r) {
+        const int i = tid + r * SORT_THREADS;
+        KeyT out = SENTINEL;
+        int dst = i;                                // slots >= total_valid keep the sentinel
+        if (i < total_valid) {
+          out = tmp[i];
+          const int b = static_cast<int>(((static_cast<unsigned long long>(out >> SHIFT)) << 12) /
+                                         static_cast<unsigned long long>(vocab));
+          const int b0 = start[b], nb = cnt[b];
+          int rank = 0;
+          for (int q = 0; q < nb; ++q) rank += tmp[b0 + q] < out ? 1 : 0;
+          dst = b0 + rank;
+        }
+        keys[dst] = out;
+      }
+      __syncthreads();
+      sorted = true;
+    }
+  }
+
   // Bitonic sort, ascending.  Thread t holds keys [4t, 4t+4) in registers: compare-exchange partners
   // at distance j < 4 are in the same thread, at 4 <= j <= 128 in the same wave (lane ^ j/4: one
   // shuffle per key, no LDS traffic, no barrier), and only the 10 steps with j >= 256 (of 78) go
@@ -70,7 +164,7 @@ __global__ __launch_bounds__(SORT_THREADS) void rowplan_sort(
 #pragma unroll
   for (int r = 0; r < PER_THREAD; ++r) v[r] = keys[tid * PER_THREAD + r];
   static_assert(PER_THREAD == 4, "the register steps below are written for 4 keys per thread");
-  for (int k = 2; k <= ((ablate & 1) ? 0 : CH); k <<= 1) {
+  for (int k = 2; k <= ((sorted || (ablate & 1)) ? 0 : CH); k <<= 1) {
     for (int j = k >> 1; j > 0; j >>= 1) {
       KeyT other[PER_THREAD];
       if (j >= 256) {
