@@ -54,16 +54,27 @@ class _LinearBnReluDropoutFn(torch.autograd.Function):
         M, K = x.shape
         N = weight.shape[0]
         z = torch.empty(M, N, dtype=torch.float32, device=x.device)
-        _gemm(x, K, True, weight, K, True, z, M, N, K, bias=bias)                 # z = x W^T + b
         out = torch.empty_like(z)
         stats = torch.empty(2, N, dtype=torch.float32, device=z.device)
-        ws = torch.empty(max(lib.dfm_bn_workspace_bytes(M, N) // 4, 1), dtype=torch.float32, device=z.device)
         track = bn.track_running_stats and bn.running_mean is not None
-        _lib.check(lib.dfm_bn_relu_dropout_forward(
-            z.data_ptr(), M, N, gamma.data_ptr(), beta.data_ptr(),
-            bn.running_mean.data_ptr() if track else None, bn.running_var.data_ptr() if track else None,
-            bn.num_batches_tracked.data_ptr() if track else None, float(bn.momentum), float(bn.eps), float(p),
-            _lib.ptr(seed), salt, out.data_ptr(), stats.data_ptr(), ws.data_ptr(), _lib.stream_handle()))
+        rm = bn.running_mean.data_ptr() if track else None
+        rv = bn.running_var.data_ptr() if track else None
+        nb = bn.num_batches_tracked.data_ptr() if track else None
+        if N % 4 == 0 and all(t.data_ptr() % 16 == 0 for t in (gamma, beta)):
+            # two launches (csrc/tower.hip): GEMM + per-tile column statistics, then merge + normalise
+            ws = torch.empty(max(lib.dfm_linear_bn_workspace_bytes(M, N) // 4, 1), dtype=torch.float32, device=z.device)
+            _lib.check(lib.dfm_linear_bn_forward(x.data_ptr(), K, weight.data_ptr(), _lib.ptr(bias), M, N, K,
+                                                 z.data_ptr(), ws.data_ptr(), _lib.stream_handle()))
+            _lib.check(lib.dfm_bn_relu_dropout_apply(
+                z.data_ptr(), M, N, ws.data_ptr(), gamma.data_ptr(), beta.data_ptr(), stats.data_ptr(), rm, rv, nb,
+                float(bn.momentum), float(bn.eps), float(p), _lib.ptr(seed), salt, out.data_ptr(),
+                _lib.stream_handle()))
+        else:
+            _gemm(x, K, True, weight, K, True, z, M, N, K, bias=bias)                 # z = x W^T + b
+            ws = torch.empty(max(lib.dfm_bn_workspace_bytes(M, N) // 4, 1), dtype=torch.float32, device=z.device)
+            _lib.check(lib.dfm_bn_relu_dropout_forward(
+                z.data_ptr(), M, N, gamma.data_ptr(), beta.data_ptr(), rm, rv, nb, float(bn.momentum), float(bn.eps),
+                float(p), _lib.ptr(seed), salt, out.data_ptr(), stats.data_ptr(), ws.data_ptr(), _lib.stream_handle()))
         ctx.save_for_backward(x, weight, z, gamma, beta, stats)
         ctx.p, ctx.seed, ctx.salt = p, seed, salt
         ctx.params = (weight, bias, gamma, beta)
