@@ -57,8 +57,9 @@ size_t cin_bwd_packed_wt_elems(int H, int F, int C);
 int cin_bwd_pack_wt(const float* W, int C, int H, int F, bf16_t* hi, bf16_t* lo, hipStream_t st);
 int cin_mfma_dgrad(const CinBwdArgs& args, int D, bool split, hipStream_t st);
 size_t cin_mfma_wgrad_workspace_bytes(int64_t B, int C, int H, int F);
+bool cin_mfma_wgrad_has_bias(int F);
 int cin_mfma_wgrad(const float* dY, const float* x0, const float* hidden, int64_t hidden_stride, int64_t B,
-                   int F, int H, int C, float* dW, void* workspace, bool split, hipStream_t st);
+                   int F, int H, int C, float* dW, float* db, void* workspace, bool split, hipStream_t st);
 size_t cin_bias_grad_workspace_bytes(int C);
 int cin_bias_grad_launch(const float* dY, int64_t B, int C, int D, float* db, float* partial, hipStream_t st);
 bool cin_mfma_supported(int F, int D, const int* C, const int* H, int L);
@@ -279,11 +280,14 @@ extern "C" int dfm_cin_backward(const float* d_x0, int64_t batch, int num_fields
     if (int rc = cin_mfma_dgrad(args, dim, split, st)) return rc;
     for (int i = 0; i < lo.L; ++i) {
       const CinBwdLayer& ly = args.layer[i];
+      // the bias gradient rides in a padding column of the weight-gradient GEMM when there is one
+      const bool fused_bias = cin_mfma_wgrad_has_bias(num_fields);
       if (int rc = cin_mfma_wgrad(ly.dY, d_x0, ly.hidden, ly.hidden_stride, batch, num_fields, lo.H[i], lo.C[i],
-                                  g_weights[i], wg_ws, split, st))
+                                  g_weights[i], fused_bias ? g_biases[i] : nullptr, wg_ws, split, st))
         return rc;
-      // wgrad's slabs are consumed (stream order): its workspace doubles as the bias partials
-      if (int rc = cin_bias_grad_launch(ly.dY, batch, lo.C[i], dim, g_biases[i], reinterpret_cast<float*>(wg_ws), st)) return rc;
+      // else: wgrad's slabs are consumed (stream order), its workspace doubles as the bias partials
+      if (!fused_bias)
+        if (int rc = cin_bias_grad_launch(ly.dY, batch, lo.C[i], dim, g_biases[i], reinterpret_cast<float*>(wg_ws), st)) return rc;
     }
     return DFM_OK;
   }

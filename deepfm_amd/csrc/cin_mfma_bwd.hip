@@ -132,27 +132,31 @@ __global__ __launch_bounds__(kBwdWaves * 64, 2) void cin_dgrad_mfma(CinBwdArgs a
     const int nblk = ly.HQ * FG;
     // Weight pipeline as in the forward: block t is loaded to registers during block t-2,
     // written to LDS at the start of block t-1, read during block t.
-    uint4 sh[2] = {}, sl[2] = {};
+    // (named registers, not arrays: the compiler kept `uint4 sh[2]` in scratch memory, which put a
+    // scratch round trip and a full wait on the global load into every block)
+    uint4 sh0 = {}, sh1 = {}, sl0 = {}, sl1 = {};
+    const int p0 = tid, p1 = 256 + tid;
+    const bool has0 = p0 < KS * 64, has1 = p1 < KS * 64;
     auto stage_load = [&](int blk) {
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const int p = q * 256 + tid;                       // (ks, lane) piece
-        if (p < KS * 64) {
-          const int64_t e = static_cast<int64_t>(blk) * KS * 64 + p;
-          sh[q] = reinterpret_cast<const uint4*>(ly.wt_hi)[e];
-          if (SPLIT) sl[q] = reinterpret_cast<const uint4*>(ly.wt_lo)[e];
-        }
+      const int64_t e = static_cast<int64_t>(blk) * KS * 64;
+      if (has0) {
+        sh0 = reinterpret_cast<const uint4*>(ly.wt_hi)[e + p0];
+        if (SPLIT) sl0 = reinterpret_cast<const uint4*>(ly.wt_lo)[e + p0];
+      }
+      if (has1) {
+        sh1 = reinterpret_cast<const uint4*>(ly.wt_hi)[e + p1];
+        if (SPLIT) sl1 = reinterpret_cast<const uint4*>(ly.wt_lo)[e + p1];
       }
     };
     auto stage_store = [&](int buf) {
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const int p = q * 256 + tid;
-        if (p < KS * 64) {
-          unsigned char* base = wbuf + buf * 2 * SLAB;
-          reinterpret_cast<uint4*>(base)[p] = sh[q];
-          if (SPLIT) reinterpret_cast<uint4*>(base + SLAB)[p] = sl[q];
-        }
+      unsigned char* base = wbuf + buf * 2 * SLAB;
+      if (has0) {
+        reinterpret_cast<uint4*>(base)[p0] = sh0;
+        if (SPLIT) reinterpret_cast<uint4*>(base + SLAB)[p0] = sl0;
+      }
+      if (has1) {
+        reinterpret_cast<uint4*>(base)[p1] = sh1;
+        if (SPLIT) reinterpret_cast<uint4*>(base + SLAB)[p1] = sl1;
       }
     };
     __syncthreads();
@@ -247,6 +251,7 @@ struct CinWgradArgs {
   float* slabs;            // (slices, MB*32, KT*32) fp32 partials
   int64_t B;
   int F, H, MB, KT, slices, FP;  // KT: 32-wide column tiles over k' = h*FP + f (FP = padded F)
+  int bias_col;                  // 1: column k' = F carries the bias gradient (needs FP > F)
 };
 
 // grid (ceil(KT/4), slices); a wave owns one 32-column tile of k', all C rows.  One pipeline step
@@ -263,6 +268,9 @@ __global__ __launch_bounds__(256, 2) void cin_wgrad_mfma(CinWgradArgs a) {
   const int kcol = kt * 32 + (lane & 31), hf = lane >> 5;
   const int h = kcol / a.FP, f = kcol % a.FP;
   const bool kvalid = kt < a.KT && h < a.H && f < a.F;
+  // bias gradient for free: the first padding column of hidden row 0 (k' = F, present when F is not a
+  // multiple of 8) multiplies dY by ones, so its slab column is db[c] = sum_{b,d} dY[c,b,d]
+  const bool kbias = a.bias_col && kt < a.KT && h == 0 && f == a.F;
   const int64_t per = (a.B + a.slices - 1) / a.slices;
   const int64_t b0 = blockIdx.y * per, b1 = b0 + per < a.B ? b0 + per : a.B;
   const int64_t nsteps = b1 > b0 ? (b1 - b0 + kWgStep - 1) / kWgStep : 0;
@@ -302,6 +310,8 @@ __global__ __launch_bounds__(256, 2) void cin_wgrad_mfma(CinWgradArgs a) {
         const float* hp = a.hidden + bb * a.hidden_stride + h * 16 + 8 * hf;
         const float* xp = a.x0 + (bb * a.F + f) * 16 + 8 * hf;
         hb[u][0] = ld4(hp); hb[u][1] = ld4(hp + 4); xb[u][0] = ld4(xp); xb[u][1] = ld4(xp + 4);
+      } else if (kbias && bb < b1) {
+        hb[u][0] = hb[u][1] = xb[u][0] = xb[u][1] = float4{1.f, 1.f, 1.f, 1.f};
       }
     }
   };
@@ -364,19 +374,22 @@ __global__ __launch_bounds__(256, 2) void cin_wgrad_mfma(CinWgradArgs a) {
   }
 }
 
-// dW[c][h*F+f] += sum_s slabs[s][c][h*FP+f]  (fixed order)
+// dW[c][h*F+f] += sum_s slabs[s][c][h*FP+f]  (fixed order); with db: db[c] += sum_s slabs[s][c][F]
 __global__ __launch_bounds__(256) void cin_wgrad_reduce_mfma(const float* __restrict__ slabs, int slices,
                                                              int rows_pad, int cols_pad, int C, int H, int F,
-                                                             int FP, float* __restrict__ dW) {
+                                                             int FP, float* __restrict__ dW, float* __restrict__ db) {
   const int64_t o = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
   const int64_t K = static_cast<int64_t>(H) * F;
-  if (o >= C * K) return;
-  const int c = static_cast<int>(o / K), k = static_cast<int>(o % K);
-  const int kp = (k / F) * FP + k % F;
+  const int64_t n = C * K;
+  if (o >= n + (db ? C : 0)) return;
+  const int c = o < n ? static_cast<int>(o / K) : static_cast<int>(o - n);
+  const int k = static_cast<int>(o % K);
+  const int kp = o < n ? (k / F) * FP + k % F : F;
   float acc = 0.f;
   for (int s = 0; s < slices; ++s)
     acc += slabs[(static_cast<int64_t>(s) * rows_pad + c) * cols_pad + kp];
-  dW[o] += acc;
+  if (o < n) dW[o] += acc;
+  else db[c] += acc;
 }
 
 // ---- host side ---------------------------------------------------------------------------
@@ -434,9 +447,13 @@ size_t cin_mfma_wgrad_workspace_bytes(int64_t B, int C, int H, int F) {
   return dy + slabs + 512;
 }
 
-// dW += dY^T (hidden (x) x0), db += column sums; D must be 16
+// true: cin_mfma_wgrad also produces the bias gradient (a free padding column exists)
+bool cin_mfma_wgrad_has_bias(int F) { return F % 8 != 0; }
+
+// dW += dY^T (hidden (x) x0); db += sum_{b,d} dY when `db` is given (cin_mfma_wgrad_has_bias); D must be 16
 int cin_mfma_wgrad(const float* dY, const float* x0, const float* hidden, int64_t hidden_stride, int64_t B,
-                   int F, int H, int C, float* dW, void* workspace, bool split, hipStream_t st) {
+                   int F, int H, int C, float* dW, float* db, void* workspace, bool split, hipStream_t st) {
+  DFM_REQUIRE(!db || cin_mfma_wgrad_has_bias(F), "no padding column for the bias gradient (F = %d)", F);
   const int MB = (C + 31) / 32, FP = ((F + 7) / 8) * 8;
   const int KT = (H * FP + 31) / 32;
   const size_t nfrag = static_cast<size_t>(B) * MB * 64 * 8;
@@ -450,13 +467,14 @@ int cin_mfma_wgrad(const float* dY, const float* x0, const float* hidden, int64_
   CinWgradArgs a;
   a.dy_hi = hi; a.dy_lo = lo; a.x0 = x0; a.hidden = hidden; a.hidden_stride = hidden_stride; a.slabs = slabs;
   a.B = B; a.F = F; a.H = H; a.MB = MB; a.KT = KT; a.slices = slices; a.FP = FP;
+  a.bias_col = db ? 1 : 0;
   const dim3 grid((KT + 3) / 4, slices);
   if (split) hipLaunchKernelGGL(cin_wgrad_mfma<true>, grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL(cin_wgrad_mfma<false>, grid, dim3(256), 0, st, a);
   DFM_LAUNCH_CHECK();
-  const int64_t n = static_cast<int64_t>(C) * H * F;
+  const int64_t n = static_cast<int64_t>(C) * H * F + (db ? C : 0);
   hipLaunchKernelGGL(cin_wgrad_reduce_mfma, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, st, slabs,
-                     slices, MB * 32, KT * 32, C, H, F, FP, dW);
+                     slices, MB * 32, KT * 32, C, H, F, FP, dW, db);
   DFM_LAUNCH_CHECK();
   return DFM_OK;
 }
