@@ -20,6 +20,8 @@
 // Numerics: bf16 x 3 split — W = Wh + Wl, Z = Zh + Zl, acc += Wh*Zh + Wh*Zl + Wl*Zh (fp32
 // accumulate) — which holds the 1e-4 logit bar (plain bf16 is 4e-3, the split
 // 7e-6); SPLIT = false is the plain-bf16 throughput mode (own tolerance, never used for parity).
+#include <type_traits>
+
 #include "common.h"
 
 using namespace dfm;
@@ -45,7 +47,7 @@ struct CinMfmaArgs {
   float* out;
   int64_t B;
   int F, L, out_dim, hid_rows;  // hid_rows: rows of the per-wave hidden image in LDS
-  int ablate;                   // timing-only switches (tools/time_layers.py): 1 no staging, 2 no B-gen, 4 no barrier
+  int ablate;                   // unused (timing-only switches of an earlier version of the kernel)
   CinMfmaLayer layer[kCinMaxLayers];
 };
 
@@ -151,42 +153,72 @@ __global__ __launch_bounds__(kCinWaves * 64, 2) void cin_fwd_mfma(CinMfmaArgs ar
     stage_store(0, vh, vl);
     if (ksteps > 1) stage_load(1, vh, vl);
     __syncthreads();
-    int ks = 0;
-    for (int hp = 0; hp < ly.HP; ++hp) {
-      const float hv = hid[(2 * hp + hf) * kCinCols + n];
+    // One k-step = one 16-deep slice of the reduction: 4 (MB) x 3 (split) MFMAs per wave.  All A
+    // fragments of the step are requested from LDS first, the B operand is generated while they are
+    // in flight, and the MFMAs run hh / hl / lh across the four independent accumulators.  FULL
+    // (MB == 4, the usual 128-channel layer) is free of branches, so nothing waits early: with a
+    // uniform `mb < MB` test around every accumulator the compiler issued read - wait - MFMA eight
+    // times per step (LDS latency exposed each time).
+    auto kloop = [&](auto full_tag) {
+      constexpr bool FULL = decltype(full_tag)::value;
+      int ks = 0;
+      for (int hp = 0; hp < ly.HP; ++hp) {
+        const float hv = hid[(2 * hp + hf) * kCinCols + n];
 #pragma unroll
-      for (int fg = 0; fg < FG; ++fg, ++ks) {
-        const int cur = ks & 1;
-        if (!(args.ablate & 1)) {
-          if (ks + 1 < ksteps) stage_store(cur ^ 1, vh, vl);   // slab ks+1 (loaded one step ago)
-          if (ks + 2 < ksteps) stage_load(ks + 2, vh, vl);
-        }
-        // B operand: Z values of this k-step for the lane's column
-        float z[8];
+        for (int fg = 0; fg < FG; ++fg, ++ks) {
+          const int cur = ks & 1;
+          const unsigned char* base = wbuf + cur * 2 * SLAB;
+          bf16x8 ah[4], al[4];
+          if constexpr (FULL) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) z[j] = (args.ablate & 2) ? x0r[j] : hv * x0r[fg * 8 + j];
-        bf16x8 bh, bl;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          bh[j] = static_cast<__bf16>(z[j]);
-          if (SPLIT) bl[j] = (args.ablate & 2) ? bh[j] : static_cast<__bf16>(z[j] - static_cast<float>(bh[j]));
-        }
-        const unsigned char* base = wbuf + cur * 2 * SLAB;
-#pragma unroll
-        for (int mb = 0; mb < 4; ++mb) {
-          if (mb < MB) {
-            const bf16x8 ah = reinterpret_cast<const bf16x8*>(base)[mb * 64 + lane];
-            acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[mb], 0, 0, 0);
-            if (SPLIT) {
-              const bf16x8 al = reinterpret_cast<const bf16x8*>(base + SLAB)[mb * 64 + lane];
-              acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[mb], 0, 0, 0);
-              acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[mb], 0, 0, 0);
+            for (int mb = 0; mb < 4; ++mb) {
+              ah[mb] = reinterpret_cast<const bf16x8*>(base)[mb * 64 + lane];
+              if (SPLIT) al[mb] = reinterpret_cast<const bf16x8*>(base + SLAB)[mb * 64 + lane];
             }
           }
+          if (ks + 1 < ksteps) stage_store(cur ^ 1, vh, vl);   // slab ks+1 (loaded one step ago)
+          if (ks + 2 < ksteps) stage_load(ks + 2, vh, vl);
+          // B operand: Z values of this k-step for the lane's column
+          bf16x8 bh, bl;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float z = hv * x0r[fg * 8 + j];
+            bh[j] = static_cast<__bf16>(z);
+            if (SPLIT) bl[j] = static_cast<__bf16>(z - static_cast<float>(bh[j]));
+          }
+          if constexpr (FULL) {
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+              acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mb], bh, acc[mb], 0, 0, 0);
+            if (SPLIT) {
+#pragma unroll
+              for (int mb = 0; mb < 4; ++mb)
+                acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mb], bl, acc[mb], 0, 0, 0);
+#pragma unroll
+              for (int mb = 0; mb < 4; ++mb)
+                acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mb], bh, acc[mb], 0, 0, 0);
+            }
+          } else {
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+              if (mb < MB) {
+                const bf16x8 a_h = reinterpret_cast<const bf16x8*>(base)[mb * 64 + lane];
+                acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, bh, acc[mb], 0, 0, 0);
+                if (SPLIT) {
+                  const bf16x8 a_l = reinterpret_cast<const bf16x8*>(base + SLAB)[mb * 64 + lane];
+                  acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, bl, acc[mb], 0, 0, 0);
+                  acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_l, bh, acc[mb], 0, 0, 0);
+                }
+              }
+            }
+          }
+          __syncthreads();
         }
-        if (!(args.ablate & 4)) __syncthreads();
       }
-    }
+    };
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+    if (MB == 4) kloop(std::true_type{});
+    else kloop(std::false_type{});
     // ---- epilogue: ReLU, sum-pool of the direct channels, hand the next channels over ------
     const bool last = li == args.L - 1;
     // the hidden image is rewritten below: every row of the next layer's (padded) image

@@ -19,6 +19,8 @@
 // cin_pack_dy), the B operand hidden*x0 is generated in registers.  Split over batch slices,
 // partial slabs reduced in a fixed order (bitwise reproducible).
 // Numerics: the same bf16 x 3 split as the forward (SPLIT) or plain bf16 (throughput mode).
+#include <type_traits>
+
 #include "common.h"
 
 using namespace dfm;
@@ -164,49 +166,91 @@ __global__ __launch_bounds__(kBwdWaves * 64, 2) void cin_dgrad_mfma(CinBwdArgs a
     stage_store(0);
     if (nblk > 1) stage_load(1);
     __syncthreads();
-    int blk = 0;
-    for (int hq = 0; hq < ly.HQ; ++hq) {
-      float hv[4], dhq[4];
+    // FULL (KS == 8: a 128-channel layer): no branch inside a block, the A fragments are requested
+    // four k-steps at a time and the waits are counted; the generic path tests `ks < KS` around every
+    // k-step (read - wait - MFMA each time).  The explicit wait in front of the loop only tells the
+    // compiler that the layer preamble's loads are complete: without it the loop header inherits them
+    // as pending and the first block of every iteration waits for vmcnt(0) right after issuing its
+    // own weight loads.
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+    auto blocks = [&](auto full_tag) {
+      constexpr bool FULL = decltype(full_tag)::value;
+      int blk = 0;
+      for (int hq = 0; hq < ly.HQ; ++hq) {
+        float hv[4], dhq[4];
 #pragma unroll
-      for (int hl = 0; hl < 4; ++hl) {
-        const int h = 4 * hq + hl;
-        hv[hl] = (live && h < ly.H) ? ly.hidden[b * ly.hidden_stride + h * D + d] : 0.f;
-        dhq[hl] = 0.f;
-      }
+        for (int hl = 0; hl < 4; ++hl) {
+          const int h = 4 * hq + hl;
+          hv[hl] = (live && h < ly.H) ? ly.hidden[b * ly.hidden_stride + h * D + d] : 0.f;
+          dhq[hl] = 0.f;
+        }
 #pragma unroll
-      for (int fg = 0; fg < FG; ++fg, ++blk) {
-        const int cur = blk & 1;
-        if (blk + 1 < nblk) stage_store(cur ^ 1);          // block blk+1 (loaded one block ago)
-        if (blk + 2 < nblk) stage_load(blk + 2);
-        const unsigned char* base = wbuf + cur * 2 * SLAB;
-        f32x16 acc = {};
+        for (int fg = 0; fg < FG; ++fg, ++blk) {
+          const int cur = blk & 1;
+          const unsigned char* base = wbuf + cur * 2 * SLAB;
+          f32x16 acc = {};
+          if constexpr (FULL) {
+            bf16x8 ah[4], al[4];
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-          if (ks < KS) {
-            const bf16x8 ah = reinterpret_cast<const bf16x8*>(base)[ks * 64 + lane];
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, dyh[ks], acc, 0, 0, 0);
-            if (SPLIT) {
-              const bf16x8 al = reinterpret_cast<const bf16x8*>(base + SLAB)[ks * 64 + lane];
-              acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, dyl[ks], acc, 0, 0, 0);
-              acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, dyh[ks], acc, 0, 0, 0);
+            for (int q = 0; q < 4; ++q) {
+              ah[q] = reinterpret_cast<const bf16x8*>(base)[q * 64 + lane];
+              if (SPLIT) al[q] = reinterpret_cast<const bf16x8*>(base + SLAB)[q * 64 + lane];
+            }
+            if (blk + 1 < nblk) stage_store(cur ^ 1);          // block blk+1 (loaded one block ago)
+            if (blk + 2 < nblk) stage_load(blk + 2);
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const int ks = half * 4 + q;
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[q], dyh[ks], acc, 0, 0, 0);
+                if (SPLIT) {
+                  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[q], dyl[ks], acc, 0, 0, 0);
+                  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[q], dyh[ks], acc, 0, 0, 0);
+                }
+              }
+              if (half == 0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                  ah[q] = reinterpret_cast<const bf16x8*>(base)[(4 + q) * 64 + lane];
+                  if (SPLIT) al[q] = reinterpret_cast<const bf16x8*>(base + SLAB)[(4 + q) * 64 + lane];
+                }
+              }
+            }
+          } else {
+            if (blk + 1 < nblk) stage_store(cur ^ 1);
+            if (blk + 2 < nblk) stage_load(blk + 2);
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+              if (ks < KS) {
+                const bf16x8 a_h = reinterpret_cast<const bf16x8*>(base)[ks * 64 + lane];
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, dyh[ks], acc, 0, 0, 0);
+                if (SPLIT) {
+                  const bf16x8 a_l = reinterpret_cast<const bf16x8*>(base + SLAB)[ks * 64 + lane];
+                  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, dyl[ks], acc, 0, 0, 0);
+                  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_l, dyh[ks], acc, 0, 0, 0);
+                }
+              }
             }
           }
-        }
-        // accumulator register r: hidden row 4*hq + (r>>2), field fg*8 + 4*hf + (r&3)
+          // accumulator register r: hidden row 4*hq + (r>>2), field fg*8 + 4*hf + (r&3)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          dhq[r >> 2] = fmaf(x0q[fg * 4 + (r & 3)], acc[r], dhq[r >> 2]);
-          dx0[fg * 4 + (r & 3)] = fmaf(hv[r >> 2], acc[r], dx0[fg * 4 + (r & 3)]);
+          for (int r = 0; r < 16; ++r) {
+            dhq[r >> 2] = fmaf(x0q[fg * 4 + (r & 3)], acc[r], dhq[r >> 2]);
+            dx0[fg * 4 + (r & 3)] = fmaf(hv[r >> 2], acc[r], dx0[fg * 4 + (r & 3)]);
+          }
+          __syncthreads();
         }
-        __syncthreads();
-      }
-      // the other lane half holds the other 4 fields of every group
+        // the other lane half holds the other 4 fields of every group
 #pragma unroll
-      for (int hl = 0; hl < 4; ++hl) {
-        const float tot = dhq[hl] + __shfl_xor(dhq[hl], 32, kWave);
-        if ((hl & 1) == hf) dH[(4 * hq + hl) * kBwdCols + n] = tot;
+        for (int hl = 0; hl < 4; ++hl) {
+          const float tot = dhq[hl] + __shfl_xor(dhq[hl], 32, kWave);
+          if ((hl & 1) == hf) dH[(4 * hq + hl) * kBwdCols + n] = tot;
+        }
       }
-    }
+    };
+    if (KS == 8) blocks(std::true_type{});
+    else blocks(std::false_type{});
     if (li == 0) {   // hidden_0 is x0 itself: its gradient joins d x0
 #pragma unroll
       for (int i = 0; i < FG * 4; ++i) {
@@ -322,42 +366,73 @@ __global__ __launch_bounds__(256, 2) void cin_wgrad_mfma(CinWgradArgs a) {
     if (nsteps > 1) load_a(1);
   }
   __syncthreads();
-  for (int64_t step = 0; step < nsteps; ++step) {
-    const int cur = static_cast<int>(step & 1);
-    if (step + 1 < nsteps) store_a(cur ^ 1);
-    if (step + 2 < nsteps) load_a(step + 2);
-    // B operands of this step from the registers loaded one step ago
-    bf16x8 bh[kWgStep], bl[kWgStep];
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): see cin_dgrad_mfma
+  auto steps = [&](auto full_tag) {
+    constexpr bool FULL = decltype(full_tag)::value;
+    for (int64_t step = 0; step < nsteps; ++step) {
+      const int cur = static_cast<int>(step & 1);
+      const unsigned char* base = wbuf + cur * 2 * SLAB;
+      bf16x8 ah[kWgStep][4], al[kWgStep][4];
+      if constexpr (FULL) {
 #pragma unroll
-    for (int u = 0; u < kWgStep; ++u) {
-      const float z[8] = {hb[u][0].x * xb[u][0].x, hb[u][0].y * xb[u][0].y, hb[u][0].z * xb[u][0].z,
-                          hb[u][0].w * xb[u][0].w, hb[u][1].x * xb[u][1].x, hb[u][1].y * xb[u][1].y,
-                          hb[u][1].z * xb[u][1].z, hb[u][1].w * xb[u][1].w};
+        for (int u = 0; u < kWgStep; ++u) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        bh[u][j] = static_cast<__bf16>(z[j]);
-        if (SPLIT) bl[u][j] = static_cast<__bf16>(z[j] - static_cast<float>(bh[u][j]));
-      }
-    }
-    if (step + 1 < nsteps) load_b(step + 1);
-    const unsigned char* base = wbuf + cur * 2 * SLAB;
-#pragma unroll
-    for (int u = 0; u < kWgStep; ++u) {
-#pragma unroll
-      for (int mb = 0; mb < 4; ++mb) {
-        if (mb < a.MB) {
-          const bf16x8 ah = reinterpret_cast<const bf16x8*>(base)[(u * 4 + mb) * 64 + lane];
-          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[u], acc[mb], 0, 0, 0);
-          if (SPLIT) {
-            const bf16x8 al = reinterpret_cast<const bf16x8*>(base + SLAB)[(u * 4 + mb) * 64 + lane];
-            acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[u], acc[mb], 0, 0, 0);
-            acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[u], acc[mb], 0, 0, 0);
+          for (int mb = 0; mb < 4; ++mb) {
+            ah[u][mb] = reinterpret_cast<const bf16x8*>(base)[(u * 4 + mb) * 64 + lane];
+            if (SPLIT) al[u][mb] = reinterpret_cast<const bf16x8*>(base + SLAB)[(u * 4 + mb) * 64 + lane];
           }
         }
       }
+      if (step + 1 < nsteps) store_a(cur ^ 1);
+      if (step + 2 < nsteps) load_a(step + 2);
+      // B operands of this step from the registers loaded one step ago
+      bf16x8 bh[kWgStep], bl[kWgStep];
+#pragma unroll
+      for (int u = 0; u < kWgStep; ++u) {
+        const float z[8] = {hb[u][0].x * xb[u][0].x, hb[u][0].y * xb[u][0].y, hb[u][0].z * xb[u][0].z,
+                            hb[u][0].w * xb[u][0].w, hb[u][1].x * xb[u][1].x, hb[u][1].y * xb[u][1].y,
+                            hb[u][1].z * xb[u][1].z, hb[u][1].w * xb[u][1].w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          bh[u][j] = static_cast<__bf16>(z[j]);
+          if (SPLIT) bl[u][j] = static_cast<__bf16>(z[j] - static_cast<float>(bh[u][j]));
+        }
+      }
+      if (step + 1 < nsteps) load_b(step + 1);
+#pragma unroll
+      for (int u = 0; u < kWgStep; ++u) {
+        if constexpr (FULL) {
+#pragma unroll
+          for (int mb = 0; mb < 4; ++mb)
+            acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[u][mb], bh[u], acc[mb], 0, 0, 0);
+          if (SPLIT) {
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+              acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[u][mb], bl[u], acc[mb], 0, 0, 0);
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+              acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[u][mb], bh[u], acc[mb], 0, 0, 0);
+          }
+        } else {
+#pragma unroll
+          for (int mb = 0; mb < 4; ++mb) {
+            if (mb < a.MB) {
+              const bf16x8 a_h = reinterpret_cast<const bf16x8*>(base)[(u * 4 + mb) * 64 + lane];
+              acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, bh[u], acc[mb], 0, 0, 0);
+              if (SPLIT) {
+                const bf16x8 a_l = reinterpret_cast<const bf16x8*>(base + SLAB)[(u * 4 + mb) * 64 + lane];
+                acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, bl[u], acc[mb], 0, 0, 0);
+                acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_l, bh[u], acc[mb], 0, 0, 0);
+              }
+            }
+          }
+        }
+      }
+      __syncthreads();
     }
-    __syncthreads();
-  }
+  };
+  if (a.MB == 4) steps(std::true_type{});
+  else steps(std::false_type{});
   if (kt < a.KT) {
     // accumulator: col = k' column (lane&31), row = c = mb*32 + (r&3) + 8*(r>>2) + 4*hf
     float* out = a.slabs + (static_cast<int64_t>(blockIdx.y) * a.MB * 32 + 4 * hf) * (a.KT * 32) + kt * 32 + (lane & 31);
