@@ -512,13 +512,24 @@ int cin_mfma_dgrad(const CinBwdArgs& args, int D, bool split, hipStream_t st) {
   return fail(DFM_ERR_UNSUPPORTED, "no MFMA CIN dgrad kernel for D=%d, F=%d", D, args.F);
 }
 
-constexpr int kWgradMfmaSlices = 32;
+// Batch slices of the weight-gradient GEMM: the grid is (column groups) x (slices) workgroups of
+// equal work, two resident per CU, so the slice count is chosen to fill ONE round of 2 x 256
+// workgroup slots (20 column groups x 32 slices = 640 workgroups ran a second round at 25 %
+// occupancy: 184 us where 118 us of work was needed).
+constexpr int kWgradMaxSlices = 64;
+constexpr int kWgSlots = 2 * 256;
+static int wgrad_slices(int64_t B, int KT) {
+  const int cols = (KT + 3) / 4;
+  int slices = kWgSlots / cols;
+  slices = slices < 1 ? 1 : (slices > kWgradMaxSlices ? kWgradMaxSlices : slices);
+  return B < slices ? static_cast<int>(B) : slices;
+}
 
 size_t cin_mfma_wgrad_workspace_bytes(int64_t B, int C, int H, int F) {
   const int MB = (C + 31) / 32, FP = ((F + 7) / 8) * 8;
   const int KT = (H * FP + 31) / 32;
   const size_t dy = 2 * sizeof(__bf16) * static_cast<size_t>(B) * MB * 64 * 8;
-  const size_t slabs = sizeof(float) * static_cast<size_t>(kWgradMfmaSlices) * MB * 32 * KT * 32;
+  const size_t slabs = sizeof(float) * static_cast<size_t>(wgrad_slices(B, KT)) * MB * 32 * KT * 32;
   return dy + slabs + 512;
 }
 
@@ -538,7 +549,7 @@ int cin_mfma_wgrad(const float* dY, const float* x0, const float* hidden, int64_
   hipLaunchKernelGGL(cin_pack_dy, dim3(static_cast<unsigned>((nfrag + 255) / 256)), dim3(256), 0, st, dY, B, C, MB,
                      hi, lo);
   DFM_LAUNCH_CHECK();
-  const int slices = B < kWgradMfmaSlices ? static_cast<int>(B) : kWgradMfmaSlices;
+  const int slices = wgrad_slices(B, KT);
   CinWgradArgs a;
   a.dy_hi = hi; a.dy_lo = lo; a.x0 = x0; a.hidden = hidden; a.hidden_stride = hidden_stride; a.slabs = slabs;
   a.B = B; a.F = F; a.H = H; a.MB = MB; a.KT = KT; a.slices = slices; a.FP = FP;
