@@ -218,6 +218,11 @@ __device__ __forceinline__ void mainloop(const float* __restrict__ A, int64_t ld
                                                   spb, va, vb, oka, okb, fa, fb, acc)
   // slice s: LDS buffer s % 2, global-prefetch slot s % 4
   int k0 = kb;
+  // Tell the compiler that nothing older than the four prefetch slots is in flight on loop entry.
+  // Without this wait the loop header inherits "possibly pending" loads from the branchy prologue
+  // and the steady state waits for vmcnt(0) once per four slices (the prefetch ring drains);
+  // with it every slice waits for vmcnt(7) / vmcnt(6), i.e. only for its own slot.
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
   for (; k0 + (kPrefetch + 6) * BK <= ke; k0 += kPrefetch * BK) {  // slices up to s+9 are FULL slices: no checks
     DFM_PIPE(0, false); DFM_PIPE(1, false); DFM_PIPE(2, false); DFM_PIPE(3, false);
   }

@@ -2,7 +2,7 @@
 """Whole-model training steps at the BASELINE.json configurations 2-4 (B = 4096, V = 1e6):
 DeepFM (fused tower step), xDeepFM (CIN [128,128,128]) and AttentionDeepFM (embed_dim 32, 4 heads) on
 the autograd step, all with row-sparse Adam, packed tables and HIP graphs.
-usage: python tools/time_models.py [steps]"""
+usage: python tools/time_models.py [steps] [model ...]"""
 import os
 import sys
 import time
@@ -58,6 +58,6 @@ def run(name, dim, steps, B=4096, V=1_000_000):
 
 if __name__ == "__main__":
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 100
-    run("deepfm", 16, steps)
-    run("xdeepfm", 16, steps)
-    run("attention_deepfm", 32, steps)
+    which = sys.argv[2:] or ["deepfm", "xdeepfm", "attention_deepfm"]
+    for name in which:
+        run(name, 32 if name == "attention_deepfm" else 16, steps)
