@@ -4,8 +4,8 @@
 // + b (attention.py:95-97) and out = O Wo^T + bo (:115) — and run on dfm_gemm_f32 (exact fp32
 // MFMA).  What is left is small and per sample:
 //   * attn_core_fwd / attn_core_bwd: softmax(Q_h K_h^T / sqrt(hd)) V_h for one (sample, head) per
-//     wave (:100-112).  F = 39 "tokens": lane i owns query row i; K_h / V_h rows are LDS
-//     broadcasts; the (B, heads, F, F) score tensor of the reference never leaves registers/LDS.
+//     wave (:100-112).  F = 39 "tokens": lane i owns query row i; K_h / V_h rows are scalar
+//     operands (SGPRs); the (B, heads, F, F) score tensor of the reference never leaves LDS.
 //     The backward recomputes P from Q, K.
 //   * layernorm_fwd / layernorm_bwd: LayerNorm(out + x) over D (:117-118), one row per lane
 //     group, parameter gradients as fixed-order partial sums.
@@ -18,43 +18,55 @@ constexpr int kMaxF = 64;     // one lane per query row
 constexpr int kWavesPerBlock = 4;
 }  // namespace
 
-// qkv (B*F, 3A): row = [q (A) | k (A) | v (A)];  o (B*F, A).  One wave per (b, h).
-// LDS per wave: k_h, v_h (F x hd each) and the score rows P (F x F; lane i owns row i — a
-// runtime-indexed register array would be demoted to scratch).
+// qkv (B*F, 3A): row = [q (A) | k (A) | v (A)];  o (B*F, A).  One wave per (b, h); lane i owns
+// query row i.  The K_h / V_h / Q_h / dO_h rows a lane multiplies against are the SAME for every
+// lane of the wave (row j of the head), so they are read with wave-uniform addresses straight from
+// global memory — scalar loads into SGPRs through the scalar cache, used as scalar operands of the
+// FMAs — instead of LDS broadcasts: an LDS broadcast still moves 64 x 16 B through the LDS pipe, and
+// with 6 sweeps of 39 rows per (sample, head) that pipe (shared by the CU's four SIMDs) was the
+// bound.  LDS now only holds the score rows (F x F per wave; lane i owns row i — a runtime-indexed
+// register array would be demoted to scratch).  (Prefetching row j+1 into a second SGPR set while
+// row j is multiplied measured slower: 0.912 vs 0.869 ms forward + backward — SGPR spills and moves.)
+template <int HD>
+__device__ __forceinline__ void load_row(const float* __restrict__ p, float (&r)[HD]) {
+#pragma unroll
+  for (int e = 0; e < HD; ++e) r[e] = p[e];
+}
+template <int HD>
+__device__ __forceinline__ float dot_row(const float (&a)[HD], const float (&b)[HD]) {
+  float acc = 0.f;
+#pragma unroll
+  for (int e = 0; e < HD; ++e) acc = fmaf(a[e], b[e], acc);
+  return acc;
+}
+
 template <int HD>
 __global__ __launch_bounds__(kWavesPerBlock * 64) void attn_core_fwd(const float* __restrict__ qkv, int64_t B,
                                                                        int F, int A, int heads,
                                                                        float* __restrict__ o) {
   extern __shared__ float lds[];
   const int lane = lane_id(), wave = wave_id_uniform();
-  const int64_t unit = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave;   // (b, h)
+  const int64_t unit = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave;   // (b, h): wave-uniform
   if (unit >= B * heads) return;
   const int64_t b = unit / heads;
   const int h = static_cast<int>(unit % heads);
-  float* ks = lds + static_cast<size_t>(wave) * (2 * F * HD + F * F);
-  float* vs = ks + F * HD;
-  float* Ps = vs + F * HD;
-  const float* base = qkv + b * F * 3 * A + h * HD;
-  for (int i = lane; i < F * HD; i += 64) {
-    const int j = i / HD, e = i % HD;
-    ks[i] = base[static_cast<int64_t>(j) * 3 * A + A + e];
-    vs[i] = base[static_cast<int64_t>(j) * 3 * A + 2 * A + e];
-  }
+  float* Ps = lds + static_cast<size_t>(wave) * F * F;
+  const float* base = qkv + b * F * 3 * A + h * HD;          // wave-uniform
+  const int64_t rs = 3 * static_cast<int64_t>(A);            // row stride of qkv
   // wave-private LDS: same-wave LDS ops are ordered, no barrier needed
   const bool live = lane < F;
   const int row = live ? lane : 0;
   float* prow = Ps + row * F;
   float q[HD];
-#pragma unroll
-  for (int e = 0; e < HD; ++e) q[e] = base[static_cast<int64_t>(row) * 3 * A + e];
+  load_row<HD>(base + row * rs, q);
   const float inv_scale = 1.f / sqrtf(static_cast<float>(HD));
   // scores of this lane's row; running max
   float mx = -INFINITY;
+#pragma unroll 3
   for (int j = 0; j < F; ++j) {
-    float acc = 0.f;
-#pragma unroll
-    for (int e = 0; e < HD; ++e) acc = fmaf(q[e], ks[j * HD + e], acc);
-    acc *= inv_scale;
+    float kr[HD];
+    load_row<HD>(base + j * rs + A, kr);                     // uniform address: scalar load
+    const float acc = dot_row<HD>(q, kr) * inv_scale;
     if (live) prow[j] = acc;
     mx = fmaxf(mx, acc);
   }
@@ -68,10 +80,13 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void attn_core_fwd(const float
   float out[HD];
 #pragma unroll
   for (int e = 0; e < HD; ++e) out[e] = 0.f;
+#pragma unroll 3
   for (int j = 0; j < F; ++j) {
+    float vr[HD];
+    load_row<HD>(base + j * rs + 2 * A, vr);
     const float p = prow[j] * inv;
 #pragma unroll
-    for (int e = 0; e < HD; ++e) out[e] = fmaf(p, vs[j * HD + e], out[e]);
+    for (int e = 0; e < HD; ++e) out[e] = fmaf(p, vr[e], out[e]);
   }
   if (live) {
     float* dst = o + (b * F + lane) * A + h * HD;
@@ -80,9 +95,8 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void attn_core_fwd(const float
   }
 }
 
-// d_qkv (B*F, 3A) from d_o (B*F, A); recomputes P.  LDS per wave: q, k, v, dO (F x hd each) and ONE
-// F x F matrix that holds P for the dV sweep and is then overwritten by dS for the dK sweep (dP is
-// recomputed instead of stored: 16 FMAs per element buy a second resident workgroup per CU).
+// d_qkv (B*F, 3A) from d_o (B*F, A); recomputes P.  LDS per wave: ONE F x F matrix that holds P for
+// the dV sweep and is then overwritten by dS for the dK sweep (dP is recomputed instead of stored).
 template <int HD>
 __global__ __launch_bounds__(kWavesPerBlock * 64) void attn_core_bwd(const float* __restrict__ qkv,
                                                                        const float* __restrict__ d_o, int64_t B,
@@ -94,34 +108,24 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void attn_core_bwd(const float
   if (unit >= B * heads) return;
   const int64_t b = unit / heads;
   const int h = static_cast<int>(unit % heads);
-  float* qs = lds + static_cast<size_t>(wave) * (4 * F * HD + F * F);
-  float* ks = qs + F * HD;
-  float* vs = ks + F * HD;
-  float* gs = vs + F * HD;          // dO
-  float* Ms = gs + F * HD;          // P, later dS  (row i, col j at i*F + j)
-  const float* base = qkv + b * F * 3 * A + h * HD;
+  float* Ms = lds + static_cast<size_t>(wave) * F * F;       // P, later dS  (row i, col j at i*F + j)
+  const float* base = qkv + b * F * 3 * A + h * HD;          // wave-uniform
   const float* gbase = d_o + b * F * A + h * HD;
-  for (int i = lane; i < F * HD; i += 64) {
-    const int j = i / HD, e = i % HD;
-    qs[i] = base[static_cast<int64_t>(j) * 3 * A + e];
-    ks[i] = base[static_cast<int64_t>(j) * 3 * A + A + e];
-    vs[i] = base[static_cast<int64_t>(j) * 3 * A + 2 * A + e];
-    gs[i] = gbase[static_cast<int64_t>(j) * A + e];
-  }
+  const int64_t rs = 3 * static_cast<int64_t>(A);
   const bool live = lane < F;
   const int row = live ? lane : 0;
   const float inv_scale = 1.f / sqrtf(static_cast<float>(HD));
   float q[HD], g[HD];
-#pragma unroll
-  for (int e = 0; e < HD; ++e) { q[e] = qs[row * HD + e]; g[e] = gs[row * HD + e]; }
+  load_row<HD>(base + row * rs, q);
+  load_row<HD>(gbase + static_cast<int64_t>(row) * A, g);
   float* mrow = Ms + row * F;       // dead lanes shadow row 0 and never write
   // ---- P row of this lane ---------------------------------------------------------------------
   float mx = -INFINITY;
+#pragma unroll 3
   for (int j = 0; j < F; ++j) {
-    float acc = 0.f;
-#pragma unroll
-    for (int e = 0; e < HD; ++e) acc = fmaf(q[e], ks[j * HD + e], acc);
-    acc *= inv_scale;
+    float kr[HD];
+    load_row<HD>(base + j * rs + A, kr);
+    const float acc = dot_row<HD>(q, kr) * inv_scale;
     if (live) mrow[j] = acc;
     mx = fmaxf(mx, acc);
   }
@@ -133,11 +137,12 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void attn_core_bwd(const float
   }
   const float inv = 1.f / sum;
   float dot = 0.f;                  // sum_j dP_ij P_ij
+#pragma unroll 3
   for (int j = 0; j < F; ++j) {
+    float vr[HD];
+    load_row<HD>(base + j * rs + 2 * A, vr);
     const float p = mrow[j] * inv;
-    float dp = 0.f;
-#pragma unroll
-    for (int e = 0; e < HD; ++e) dp = fmaf(g[e], vs[j * HD + e], dp);
+    const float dp = dot_row<HD>(g, vr);
     if (live) mrow[j] = p;
     dot = fmaf(dp, p, dot);
   }
@@ -147,14 +152,17 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void attn_core_bwd(const float
     float dv[HD];
 #pragma unroll
     for (int e = 0; e < HD; ++e) dv[e] = 0.f;
+#pragma unroll 3
     for (int i = 0; i < F; ++i) {
+      float gr[HD];
+      load_row<HD>(gbase + static_cast<int64_t>(i) * A, gr);
       const float p = Ms[i * F + row];
 #pragma unroll
-      for (int e = 0; e < HD; ++e) dv[e] = fmaf(p, gs[i * HD + e], dv[e]);
+      for (int e = 0; e < HD; ++e) dv[e] = fmaf(p, gr[e], dv[e]);
     }
     if (live) {
 #pragma unroll
-      for (int e = 0; e < HD; ++e) dbase[static_cast<int64_t>(row) * 3 * A + 2 * A + e] = dv[e];
+      for (int e = 0; e < HD; ++e) dbase[row * rs + 2 * A + e] = dv[e];
     }
   }
   // ---- dS row (overwrites P), dQ -----------------------------------------------------------------
@@ -162,18 +170,20 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void attn_core_bwd(const float
     float dq[HD];
 #pragma unroll
     for (int e = 0; e < HD; ++e) dq[e] = 0.f;
+#pragma unroll 3
     for (int j = 0; j < F; ++j) {
-      float dp = 0.f;
-#pragma unroll
-      for (int e = 0; e < HD; ++e) dp = fmaf(g[e], vs[j * HD + e], dp);
+      float vr[HD], kr[HD];
+      load_row<HD>(base + j * rs + 2 * A, vr);
+      load_row<HD>(base + j * rs + A, kr);
+      const float dp = dot_row<HD>(g, vr);
       const float ds = mrow[j] * (dp - dot) * inv_scale;
       if (live) mrow[j] = ds;
 #pragma unroll
-      for (int e = 0; e < HD; ++e) dq[e] = fmaf(ds, ks[j * HD + e], dq[e]);
+      for (int e = 0; e < HD; ++e) dq[e] = fmaf(ds, kr[e], dq[e]);
     }
     if (live) {
 #pragma unroll
-      for (int e = 0; e < HD; ++e) dbase[static_cast<int64_t>(row) * 3 * A + e] = dq[e];
+      for (int e = 0; e < HD; ++e) dbase[row * rs + e] = dq[e];
     }
   }
   // ---- dK[j] = sum_i dS[i][j] q[i] --------------------------------------------------------------
@@ -181,14 +191,17 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void attn_core_bwd(const float
     float dk[HD];
 #pragma unroll
     for (int e = 0; e < HD; ++e) dk[e] = 0.f;
+#pragma unroll 3
     for (int i = 0; i < F; ++i) {
+      float qr[HD];
+      load_row<HD>(base + i * rs, qr);
       const float ds = Ms[i * F + row];
 #pragma unroll
-      for (int e = 0; e < HD; ++e) dk[e] = fmaf(ds, qs[i * HD + e], dk[e]);
+      for (int e = 0; e < HD; ++e) dk[e] = fmaf(ds, qr[e], dk[e]);
     }
     if (live) {
 #pragma unroll
-      for (int e = 0; e < HD; ++e) dbase[static_cast<int64_t>(row) * 3 * A + A + e] = dk[e];
+      for (int e = 0; e < HD; ++e) dbase[row * rs + A + e] = dk[e];
     }
   }
 }
@@ -311,7 +324,7 @@ extern "C" int dfm_attention_core_forward(const float* d_qkv, int64_t batch, int
   const int hd = attention_dim / num_heads;
   const int64_t units = batch * num_heads;
   const dim3 grid(static_cast<unsigned>((units + kWavesPerBlock - 1) / kWavesPerBlock)), block(kWavesPerBlock * 64);
-  const size_t lds = sizeof(float) * kWavesPerBlock * (2 * num_fields * hd + num_fields * num_fields);
+  const size_t lds = sizeof(float) * kWavesPerBlock * (num_fields * num_fields);
   DFM_REQUIRE(lds <= 64 * 1024, "attention core needs %zu bytes of LDS", lds);
   hipStream_t st = as_stream(stream);
 #define DFM_CORE(HD) hipLaunchKernelGGL(attn_core_fwd<HD>, grid, block, lds, st, d_qkv, batch, num_fields, attention_dim, num_heads, d_o)
@@ -330,7 +343,7 @@ extern "C" int dfm_attention_core_backward(const float* d_qkv, const float* d_g_
   const int hd = attention_dim / num_heads;
   const int64_t units = batch * num_heads;
   const dim3 grid(static_cast<unsigned>((units + kWavesPerBlock - 1) / kWavesPerBlock)), block(kWavesPerBlock * 64);
-  const size_t lds = sizeof(float) * kWavesPerBlock * (4 * num_fields * hd + num_fields * num_fields);
+  const size_t lds = sizeof(float) * kWavesPerBlock * (num_fields * num_fields);
   DFM_REQUIRE(lds <= 160 * 1024, "attention core backward needs %zu bytes of LDS", lds);
   hipStream_t st = as_stream(stream);
 #define DFM_CORE(HD)                                                                                        \
