@@ -112,6 +112,8 @@ SIGNATURES = {
     "dfm_bce_with_logits": (_I, [_P, _P, _L, _P, _P, _P, _P]),
     "dfm_gemm_workspace_bytes": (_SZ, [_I, _I, _I]),
     "dfm_gemm_f32": (_I, [_P, _L, _I, _P, _L, _I, _P, _L, _I, _I, _I, _P, _I, _P, _P]),
+    "dfm_weight_grad_workspace_bytes": (_SZ, [_L, _I, _I]),
+    "dfm_weight_grad_f32": (_I, [_P, _L, _P, _L, _L, _I, _I, _P, _L, _P, _I, _P, _P]),
     "dfm_attention_core_supported": (_I, [_I, _I, _I]),
     "dfm_attention_core_forward": (_I, [_P, _L, _I, _I, _I, _P, _P]),
     "dfm_attention_core_backward": (_I, [_P, _P, _L, _I, _I, _I, _P, _P]),

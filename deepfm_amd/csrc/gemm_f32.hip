@@ -79,6 +79,15 @@ __global__ __launch_bounds__(256) void gemm_f32_reduce(const float* __restrict__
   *dst = (accumulate ? *dst : 0.f) + (bias ? bias[n] : 0.f) + acc;
 }
 
+namespace dfm {   // gemm_skinny.hip
+bool gemm_rows_try(const float* A, int64_t lda, const float* W, int64_t ldw, bool w_kc, float* C, int64_t ldc,
+                   int64_t M, int N, int K, const float* bias, int accumulate, hipStream_t st);
+bool gemm_wgrad_supported(int64_t M, int N1, int N2);
+size_t gemm_wgrad_workspace_bytes(int64_t M, int N1, int N2);
+bool gemm_wgrad_try(const float* G, int64_t ldg, const float* X, int64_t ldx, int64_t M, int N1, int N2,
+                    float* dW, int64_t ldw, float* db, int accumulate, void* workspace, hipStream_t st);
+}  // namespace dfm
+
 namespace {
 int pick_splits(int m, int n, int k) {
   const int64_t tiles = static_cast<int64_t>((m + BM - 1) / BM) * ((n + BN - 1) / BN);
@@ -92,7 +101,13 @@ int pick_splits(int m, int n, int k) {
 
 extern "C" size_t dfm_gemm_workspace_bytes(int m, int n, int k) {
   const int s = pick_splits(m, n, k);
-  return s > 1 ? sizeof(float) * static_cast<size_t>(s) * m * n : 0;
+  size_t bytes = s > 1 ? sizeof(float) * static_cast<size_t>(s) * m * n : 0;
+  // (the caller does not say which operand layout it will use: cover the streamed weight gradient too)
+  if (dfm::gemm_wgrad_supported(k, m, n)) {
+    const size_t w = dfm::gemm_wgrad_workspace_bytes(k, m, n);
+    bytes = w > bytes ? w : bytes;
+  }
+  return bytes;
 }
 
 extern "C" int dfm_gemm_f32(const float* d_a, int64_t lda, int a_k_contiguous, const float* d_b, int64_t ldb,
@@ -100,6 +115,18 @@ extern "C" int dfm_gemm_f32(const float* d_a, int64_t lda, int a_k_contiguous, c
                             const float* d_bias, int accumulate, void* d_workspace, dfm_stream_t stream) {
   DFM_REQUIRE(d_a && d_b && d_c, "null argument");
   DFM_REQUIRE(m > 0 && n > 0 && k > 0, "bad shape");
+  // many rows against a tiny weight (the attention projections and their gradients): gemm_skinny.hip
+  if (a_k_contiguous && dfm::gemm_rows_try(d_a, lda, d_b, ldb, b_k_contiguous != 0, d_c, ldc, m, n, k, d_bias,
+                                           accumulate, as_stream(stream))) {
+    DFM_LAUNCH_CHECK();
+    return DFM_OK;
+  }
+  if (!a_k_contiguous && !b_k_contiguous && !d_bias &&
+      dfm::gemm_wgrad_try(d_a, lda, d_b, ldb, k, m, n, d_c, ldc, nullptr, accumulate, d_workspace,
+                          as_stream(stream))) {
+    DFM_LAUNCH_CHECK();
+    return DFM_OK;
+  }
   int splits = d_workspace ? pick_splits(m, n, k) : 1;
   int k_per_split = ((k + splits - 1) / splits + BK - 1) / BK * BK;
   splits = (k + k_per_split - 1) / k_per_split;

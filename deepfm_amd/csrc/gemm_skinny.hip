@@ -1,0 +1,358 @@
+// Exact-fp32 MFMA GEMMs for the "many rows, tiny weight" shapes of the attention projections
+// (attention.py:95-97, :115 and their autograd: B*F = 159 744 rows against 32 ... 192 columns).
+// These are HBM-bound (the QKV projection reads 20 MB and writes 123 MB for 2 GFLOP); the tiled
+// kernel of gemm_f32.hip spends them in per-tile prologues (one 32-deep slice per 64 x 64 tile).
+// Here nothing is staged through LDS and there is no workgroup barrier:
+//
+//   rows kernel    C[M,N] (+)= A[M,K] W^T (+ bias)       N <= 192, K <= 192, N*K <= 6144
+//     The whole weight lives in REGISTERS as MFMA B fragments (<= 96 VGPRs), loaded once per wave.
+//     A wave walks 32-row tiles of A: one float4 load per lane and 8 k, straight into the A-fragment
+//     layout (the k order inside a v_mfma_f32_32x32x2 chain is free as long as A and B agree: lane
+//     half h takes k = 8j + 4h .. 8j + 4h + 3, so the loads are 16-byte row pieces), N/32
+//     independent accumulators, 128-byte coalesced row stores.
+//   weight-gradient kernel   dW[N1,N2] (+)= G[M,N1]^T X[M,N2],  db[N1] (+)= sum_m G[m,:]
+//     both operands stream (coalesced 128-byte row pieces, the reduction index m is the MFMA k);
+//     every wave keeps the whole dW in accumulators over its row chunks, the four waves of a
+//     workgroup are added through LDS, the per-workgroup partials by a second kernel in a fixed
+//     order (bitwise reproducible).  db comes from the A fragments with VALU adds — no ones-column
+//     GEMM.
+#include "common.h"
+
+using namespace dfm;
+
+namespace {
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kWaves = 4;
+constexpr int kMaxResidentWaves = 2 * 256 * kWaves;   // 2 workgroups per CU
+constexpr int kWgradWaves = 256 * kWaves;             // weight gradient: one workgroup per CU (the per-wave epilogue is heavy)
+
+// ---- rows kernel -----------------------------------------------------------------------------
+template <int NT, int K>
+__global__ __launch_bounds__(kWaves * 64, 2) void gemm_rows_kernel(
+    const float* __restrict__ A, int64_t lda, const float* __restrict__ W, int64_t ldw, int w_kc,
+    float* __restrict__ C, int64_t ldc, int64_t M, const float* __restrict__ bias, int accumulate,
+    int tiles_per_wave) {
+  constexpr int KH = K / 2;                        // k values per lane (its half of every k pair)
+  const int lane = lane_id(), wave = wave_id_uniform();
+  const int r = lane & 31, hf = lane >> 5;
+  const int64_t wid = static_cast<int64_t>(blockIdx.x) * kWaves + wave;
+  const int64_t ntiles = (M + 31) / 32;
+  // B fragments: b[t][i] = W(n = 32 t + r, k = kmap(i)), kmap(i) = 8 (i / 4) + 4 hf + i % 4
+  float b[NT][KH];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int n = t * 32 + r;
+    if (w_kc) {
+#pragma unroll
+      for (int j = 0; j < K / 8; ++j) {
+        const float4 v = ld4(W + n * ldw + 8 * j + 4 * hf);
+        b[t][4 * j] = v.x; b[t][4 * j + 1] = v.y; b[t][4 * j + 2] = v.z; b[t][4 * j + 3] = v.w;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < KH; ++i) b[t][i] = W[(8 * (i >> 2) + 4 * hf + (i & 3)) * ldw + n];
+    }
+  }
+  float bv[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) bv[t] = bias ? bias[t * 32 + r] : 0.f;
+
+  // A fragments of a tile: one float4 per lane and 8 k (rows clamped: a dead row only reaches a dead
+  // output row).  With K <= 64 the next tile's fragments are requested before this tile's MFMAs.
+  constexpr bool PREFETCH = KH <= 32;
+  auto load_a = [&](int64_t tile, float (&dst)[KH]) __attribute__((always_inline)) {
+    const int64_t row = tile * 32 + r;
+    const float* arow = A + (row < M ? row : M - 1) * lda + 4 * hf;
+#pragma unroll
+    for (int j = 0; j < K / 8; ++j) {
+      const float4 v = ld4(arow + 8 * j);
+      dst[4 * j] = v.x; dst[4 * j + 1] = v.y; dst[4 * j + 2] = v.z; dst[4 * j + 3] = v.w;
+    }
+  };
+  const int64_t tile0 = wid * tiles_per_wave;
+  float a[KH], an[KH];
+  if (PREFETCH && tile0 < ntiles) load_a(tile0, an);
+  for (int it = 0; it < tiles_per_wave; ++it) {
+    const int64_t tile = tile0 + it;                         // wave-uniform
+    if (tile >= ntiles) break;
+    if (PREFETCH) {
+#pragma unroll
+      for (int i = 0; i < KH; ++i) a[i] = an[i];
+      if (it + 1 < tiles_per_wave && tile + 1 < ntiles) load_a(tile + 1, an);
+    } else {
+      load_a(tile, a);
+    }
+    // column tiles in groups of at most three: 48 accumulator registers live at a time (six tiles
+    // at once needed 324 VGPRs: one wave per SIMD, or spills at two)
+    constexpr int TG = NT > 3 ? 3 : NT;
+    float* cbase = C + (tile * 32 + 4 * hf) * ldc + r;
+    const int64_t rlim = M - (tile * 32 + 4 * hf);             // row offset (q & 3) + 8 (q >> 2) must stay below
+#pragma unroll
+    for (int g0 = 0; g0 < NT; g0 += TG) {
+      f32x16 acc[TG];
+#pragma unroll
+      for (int t = 0; t < TG; ++t) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[t][q] = bv[g0 + t];
+      }
+#pragma unroll
+      for (int i = 0; i < KH; ++i) {
+#pragma unroll
+        for (int t = 0; t < TG; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[g0 + t][i], acc[t], 0, 0, 0);
+      }
+      // accumulator register q: row (q & 3) + 8 (q >> 2) + 4 hf of the tile, column r
+      if (accumulate) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int ro = (q & 3) + 8 * (q >> 2);
+          if (ro < rlim) {
+#pragma unroll
+            for (int t = 0; t < TG; ++t) cbase[ro * ldc + (g0 + t) * 32] += acc[t][q];
+          }
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int ro = (q & 3) + 8 * (q >> 2);
+          if (ro < rlim) {
+#pragma unroll
+            for (int t = 0; t < TG; ++t) cbase[ro * ldc + (g0 + t) * 32] = acc[t][q];
+          }
+        }
+      }
+    }
+  }
+}
+
+// ---- weight-gradient kernel ----------------------------------------------------------------------
+// partial[block][N1*N2 + N1]: the workgroup's dW (row-major N1 x N2) followed by its db
+template <int T1, int T2>
+__global__ __launch_bounds__(kWaves * 64, 2) void gemm_wgrad_kernel(
+    const float* __restrict__ G, int64_t ldg, const float* __restrict__ X, int64_t ldx, int64_t M,
+    float* __restrict__ partial, int chunks_per_wave) {
+  constexpr int N1 = T1 * 32, N2 = T2 * 32;
+  constexpr int PS = N1 * N2 + N1;
+  __shared__ float red[2 * PS];                    // two waves' partials at a time (<= 50 KB)
+  const int lane = lane_id(), wave = wave_id_uniform();
+  const int r = lane & 31, hf = lane >> 5;
+  const int64_t wid = static_cast<int64_t>(blockIdx.x) * kWaves + wave;
+  const int64_t nchunks = (M + 31) / 32;
+  f32x16 acc[T1][T2];
+  float colsum[T1];
+#pragma unroll
+  for (int t1 = 0; t1 < T1; ++t1) {
+    colsum[t1] = 0.f;
+#pragma unroll
+    for (int t2 = 0; t2 < T2; ++t2) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[t1][t2][q] = 0.f;
+    }
+  }
+  for (int it = 0; it < chunks_per_wave; ++it) {
+    const int64_t chunk = wid * chunks_per_wave + it;        // wave-uniform
+    if (chunk >= nchunks) break;
+    const int64_t m0 = chunk * 32 + hf;
+    // k pair i of the chunk = rows m0 + 2 i (lane half 0) and m0 + 2 i + 1 (half 1); lane r = column
+    float a[T1][16], bq[T2][16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int64_t m = m0 + 2 * i;
+      const bool ok = m < M;
+      const int64_t mc = ok ? m : M - 1;
+#pragma unroll
+      for (int t1 = 0; t1 < T1; ++t1) {
+        const float v = G[mc * ldg + t1 * 32 + r];
+        a[t1][i] = ok ? v : 0.f;
+      }
+#pragma unroll
+      for (int t2 = 0; t2 < T2; ++t2) {
+        const float v = X[mc * ldx + t2 * 32 + r];
+        bq[t2][i] = ok ? v : 0.f;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+#pragma unroll
+      for (int t1 = 0; t1 < T1; ++t1) {
+        colsum[t1] += a[t1][i];
+#pragma unroll
+        for (int t2 = 0; t2 < T2; ++t2)
+          acc[t1][t2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t1][i], bq[t2][i], acc[t1][t2], 0, 0, 0);
+      }
+    }
+  }
+  // db: the two lane halves saw alternate rows
+#pragma unroll
+  for (int t1 = 0; t1 < T1; ++t1) colsum[t1] += __shfl_xor(colsum[t1], 32, kWave);
+  // element (n1 = 32 t1 + row(q), n2 = 32 t2 + r) of this wave's partial dW
+  auto put = [&](float* dst) {
+#pragma unroll
+    for (int t1 = 0; t1 < T1; ++t1) {
+#pragma unroll
+      for (int t2 = 0; t2 < T2; ++t2) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int n1 = t1 * 32 + (q & 3) + 8 * (q >> 2) + 4 * hf;
+          dst[n1 * N2 + t2 * 32 + r] = acc[t1][t2][q];
+        }
+      }
+      if (hf == 0) dst[N1 * N2 + t1 * 32 + r] = colsum[t1];
+    }
+  };
+  auto add = [&](const float* src) {
+#pragma unroll
+    for (int t1 = 0; t1 < T1; ++t1) {
+#pragma unroll
+      for (int t2 = 0; t2 < T2; ++t2) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int n1 = t1 * 32 + (q & 3) + 8 * (q >> 2) + 4 * hf;
+          acc[t1][t2][q] += src[n1 * N2 + t2 * 32 + r];
+        }
+      }
+      colsum[t1] += src[N1 * N2 + t1 * 32 + r];
+    }
+  };
+  // fixed order: (wave 0 + wave 2) + (wave 1 + wave 3)
+  static_assert(kWaves == 4, "the reduction tree below is written for four waves");
+  if (wave >= 2) put(red + (wave - 2) * PS);
+  __syncthreads();
+  if (wave < 2) add(red + wave * PS);
+  __syncthreads();
+  if (wave == 1) put(red);
+  __syncthreads();
+  if (wave == 0) {
+    add(red);
+    put(partial + static_cast<int64_t>(blockIdx.x) * PS);
+  }
+}
+
+// out[e] (+)= sum_blocks partial[block][e]  (fixed order); the last N1 entries go to db.
+// 64 elements per workgroup, four threads per element: thread (e, g) adds blocks g, g+4, g+8, ... and
+// the four sums are added in the order g = 0,1,2,3.
+__global__ __launch_bounds__(256) void gemm_wgrad_reduce(const float* __restrict__ partial, int blocks, int n1n2,
+                                                         int n1, int N2, float* __restrict__ dW, int64_t ldw,
+                                                         float* __restrict__ db, int accumulate) {
+  __shared__ float part[4][64];
+  const int el = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + el;
+  const int total = n1n2 + n1;
+  float acc = 0.f;
+  if (e < total) {
+    int s = g;
+    for (; s + 28 < blocks; s += 32) {
+      float t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = partial[static_cast<int64_t>(s + 4 * u) * total + e];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += t[u];
+    }
+    for (; s < blocks; s += 4) acc += partial[static_cast<int64_t>(s) * total + e];
+  }
+  part[g][el] = acc;
+  __syncthreads();
+  if (g != 0 || e >= total) return;
+  acc = ((part[0][el] + part[1][el]) + part[2][el]) + part[3][el];
+  if (e < n1n2) {
+    float* dst = dW + static_cast<int64_t>(e / N2) * ldw + e % N2;
+    *dst = accumulate ? *dst + acc : acc;
+  } else if (db) {
+    db[e - n1n2] = accumulate ? db[e - n1n2] + acc : acc;
+  }
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+int wgrad_blocks(int64_t M, int* chunks_per_wave) {
+  const int64_t nchunks = (M + 31) / 32;
+  const int64_t cpw = (nchunks + kWgradWaves - 1) / kWgradWaves;
+  *chunks_per_wave = static_cast<int>(cpw);
+  const int64_t waves = (nchunks + cpw - 1) / cpw;
+  return static_cast<int>((waves + kWaves - 1) / kWaves);
+}
+}  // namespace
+
+namespace dfm {
+constexpr int64_t kSkinnyMinRows = 8192;
+
+// C (+)= A W^T (+ bias) on the rows kernel; false if the shape is not one it takes
+bool gemm_rows_try(const float* A, int64_t lda, const float* W, int64_t ldw, bool w_kc, float* C, int64_t ldc,
+                   int64_t M, int N, int K, const float* bias, int accumulate, hipStream_t st) {
+  if (M < kSkinnyMinRows || !aligned16(A) || lda % 4 != 0) return false;
+  if (w_kc && (!aligned16(W) || ldw % 4 != 0)) return false;
+  const int64_t ntiles = (M + 31) / 32;
+  const int64_t tpw = (ntiles + kMaxResidentWaves - 1) / kMaxResidentWaves;
+  const int64_t waves = (ntiles + tpw - 1) / tpw;
+  const dim3 grid(static_cast<unsigned>((waves + kWaves - 1) / kWaves)), block(kWaves * 64);
+#define DFM_ROWS(NT_, K_)                                                                                      \
+  if (N == NT_ * 32 && K == K_) {                                                                              \
+    hipLaunchKernelGGL((gemm_rows_kernel<NT_, K_>), grid, block, 0, st, A, lda, W, ldw, w_kc ? 1 : 0, C, ldc, M, \
+                       bias, accumulate, static_cast<int>(tpw));                                               \
+    return true;                                                                                               \
+  }
+  if (N == 192 && K == 32) {
+    // six column tiles need > 256 VGPRs with the whole weight resident (one wave per SIMD, or spills):
+    // two launches over three tiles each; A (the small operand of this shape) is read twice
+    for (int half = 0; half < 2; ++half)
+      hipLaunchKernelGGL((gemm_rows_kernel<3, 32>), grid, block, 0, st, A, lda, w_kc ? W + 96 * half * ldw : W + 96 * half,
+                         ldw, w_kc ? 1 : 0, C + 96 * half, ldc, M, bias ? bias + 96 * half : nullptr, accumulate,
+                         static_cast<int>(tpw));
+    return true;
+  }
+  DFM_ROWS(1, 64) DFM_ROWS(1, 192) DFM_ROWS(2, 32)                       // Cfg4: out, d x, d o (qkv above)
+  DFM_ROWS(3, 16) DFM_ROWS(1, 32) DFM_ROWS(1, 96) DFM_ROWS(3, 32) DFM_ROWS(2, 64) DFM_ROWS(1, 16)
+#undef DFM_ROWS
+  return false;
+}
+
+size_t gemm_wgrad_workspace_bytes(int64_t M, int N1, int N2) {
+  int cpw;
+  return sizeof(float) * static_cast<size_t>(wgrad_blocks(M, &cpw)) * (static_cast<size_t>(N1) * N2 + N1);
+}
+
+bool gemm_wgrad_supported(int64_t M, int N1, int N2) {
+  if (M < kSkinnyMinRows) return false;
+  const int t1 = N1 / 32, t2 = N2 / 32;
+  if (N1 % 32 || N2 % 32) return false;
+  return (t1 == 6 && t2 == 1) || (t1 == 1 && t2 == 2) || (t1 == 1 && t2 == 1) || (t1 == 2 && t2 == 1) ||
+         (t1 == 3 && t2 == 1) || (t1 == 2 && t2 == 2) || (t1 == 1 && t2 == 3);
+}
+
+// dW (+)= G^T X, db (+)= column sums of G (db may be null); false if the shape is not taken
+bool gemm_wgrad_try(const float* G, int64_t ldg, const float* X, int64_t ldx, int64_t M, int N1, int N2,
+                    float* dW, int64_t ldw, float* db, int accumulate, void* workspace, hipStream_t st) {
+  if (!workspace || !gemm_wgrad_supported(M, N1, N2)) return false;
+  int cpw;
+  const int blocks = wgrad_blocks(M, &cpw);
+  float* partial = static_cast<float*>(workspace);
+  const dim3 grid(blocks), block(kWaves * 64);
+#define DFM_WG(T1_, T2_)                                                                                    \
+  if (N1 == T1_ * 32 && N2 == T2_ * 32)                                                                     \
+    hipLaunchKernelGGL((gemm_wgrad_kernel<T1_, T2_>), grid, block, 0, st, G, ldg, X, ldx, M, partial, cpw);
+  DFM_WG(6, 1) DFM_WG(1, 2) DFM_WG(1, 1) DFM_WG(2, 1) DFM_WG(3, 1) DFM_WG(2, 2) DFM_WG(1, 3)
+#undef DFM_WG
+  const int total = N1 * N2 + N1;
+  hipLaunchKernelGGL(gemm_wgrad_reduce, dim3((total + 63) / 64), dim3(256), 0, st, partial, blocks, N1 * N2, N1,
+                     N2, dW, ldw, db, accumulate);
+  return true;
+}
+}  // namespace dfm
+
+extern "C" size_t dfm_weight_grad_workspace_bytes(int64_t rows, int n1, int n2) {
+  return dfm::gemm_wgrad_supported(rows, n1, n2) ? dfm::gemm_wgrad_workspace_bytes(rows, n1, n2) : 0;
+}
+
+extern "C" int dfm_weight_grad_f32(const float* d_g, int64_t ldg, const float* d_x, int64_t ldx, int64_t rows,
+                                   int n1, int n2, float* d_dw, int64_t lddw, float* d_db, int accumulate,
+                                   void* d_workspace, dfm_stream_t stream) {
+  DFM_REQUIRE(d_g && d_x && d_dw, "null argument");
+  DFM_REQUIRE(rows > 0 && n1 > 0 && n2 > 0, "bad shape");
+  if (!dfm::gemm_wgrad_try(d_g, ldg, d_x, ldx, rows, n1, n2, d_dw, lddw, d_db, accumulate, d_workspace,
+                           as_stream(stream)))
+    return fail(DFM_ERR_UNSUPPORTED, "dfm_weight_grad_f32: no kernel for rows=%lld n1=%d n2=%d (workspace %p)",
+                (long long)rows, n1, n2, d_workspace);
+  DFM_LAUNCH_CHECK();
+  return DFM_OK;
+}

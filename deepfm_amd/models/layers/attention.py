@@ -82,6 +82,20 @@ def _ptrs(tensors):
     return arr
 
 
+def _weight_grad(g: torch.Tensor, x: torch.Tensor, rows: int, n1: int, n2: int, d_w: torch.Tensor,
+                 d_b: torch.Tensor) -> bool:
+    """dW = g^T x and db = column sums of g in one streamed pass (csrc/gemm_skinny.hip) when the shape
+    is one the kernel takes; False -> the caller uses the general GEMM (+ a ones-column GEMM)."""
+    lib = _lib.load()
+    ws_bytes = lib.dfm_weight_grad_workspace_bytes(rows, n1, n2)
+    if not ws_bytes:
+        return False
+    ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=g.device)
+    _lib.check(lib.dfm_weight_grad_f32(g.data_ptr(), n1, x.data_ptr(), n2, rows, n1, n2, d_w.data_ptr(), n2,
+                                       d_b.data_ptr(), 0, ws.data_ptr(), _lib.stream_handle()))
+    return True
+
+
 class _AttnGemmFn(torch.autograd.Function):
     """One _AttentionBlock as: QKV GEMM -> attention core -> output GEMM -> (+x, LayerNorm)."""
 
@@ -129,7 +143,6 @@ class _AttnGemmFn(torch.autograd.Function):
         dev = X.device
         g = g_out.contiguous().view(M, D)
         from deepfm_amd.models.layers.linear import ones_column
-        ones = ones_column(M, dev)
         grads = []
         if block.use_residual:
             g_y = torch.empty(M, D, dtype=torch.float32, device=dev)
@@ -142,18 +155,20 @@ class _AttnGemmFn(torch.autograd.Function):
         else:
             g_y = g
         d_wo = torch.empty(D, A, dtype=torch.float32, device=dev)
-        _gemm(g_y, D, False, o, A, False, d_wo, D, A, M)                         # dWo = g_y^T O
         d_bo = torch.empty(D, 1, dtype=torch.float32, device=dev)
-        _gemm(g_y, D, False, ones, 1, False, d_bo, D, 1, M)
+        if not _weight_grad(g_y, o, M, D, A, d_wo, d_bo):
+            _gemm(g_y, D, False, o, A, False, d_wo, D, A, M)                     # dWo = g_y^T O
+            _gemm(g_y, D, False, ones_column(M, dev), 1, False, d_bo, D, 1, M)
         d_o = torch.empty(M, A, dtype=torch.float32, device=dev)
         _gemm(g_y, D, True, wo, A, False, d_o, M, A, D)                          # dO = g_y Wo
         d_qkv = torch.empty(M, 3 * A, dtype=torch.float32, device=dev)
         _lib.check(lib.dfm_attention_core_backward(qkv.data_ptr(), d_o.data_ptr(), B, F, A, H, d_qkv.data_ptr(),
                                                    _lib.stream_handle()))
         d_wqkv = torch.empty(3 * A, D, dtype=torch.float32, device=dev)
-        _gemm(d_qkv, 3 * A, False, X, D, False, d_wqkv, 3 * A, D, M)             # dWqkv = dQKV^T X
         d_bqkv = torch.empty(3 * A, 1, dtype=torch.float32, device=dev)
-        _gemm(d_qkv, 3 * A, False, ones, 1, False, d_bqkv, 3 * A, 1, M)
+        if not _weight_grad(d_qkv, X, M, 3 * A, D, d_wqkv, d_bqkv):
+            _gemm(d_qkv, 3 * A, False, X, D, False, d_wqkv, 3 * A, D, M)         # dWqkv = dQKV^T X
+            _gemm(d_qkv, 3 * A, False, ones_column(M, dev), 1, False, d_bqkv, 3 * A, 1, M)
         if block.use_residual:
             d_x = g_y                                                            # residual branch, then +=
             _gemm(d_qkv, 3 * A, True, w_qkv, D, False, d_x, M, D, 3 * A, accumulate=True)

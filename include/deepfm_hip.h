@@ -481,6 +481,19 @@ int dfm_gemm_f32(const float* d_a, int64_t lda, int a_k_contiguous, const float*
                  int b_k_contiguous, float* d_c, int64_t ldc, int m, int n, int k,
                  const float* d_bias, int accumulate, void* d_workspace, dfm_stream_t stream);
 
+/* Weight and bias gradient of an nn.Linear over many rows (the attention projections W_q|W_k|W_v and
+ * W_out, attention.py:95-97, :115; rows = B*F):  dW[n1,n2] (+)= sum_r g[r,n1] * x[r,n2],
+ * db[n1] (+)= sum_r g[r,n1] (d_db may be NULL).  Both operands are streamed once, per-workgroup
+ * partials are summed in a fixed order (bitwise reproducible).  Shapes: n1, n2 multiples of 32 with
+ * (n1/32, n2/32) in {(6,1),(3,1),(2,1),(1,1),(1,2),(2,2),(1,3)} and rows >= 8192 — otherwise
+ * dfm_weight_grad_workspace_bytes returns 0 and the call DFM_ERR_UNSUPPORTED (use dfm_gemm_f32).
+ * dfm_gemm_f32 itself routes these shapes (and the many-rows x tiny-weight products
+ * C = A W^T with n*k <= 6144) to the same kernels (csrc/gemm_skinny.hip). */
+size_t dfm_weight_grad_workspace_bytes(int64_t rows, int n1, int n2);
+int dfm_weight_grad_f32(const float* d_g, int64_t ldg, const float* d_x, int64_t ldx, int64_t rows, int n1,
+                        int n2, float* d_dw, int64_t lddw, float* d_db, int accumulate, void* d_workspace,
+                        dfm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
