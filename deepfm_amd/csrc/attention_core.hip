@@ -275,28 +275,29 @@ __global__ __launch_bounds__(256) void layernorm_bwd(const float* __restrict__ g
   }
 }
 
-// d gamma / d beta += column sums of the partial planes: 16 lanes per column, fixed order
+// d gamma / d beta += column sums of the partial planes.  One workgroup per column d: thread t adds
+// partial rows t, t + 256, ... and the 256 sums are combined by a fixed binary tree (the old form,
+// two workgroups walking 1 248 rows with 16 threads per column, took 22 us of dependent loads).
 __global__ __launch_bounds__(256) void layernorm_bwd_finalize(const float* __restrict__ partial, int blocks, int D,
                                                               float* __restrict__ d_gamma,
                                                               float* __restrict__ d_beta) {
-  __shared__ float red[2][16][16];
-  const int cl = threadIdx.x % 16, sl = threadIdx.x / 16;
-  const int d = blockIdx.x * 16 + cl;
+  __shared__ float red[2][256];
+  const int d = blockIdx.x, t = threadIdx.x;
   float sg = 0.f, sb = 0.f;
-  if (d < D) {
-    for (int i = sl; i < blocks; i += 16) {
-      sg += partial[(static_cast<int64_t>(i) * 2 + 0) * D + d];
-      sb += partial[(static_cast<int64_t>(i) * 2 + 1) * D + d];
-    }
+  for (int i = t; i < blocks; i += 256) {
+    sg += partial[(static_cast<int64_t>(i) * 2 + 0) * D + d];
+    sb += partial[(static_cast<int64_t>(i) * 2 + 1) * D + d];
   }
-  red[0][sl][cl] = sg;
-  red[1][sl][cl] = sb;
+  red[0][t] = sg;
+  red[1][t] = sb;
   __syncthreads();
-  if (sl == 0 && d < D) {
-    float tg = 0.f, tb = 0.f;
-    for (int i = 0; i < 16; ++i) { tg += red[0][i][cl]; tb += red[1][i][cl]; }
-    d_gamma[d] += tg;
-    d_beta[d] += tb;
+  for (int w = 128; w > 0; w >>= 1) {
+    if (t < w) { red[0][t] += red[0][t + w]; red[1][t] += red[1][t + w]; }
+    __syncthreads();
+  }
+  if (t == 0) {
+    d_gamma[d] += red[0][0];
+    d_beta[d] += red[1][0];
   }
 }
 
@@ -394,7 +395,7 @@ extern "C" int dfm_layernorm_backward(const float* d_g_out, const float* d_y, co
   hipLaunchKernelGGL(layernorm_bwd, dim3(blocks), dim3(256), 0, st, d_g_out, d_y, d_res, d_stats, rows, dim,
                      ln_lanes(dim), d_gamma, d_g_sum, partial);
   DFM_LAUNCH_CHECK();
-  hipLaunchKernelGGL(layernorm_bwd_finalize, dim3((dim + 15) / 16), dim3(256), 0, st, partial, blocks, dim,
+  hipLaunchKernelGGL(layernorm_bwd_finalize, dim3(dim), dim3(256), 0, st, partial, blocks, dim,
                      d_g_gamma, d_g_beta);
   DFM_LAUNCH_CHECK();
   return DFM_OK;
