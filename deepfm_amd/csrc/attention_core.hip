@@ -275,6 +275,88 @@ __global__ __launch_bounds__(256) void layernorm_bwd(const float* __restrict__ g
   }
 }
 
+// ---- 16-byte variants (D a multiple of 4): a lane owns 4 consecutive d, D/4 (rounded up to a power of
+// two) lanes per row.  Same arithmetic per row; the row sums add the lane's four values first.
+__device__ __forceinline__ float sum4(const float4& v) { return (v.x + v.y) + (v.z + v.w); }
+
+__global__ __launch_bounds__(256) void layernorm_fwd4(const float* __restrict__ y, const float* __restrict__ res,
+                                                      int64_t rows, int D, int l4, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, float eps,
+                                                      float* __restrict__ out, float* __restrict__ stats) {
+  const int64_t t = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  const int64_t r = t / l4;
+  const int d = static_cast<int>(t % l4) * 4;
+  const bool live = r < rows && d < D;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (live) {
+    const float4 a = ld4(y + r * D + d), b = ld4(res + r * D + d);
+    v = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+  }
+  float mu = sum4(v);
+  for (int m = 1; m < l4; m <<= 1) mu += __shfl_xor(mu, m, kWave);
+  mu /= D;
+  const float4 c = live ? make_float4(v.x - mu, v.y - mu, v.z - mu, v.w - mu) : make_float4(0.f, 0.f, 0.f, 0.f);
+  float var = sum4(make_float4(c.x * c.x, c.y * c.y, c.z * c.z, c.w * c.w));
+  for (int m = 1; m < l4; m <<= 1) var += __shfl_xor(var, m, kWave);
+  const float rstd = rsqrtf(var / D + eps);
+  if (live) {
+    const float4 ga = ld4(gamma + d), be = ld4(beta + d);
+    st4(out + r * D + d, make_float4(c.x * rstd * ga.x + be.x, c.y * rstd * ga.y + be.y, c.z * rstd * ga.z + be.z,
+                                     c.w * rstd * ga.w + be.w));
+    if (d == 0) { stats[2 * r] = mu; stats[2 * r + 1] = rstd; }
+  }
+}
+
+__global__ __launch_bounds__(256) void layernorm_bwd4(const float* __restrict__ g, const float* __restrict__ y,
+                                                      const float* __restrict__ res,
+                                                      const float* __restrict__ stats, int64_t rows, int D, int l4,
+                                                      const float* __restrict__ gamma, float* __restrict__ g_s,
+                                                      float* __restrict__ partial) {
+  __shared__ float4 red[2][256];
+  const int rpp = 256 / l4;                        // rows per pass
+  const int sr = threadIdx.x / l4, q = threadIdx.x % l4, d = q * 4;
+  const int64_t r0 = static_cast<int64_t>(blockIdx.x) * kLnRows;
+  const bool dlive = d < D;
+  const float4 ga = dlive ? ld4(gamma + d) : make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 sg = make_float4(0.f, 0.f, 0.f, 0.f), sb = sg;
+  for (int pass = 0; pass < kLnRows / rpp; ++pass) {
+    const int64_t r = r0 + pass * rpp + sr;
+    const bool live = r < rows && dlive;
+    float4 gv = make_float4(0.f, 0.f, 0.f, 0.f), xh = gv;
+    float rstd = 0.f;
+    if (live) {
+      rstd = stats[2 * r + 1];
+      const float mu = stats[2 * r];
+      const float4 a = ld4(y + r * D + d), b = ld4(res + r * D + d);
+      xh = make_float4((a.x + b.x - mu) * rstd, (a.y + b.y - mu) * rstd, (a.z + b.z - mu) * rstd,
+                       (a.w + b.w - mu) * rstd);
+      gv = ld4(g + r * D + d);
+    }
+    const float4 gg = make_float4(gv.x * ga.x, gv.y * ga.y, gv.z * ga.z, gv.w * ga.w);
+    float m1 = sum4(gg), m2 = sum4(make_float4(gg.x * xh.x, gg.y * xh.y, gg.z * xh.z, gg.w * xh.w));
+    for (int m = 1; m < l4; m <<= 1) { m1 += __shfl_xor(m1, m, kWave); m2 += __shfl_xor(m2, m, kWave); }
+    m1 /= D; m2 /= D;
+    if (live)
+      st4(g_s + r * D + d, make_float4(rstd * (gg.x - m1 - xh.x * m2), rstd * (gg.y - m1 - xh.y * m2),
+                                       rstd * (gg.z - m1 - xh.z * m2), rstd * (gg.w - m1 - xh.w * m2)));
+    sg.x = fmaf(gv.x, xh.x, sg.x); sg.y = fmaf(gv.y, xh.y, sg.y); sg.z = fmaf(gv.z, xh.z, sg.z); sg.w = fmaf(gv.w, xh.w, sg.w);
+    sb.x += gv.x; sb.y += gv.y; sb.z += gv.z; sb.w += gv.w;
+  }
+  red[0][threadIdx.x] = sg;
+  red[1][threadIdx.x] = sb;
+  __syncthreads();
+  if (sr == 0 && dlive) {
+    float4 tg = make_float4(0.f, 0.f, 0.f, 0.f), tb = tg;
+    for (int i = 0; i < rpp; ++i) {
+      const float4 u = red[0][i * l4 + q], w = red[1][i * l4 + q];
+      tg.x += u.x; tg.y += u.y; tg.z += u.z; tg.w += u.w;
+      tb.x += w.x; tb.y += w.y; tb.z += w.z; tb.w += w.w;
+    }
+    st4(partial + (static_cast<int64_t>(blockIdx.x) * 2 + 0) * D + d, tg);
+    st4(partial + (static_cast<int64_t>(blockIdx.x) * 2 + 1) * D + d, tb);
+  }
+}
+
 // d gamma / d beta += column sums of the partial planes.  One workgroup per column d: thread t adds
 // partial rows t, t + 256, ... and the 256 sums are combined by a fixed binary tree (the old form,
 // two workgroups walking 1 248 rows with 16 threads per column, took 22 us of dependent loads).
@@ -362,6 +444,13 @@ extern "C" int dfm_attention_core_backward(const float* d_qkv, const float* d_g_
 
 namespace {
 int ln_lanes(int dim) { int l = 1; while (l < dim) l <<= 1; return l; }
+// 16-byte kernels: D a multiple of 4 and every row pointer 16-byte aligned
+bool ln_vec4(int dim, const void* a, const void* b, const void* c, const void* d, const void* e) {
+  const uintptr_t bits = reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) |
+                         reinterpret_cast<uintptr_t>(c) | reinterpret_cast<uintptr_t>(d) |
+                         reinterpret_cast<uintptr_t>(e);
+  return dim % 4 == 0 && (bits & 15) == 0;
+}
 }
 extern "C" size_t dfm_layernorm_workspace_bytes(int64_t rows, int dim) {
   return sizeof(float) * 2 * static_cast<size_t>((rows + kLnRows - 1) / kLnRows) * dim;
@@ -373,6 +462,14 @@ extern "C" int dfm_layernorm_forward(const float* d_y, const float* d_res, int64
   DFM_REQUIRE(d_y && d_res && d_gamma && d_beta && d_out && d_stats, "null argument");
   DFM_REQUIRE(rows >= 0 && dim > 0 && dim <= 64, "LayerNorm kernel supports 1 <= dim <= 64");
   if (rows == 0) return DFM_OK;
+  if (ln_vec4(dim, d_y, d_res, d_out, d_gamma, d_beta)) {
+    const int l4 = ln_lanes(dim / 4);
+    const int64_t threads = rows * l4;
+    hipLaunchKernelGGL(layernorm_fwd4, dim3(static_cast<unsigned>((threads + 255) / 256)), dim3(256), 0,
+                       as_stream(stream), d_y, d_res, rows, dim, l4, d_gamma, d_beta, eps, d_out, d_stats);
+    DFM_LAUNCH_CHECK();
+    return DFM_OK;
+  }
   const int lpr = ln_lanes(dim);
   const int64_t threads = rows * lpr;
   hipLaunchKernelGGL(layernorm_fwd, dim3(static_cast<unsigned>((threads + 255) / 256)), dim3(256), 0,
@@ -392,8 +489,12 @@ extern "C" int dfm_layernorm_backward(const float* d_g_out, const float* d_y, co
   hipStream_t st = as_stream(stream);
   const int blocks = static_cast<int>((rows + kLnRows - 1) / kLnRows);
   float* partial = static_cast<float*>(d_workspace);
-  hipLaunchKernelGGL(layernorm_bwd, dim3(blocks), dim3(256), 0, st, d_g_out, d_y, d_res, d_stats, rows, dim,
-                     ln_lanes(dim), d_gamma, d_g_sum, partial);
+  if (ln_vec4(dim, d_y, d_res, d_g_out, d_gamma, d_g_sum) && (reinterpret_cast<uintptr_t>(partial) & 15) == 0)
+    hipLaunchKernelGGL(layernorm_bwd4, dim3(blocks), dim3(256), 0, st, d_g_out, d_y, d_res, d_stats, rows, dim,
+                       ln_lanes(dim / 4), d_gamma, d_g_sum, partial);
+  else
+    hipLaunchKernelGGL(layernorm_bwd, dim3(blocks), dim3(256), 0, st, d_g_out, d_y, d_res, d_stats, rows, dim,
+                       ln_lanes(dim), d_gamma, d_g_sum, partial);
   DFM_LAUNCH_CHECK();
   hipLaunchKernelGGL(layernorm_bwd_finalize, dim3(dim), dim3(256), 0, st, partial, blocks, dim,
                      d_g_gamma, d_g_beta);
