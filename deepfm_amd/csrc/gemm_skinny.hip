@@ -16,6 +16,9 @@
 //     workgroup are added through LDS, the per-workgroup partials by a second kernel in a fixed
 //     order (bitwise reproducible).  db comes from the A fragments with VALU adds — no ones-column
 //     GEMM.
+// (One workgroup per CU with a second register set for the next tile / row chunk was slower: beyond
+// 256 VGPRs the extra registers are AGPRs, which loads and VALU reach only through copies —
+// weight gradient 59 -> 167 us, K = 192 rows kernel 55 -> 69 us.)
 #include "common.h"
 
 using namespace dfm;
