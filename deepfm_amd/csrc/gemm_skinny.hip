@@ -28,7 +28,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kWaves = 4;
 constexpr int kMaxResidentWaves = 2 * 256 * kWaves;   // 2 workgroups per CU
-constexpr int kWgradWaves = 256 * kWaves;             // weight gradient: one workgroup per CU (the per-wave epilogue is heavy)
+constexpr int kWgradWaves = 2 * 256 * kWaves;         // weight gradient: two workgroups per CU
 
 // ---- rows kernel -----------------------------------------------------------------------------
 template <int NT, int K>
