@@ -60,15 +60,27 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void attn_core_fwd(const float
   float q[HD];
   load_row<HD>(base + row * rs, q);
   const float inv_scale = 1.f / sqrtf(static_cast<float>(HD));
+  const int last = F - 1;
+  constexpr int kGroup = HD <= 16 ? 3 : 2;                   // rows per scalar-load group (SGPR budget)
   // scores of this lane's row; running max
   float mx = -INFINITY;
-#pragma unroll 3
-  for (int j = 0; j < F; ++j) {
-    float kr[HD];
-    load_row<HD>(base + j * rs + A, kr);                     // uniform address: scalar load
-    const float acc = dot_row<HD>(q, kr) * inv_scale;
-    if (live) prow[j] = acc;
-    mx = fmaxf(mx, acc);
+  // rows in groups of kGroup: the group's scalar loads are issued together (distinct SGPR sets), so a
+  // cache-missing row costs one L2 round trip per group, not per row; past-the-end rows of the last
+  // group are clamped loads whose results are skipped (uniform branch)
+  for (int j0 = 0; j0 < F; j0 += kGroup) {
+    float kr[kGroup][HD];
+#pragma unroll
+    for (int u = 0; u < kGroup; ++u) load_row<HD>(base + (j0 + u < F ? j0 + u : last) * rs + A, kr[u]);
+    __builtin_amdgcn_sched_barrier(0);         // all of the group's loads are issued before any is waited for
+    // (no branch on j0 + u < F: a branch lets the compiler sink the scalar load into it, one round
+    // trip per row again.  A past-the-end slot re-does row F - 1: same value, same address.)
+#pragma unroll
+    for (int u = 0; u < kGroup; ++u) {
+      const int jc = j0 + u < F ? j0 + u : last;
+      const float acc = dot_row<HD>(q, kr[u]) * inv_scale;
+      if (live) prow[jc] = acc;
+      mx = fmaxf(mx, acc);
+    }
   }
   float sum = 0.f;
   for (int j = 0; j < F; ++j) {
@@ -80,13 +92,18 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void attn_core_fwd(const float
   float out[HD];
 #pragma unroll
   for (int e = 0; e < HD; ++e) out[e] = 0.f;
-#pragma unroll 3
-  for (int j = 0; j < F; ++j) {
-    float vr[HD];
-    load_row<HD>(base + j * rs + 2 * A, vr);
-    const float p = prow[j] * inv;
+  for (int j0 = 0; j0 < F; j0 += kGroup) {
+    float vr[kGroup][HD];
 #pragma unroll
-    for (int e = 0; e < HD; ++e) out[e] = fmaf(p, vr[e], out[e]);
+    for (int u = 0; u < kGroup; ++u) load_row<HD>(base + (j0 + u < F ? j0 + u : last) * rs + 2 * A, vr[u]);
+    __builtin_amdgcn_sched_barrier(0);         // all of the group's loads are issued before any is waited for
+#pragma unroll
+    for (int u = 0; u < kGroup; ++u) {
+      const bool ok = j0 + u < F;
+      const float p = ok ? prow[ok ? j0 + u : last] * inv : 0.f;
+#pragma unroll
+      for (int e = 0; e < HD; ++e) out[e] = fmaf(p, vr[u][e], out[e]);
+    }
   }
   if (live) {
     float* dst = o + (b * F + lane) * A + h * HD;
@@ -120,14 +137,22 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void attn_core_bwd(const float
   load_row<HD>(gbase + static_cast<int64_t>(row) * A, g);
   float* mrow = Ms + row * F;       // dead lanes shadow row 0 and never write
   // ---- P row of this lane ---------------------------------------------------------------------
+  const int last = F - 1;
+  constexpr int kGroup = HD <= 16 ? 3 : 2;                   // rows per scalar-load group (see attn_core_fwd)
+  constexpr int kGroup2 = HD <= 16 ? 2 : 1;                  // sweeps that load two rows per j
   float mx = -INFINITY;
-#pragma unroll 3
-  for (int j = 0; j < F; ++j) {
-    float kr[HD];
-    load_row<HD>(base + j * rs + A, kr);
-    const float acc = dot_row<HD>(q, kr) * inv_scale;
-    if (live) mrow[j] = acc;
-    mx = fmaxf(mx, acc);
+  for (int j0 = 0; j0 < F; j0 += kGroup) {
+    float kr[kGroup][HD];
+#pragma unroll
+    for (int u = 0; u < kGroup; ++u) load_row<HD>(base + (j0 + u < F ? j0 + u : last) * rs + A, kr[u]);
+    __builtin_amdgcn_sched_barrier(0);         // all of the group's loads are issued before any is waited for
+#pragma unroll
+    for (int u = 0; u < kGroup; ++u) {
+      const int jc = j0 + u < F ? j0 + u : last;           // past the end: row F - 1 again (same value)
+      const float acc = dot_row<HD>(q, kr[u]) * inv_scale;
+      if (live) mrow[jc] = acc;
+      mx = fmaxf(mx, acc);
+    }
   }
   float sum = 0.f;
   for (int j = 0; j < F; ++j) {
@@ -137,14 +162,19 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void attn_core_bwd(const float
   }
   const float inv = 1.f / sum;
   float dot = 0.f;                  // sum_j dP_ij P_ij
-#pragma unroll 3
-  for (int j = 0; j < F; ++j) {
-    float vr[HD];
-    load_row<HD>(base + j * rs + 2 * A, vr);
-    const float p = mrow[j] * inv;
-    const float dp = dot_row<HD>(g, vr);
-    if (live) mrow[j] = p;
-    dot = fmaf(dp, p, dot);
+  for (int j0 = 0; j0 < F; j0 += kGroup) {
+    float vr[kGroup][HD];
+#pragma unroll
+    for (int u = 0; u < kGroup; ++u) load_row<HD>(base + (j0 + u < F ? j0 + u : last) * rs + 2 * A, vr[u]);
+    __builtin_amdgcn_sched_barrier(0);         // all of the group's loads are issued before any is waited for
+#pragma unroll
+    for (int u = 0; u < kGroup; ++u) {
+      const bool ok = j0 + u < F;
+      const float p = mrow[ok ? j0 + u : 0] * inv;
+      const float dp = dot_row<HD>(g, vr[u]);
+      if (live && ok) mrow[ok ? j0 + u : 0] = p;
+      dot = fmaf(dp, ok ? p : 0.f, dot);
+    }
   }
   // ---- dV[j] = sum_i P[i][j] dO[i]   (lane j owns key/value row j) ----------------------------------
   float* dbase = d_qkv + b * F * 3 * A + h * HD;
@@ -152,13 +182,18 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void attn_core_bwd(const float
     float dv[HD];
 #pragma unroll
     for (int e = 0; e < HD; ++e) dv[e] = 0.f;
-#pragma unroll 3
-    for (int i = 0; i < F; ++i) {
-      float gr[HD];
-      load_row<HD>(gbase + static_cast<int64_t>(i) * A, gr);
-      const float p = Ms[i * F + row];
+    for (int i0 = 0; i0 < F; i0 += kGroup) {
+      float gr[kGroup][HD];
 #pragma unroll
-      for (int e = 0; e < HD; ++e) dv[e] = fmaf(p, gr[e], dv[e]);
+      for (int u = 0; u < kGroup; ++u) load_row<HD>(gbase + static_cast<int64_t>(i0 + u < F ? i0 + u : last) * A, gr[u]);
+    __builtin_amdgcn_sched_barrier(0);         // all of the group's loads are issued before any is waited for
+#pragma unroll
+      for (int u = 0; u < kGroup; ++u) {
+        const bool ok = i0 + u < F;
+        const float p = ok ? Ms[(ok ? i0 + u : last) * F + row] : 0.f;
+#pragma unroll
+        for (int e = 0; e < HD; ++e) dv[e] = fmaf(p, gr[u][e], dv[e]);
+      }
     }
     if (live) {
 #pragma unroll
@@ -170,16 +205,24 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void attn_core_bwd(const float
     float dq[HD];
 #pragma unroll
     for (int e = 0; e < HD; ++e) dq[e] = 0.f;
-#pragma unroll 3
-    for (int j = 0; j < F; ++j) {
-      float vr[HD], kr[HD];
-      load_row<HD>(base + j * rs + 2 * A, vr);
-      load_row<HD>(base + j * rs + A, kr);
-      const float dp = dot_row<HD>(g, vr);
-      const float ds = mrow[j] * (dp - dot) * inv_scale;
-      if (live) mrow[j] = ds;
+    for (int j0 = 0; j0 < F; j0 += kGroup2) {
+      float vr[kGroup2][HD], kr[kGroup2][HD];
 #pragma unroll
-      for (int e = 0; e < HD; ++e) dq[e] = fmaf(ds, kr[e], dq[e]);
+      for (int u = 0; u < kGroup2; ++u) {
+        const int64_t jr = (j0 + u < F ? j0 + u : last) * rs;
+        load_row<HD>(base + jr + 2 * A, vr[u]);
+        load_row<HD>(base + jr + A, kr[u]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < kGroup2; ++u) {
+        const bool ok = j0 + u < F;
+        const float dp = dot_row<HD>(g, vr[u]);
+        const float ds = ok ? mrow[ok ? j0 + u : 0] * (dp - dot) * inv_scale : 0.f;
+        if (live && ok) mrow[ok ? j0 + u : 0] = ds;
+#pragma unroll
+        for (int e = 0; e < HD; ++e) dq[e] = fmaf(ds, kr[u][e], dq[e]);
+      }
     }
     if (live) {
 #pragma unroll
@@ -191,13 +234,18 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void attn_core_bwd(const float
     float dk[HD];
 #pragma unroll
     for (int e = 0; e < HD; ++e) dk[e] = 0.f;
-#pragma unroll 3
-    for (int i = 0; i < F; ++i) {
-      float qr[HD];
-      load_row<HD>(base + i * rs, qr);
-      const float ds = Ms[i * F + row];
+    for (int i0 = 0; i0 < F; i0 += kGroup) {
+      float qr[kGroup][HD];
 #pragma unroll
-      for (int e = 0; e < HD; ++e) dk[e] = fmaf(ds, qr[e], dk[e]);
+      for (int u = 0; u < kGroup; ++u) load_row<HD>(base + (i0 + u < F ? i0 + u : last) * rs, qr[u]);
+    __builtin_amdgcn_sched_barrier(0);         // all of the group's loads are issued before any is waited for
+#pragma unroll
+      for (int u = 0; u < kGroup; ++u) {
+        const bool ok = i0 + u < F;
+        const float ds = ok ? Ms[(ok ? i0 + u : last) * F + row] : 0.f;
+#pragma unroll
+        for (int e = 0; e < HD; ++e) dk[e] = fmaf(ds, qr[u][e], dk[e]);
+      }
     }
     if (live) {
 #pragma unroll
