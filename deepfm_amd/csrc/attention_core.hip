@@ -67,10 +67,12 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void attn_core_fwd(const float
   // rows in groups of kGroup: the group's scalar loads are issued together (distinct SGPR sets), so a
   // cache-missing row costs one L2 round trip per group, not per row; past-the-end rows of the last
   // group are clamped loads whose results are skipped (uniform branch)
-  for (int j0 = 0; j0 < F; j0 += kGroup) {
+  const float* kp = base + A;                                // K row j0; running pointer (no multiply per row)
+  const float* const k_last = base + A + last * rs;
+  for (int j0 = 0; j0 < F; j0 += kGroup, kp += kGroup * rs) {
     float kr[kGroup][HD];
 #pragma unroll
-    for (int u = 0; u < kGroup; ++u) load_row<HD>(base + (j0 + u < F ? j0 + u : last) * rs + A, kr[u]);
+    for (int u = 0; u < kGroup; ++u) load_row<HD>(j0 + u < F ? kp + u * rs : k_last, kr[u]);
     __builtin_amdgcn_sched_barrier(0);         // all of the group's loads are issued before any is waited for
     // (no branch on j0 + u < F: a branch lets the compiler sink the scalar load into it, one round
     // trip per row again.  A past-the-end slot re-does row F - 1: same value, same address.)
@@ -92,10 +94,12 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void attn_core_fwd(const float
   float out[HD];
 #pragma unroll
   for (int e = 0; e < HD; ++e) out[e] = 0.f;
-  for (int j0 = 0; j0 < F; j0 += kGroup) {
+  const float* vp = base + 2 * A;                            // V row j0
+  const float* const v_last = base + 2 * A + last * rs;
+  for (int j0 = 0; j0 < F; j0 += kGroup, vp += kGroup * rs) {
     float vr[kGroup][HD];
 #pragma unroll
-    for (int u = 0; u < kGroup; ++u) load_row<HD>(base + (j0 + u < F ? j0 + u : last) * rs + 2 * A, vr[u]);
+    for (int u = 0; u < kGroup; ++u) load_row<HD>(j0 + u < F ? vp + u * rs : v_last, vr[u]);
     __builtin_amdgcn_sched_barrier(0);         // all of the group's loads are issued before any is waited for
 #pragma unroll
     for (int u = 0; u < kGroup; ++u) {
@@ -141,10 +145,12 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void attn_core_bwd(const float
   constexpr int kGroup = HD <= 16 ? 3 : 2;                   // rows per scalar-load group (see attn_core_fwd)
   constexpr int kGroup2 = HD <= 16 ? 2 : 1;                  // sweeps that load two rows per j
   float mx = -INFINITY;
-  for (int j0 = 0; j0 < F; j0 += kGroup) {
+  const float* kp = base + A;                                // K row j0; running pointer (no multiply per row)
+  const float* const k_last = base + A + last * rs;
+  for (int j0 = 0; j0 < F; j0 += kGroup, kp += kGroup * rs) {
     float kr[kGroup][HD];
 #pragma unroll
-    for (int u = 0; u < kGroup; ++u) load_row<HD>(base + (j0 + u < F ? j0 + u : last) * rs + A, kr[u]);
+    for (int u = 0; u < kGroup; ++u) load_row<HD>(j0 + u < F ? kp + u * rs : k_last, kr[u]);
     __builtin_amdgcn_sched_barrier(0);         // all of the group's loads are issued before any is waited for
 #pragma unroll
     for (int u = 0; u < kGroup; ++u) {
@@ -162,10 +168,12 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void attn_core_bwd(const float
   }
   const float inv = 1.f / sum;
   float dot = 0.f;                  // sum_j dP_ij P_ij
-  for (int j0 = 0; j0 < F; j0 += kGroup) {
+  const float* vp = base + 2 * A;                            // V row j0
+  const float* const v_last = base + 2 * A + last * rs;
+  for (int j0 = 0; j0 < F; j0 += kGroup, vp += kGroup * rs) {
     float vr[kGroup][HD];
 #pragma unroll
-    for (int u = 0; u < kGroup; ++u) load_row<HD>(base + (j0 + u < F ? j0 + u : last) * rs + 2 * A, vr[u]);
+    for (int u = 0; u < kGroup; ++u) load_row<HD>(j0 + u < F ? vp + u * rs : v_last, vr[u]);
     __builtin_amdgcn_sched_barrier(0);         // all of the group's loads are issued before any is waited for
 #pragma unroll
     for (int u = 0; u < kGroup; ++u) {
@@ -182,10 +190,12 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void attn_core_bwd(const float
     float dv[HD];
 #pragma unroll
     for (int e = 0; e < HD; ++e) dv[e] = 0.f;
-    for (int i0 = 0; i0 < F; i0 += kGroup) {
+    const float* gp = gbase;                                 // dO row i0
+    const float* const g_last = gbase + static_cast<int64_t>(last) * A;
+    for (int i0 = 0; i0 < F; i0 += kGroup, gp += kGroup * A) {
       float gr[kGroup][HD];
 #pragma unroll
-      for (int u = 0; u < kGroup; ++u) load_row<HD>(gbase + static_cast<int64_t>(i0 + u < F ? i0 + u : last) * A, gr[u]);
+      for (int u = 0; u < kGroup; ++u) load_row<HD>(i0 + u < F ? gp + u * A : g_last, gr[u]);
     __builtin_amdgcn_sched_barrier(0);         // all of the group's loads are issued before any is waited for
 #pragma unroll
       for (int u = 0; u < kGroup; ++u) {
@@ -205,13 +215,15 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void attn_core_bwd(const float
     float dq[HD];
 #pragma unroll
     for (int e = 0; e < HD; ++e) dq[e] = 0.f;
-    for (int j0 = 0; j0 < F; j0 += kGroup2) {
+    const float* rp = base + A;                              // K row j0 (V row: + A)
+    const float* const r_last = base + A + last * rs;
+    for (int j0 = 0; j0 < F; j0 += kGroup2, rp += kGroup2 * rs) {
       float vr[kGroup2][HD], kr[kGroup2][HD];
 #pragma unroll
       for (int u = 0; u < kGroup2; ++u) {
-        const int64_t jr = (j0 + u < F ? j0 + u : last) * rs;
-        load_row<HD>(base + jr + 2 * A, vr[u]);
-        load_row<HD>(base + jr + A, kr[u]);
+        const float* pr = j0 + u < F ? rp + u * rs : r_last;
+        load_row<HD>(pr + A, vr[u]);
+        load_row<HD>(pr, kr[u]);
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -234,10 +246,12 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void attn_core_bwd(const float
     float dk[HD];
 #pragma unroll
     for (int e = 0; e < HD; ++e) dk[e] = 0.f;
-    for (int i0 = 0; i0 < F; i0 += kGroup) {
+    const float* qp = base;                                  // Q row i0
+    const float* const q_last = base + last * rs;
+    for (int i0 = 0; i0 < F; i0 += kGroup, qp += kGroup * rs) {
       float qr[kGroup][HD];
 #pragma unroll
-      for (int u = 0; u < kGroup; ++u) load_row<HD>(base + (i0 + u < F ? i0 + u : last) * rs, qr[u]);
+      for (int u = 0; u < kGroup; ++u) load_row<HD>(i0 + u < F ? qp + u * rs : q_last, qr[u]);
     __builtin_amdgcn_sched_barrier(0);         // all of the group's loads are issued before any is waited for
 #pragma unroll
       for (int u = 0; u < kGroup; ++u) {
