@@ -152,6 +152,11 @@ class RowSparseTrainStep:
         torch.cuda.synchronize()
         self._gather()
         single = not self.opt.split
+        # opt-in (DFM_DP_GRAPH_COLLECTIVE=1): capture the exchange inside the graph — one graph launch
+        # per step under data parallelism.  Verified with a single-rank RCCL communicator only
+        # (DFM_FORCE_DP_PATH=1); not validated on a multi-GPU box, hence not the default.
+        fused_exchange = ((not single) and os.environ.get("DFM_DP_GRAPH_COLLECTIVE") == "1"
+                          and torch.distributed.is_initialized() and torch.distributed.get_backend() == "nccl")
         # thread_local capture mode: another thread (the RCCL watchdog polling its events under
         # data parallelism) must not invalidate the capture
         mode = dict(capture_error_mode="thread_local")
@@ -160,7 +165,10 @@ class RowSparseTrainStep:
             self._body_a()
             if single:
                 self._body_b()
-        if not single:
+            elif fused_exchange:
+                self.opt.exchange()
+                self._body_b()
+        if not single and not fused_exchange:
             self.opt.exchange()
             torch.cuda.synchronize()
             self.graph_b = torch.cuda.CUDAGraph()

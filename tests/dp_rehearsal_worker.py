@@ -26,7 +26,9 @@ def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
-    dist.init_process_group("gloo")
+    # a fourth argument "nccl" (single rank only): the RCCL backend, so that collectives can be captured
+    backend = sys.argv[4] if len(sys.argv) > 4 else "gloo"
+    dist.init_process_group(backend, device_id=dev if backend == "nccl" else None)
     from deepfm_amd.config import ExperimentConfig
     from deepfm_amd.models import create_model
     from deepfm_amd.training.rowsparse import RowSparseAdam

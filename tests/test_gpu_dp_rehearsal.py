@@ -37,3 +37,25 @@ def test_two_ranks_stay_bit_identical(mode, kind):
     assert ranks[0]["tables"] == ranks[1]["tables"], "embedding tables diverged between replicas"
     assert all(math.isfinite(r["loss"]) for r in ranks)
     assert ranks[0]["moved"] > 0.5        # the tables really were updated
+
+
+def _single_rank_rccl(extra_env):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "tests", "dp_rehearsal_worker.py"), "graph", "4", "fused", "nccl"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", DFM_FORCE_DP_PATH="1", **extra_env)
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("RESULT ")]
+    assert line, p.stdout[-2000:]
+    return json.loads(line[0][len("RESULT "):])[0]
+
+
+def test_exchange_captured_in_the_graph_matches_the_split_path():
+    """DFM_DP_GRAPH_COLLECTIVE=1 captures the RCCL all-gather inside the step's graph (one launch per
+    step).  With a single-rank RCCL communicator on this box it must reproduce the split path
+    (graph A -> eager exchange -> graph B) bit for bit."""
+    split = _single_rank_rccl({})
+    fused = _single_rank_rccl({"DFM_DP_GRAPH_COLLECTIVE": "1"})
+    assert split["flat"] == fused["flat"] and split["tables"] == fused["tables"]
+    assert split["loss"] == fused["loss"] and split["moved"] > 0.5
