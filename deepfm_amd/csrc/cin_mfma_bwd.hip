@@ -15,8 +15,8 @@
 // which it folds into 4 d-hidden partial sums (combined across the two lane halves once per
 // 4 hidden rows) and 4 lane-private d-x0 registers per field group.  G is never stored.
 // Kernel 2 (cin_wgrad_mfma): dW as a GEMM with rows c, columns k and the reduction over
-// n = (b,d): one k-step is one sample (16 d), the A operand is dY (pre-split to bf16 hi/lo by
-// cin_pack_dy), the B operand hidden*x0 is generated in registers.  Split over batch slices,
+// n = (b,d): one k-step is one sample (16 d), the A operand is dY (split to bf16 hi/lo on its way
+// into LDS), the B operand hidden*x0 is generated in registers.  Split over batch slices,
 // partial slabs reduced in a fixed order (bitwise reproducible).
 // Numerics: the same bf16 x 3 split as the forward (SPLIT) or plain bf16 (throughput mode).
 #include <type_traits>
@@ -267,28 +267,9 @@ __global__ __launch_bounds__(kBwdWaves * 64, 2) void cin_dgrad_mfma(CinBwdArgs a
 }
 
 // ---- weight gradient -----------------------------------------------------------------------
-// dY (B, C, D) fp32 -> A-operand fragments [b][mb][lane = hf*32 + r][j]: dY[b][32*mb + r][8*hf + j]
-// (D = 16: one k-step = one sample)
-__global__ __launch_bounds__(256) void cin_pack_dy(const float* __restrict__ dY, int64_t B, int C, int MB,
-                                                   __bf16* __restrict__ hi, __bf16* __restrict__ lo) {
-  const int64_t t = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
-  const int64_t total = B * MB * 64 * 8;
-  if (t >= total) return;
-  const int j = t & 7;
-  const int lane = (t >> 3) & 63;
-  const int64_t rest = t >> 9;
-  const int mb = static_cast<int>(rest % MB);
-  const int64_t b = rest / MB;
-  const int c = mb * 32 + (lane & 31), d = 8 * (lane >> 5) + j;
-  const float v = c < C ? dY[(b * C + c) * 16 + d] : 0.f;
-  const __bf16 vh = static_cast<__bf16>(v);
-  hi[t] = vh;
-  lo[t] = static_cast<__bf16>(v - static_cast<float>(vh));
-}
-
 struct CinWgradArgs {
-  const __bf16* dy_hi;     // (B, MB, 64, 8)
-  const __bf16* dy_lo;
+  const float* dY;         // (B, C, 16) fp32, straight from the dgrad kernel
+  int C;
   const float* x0;         // (B, F, 16)
   const float* hidden;
   int64_t hidden_stride;
@@ -320,18 +301,20 @@ __global__ __launch_bounds__(256, 2) void cin_wgrad_mfma(CinWgradArgs a) {
   const int64_t nsteps = b1 > b0 ? (b1 - b0 + kWgStep - 1) / kWgStep : 0;
   f32x16 acc[4] = {};
   const int s_mb = tid >> 6, s_lane = tid & 63;
-  uint4 rh[kWgStep] = {}, rl[kWgStep] = {};
-  float4 hb[kWgStep][2] = {}, xb[kWgStep][2] = {};
+  // A operand: fragment (mb, lane = hf*32 + r) of a sample is dY[b][32 mb + r][8 hf .. 8 hf + 7] — 32
+  // contiguous bytes of fp32, the same bytes a pre-packed bf16 hi + lo pair would take; the split into
+  // bf16 hi / lo happens on the way into LDS (a separate cin_pack_dy pass cost 21 us per layer).
+  float4 rf[kWgStep][2] = {};
+  const int s_c = 32 * s_mb + (s_lane & 31);
   auto load_a = [&](int64_t step) {
 #pragma unroll
     for (int u = 0; u < kWgStep; ++u) {
       const int64_t bb = b0 + step * kWgStep + u;
-      rh[u] = uint4{0, 0, 0, 0};
-      rl[u] = uint4{0, 0, 0, 0};
-      if (s_mb < a.MB && bb < b1) {
-        const int64_t e = (bb * a.MB + s_mb) * 64 + s_lane;
-        rh[u] = reinterpret_cast<const uint4*>(a.dy_hi)[e];
-        if (SPLIT) rl[u] = reinterpret_cast<const uint4*>(a.dy_lo)[e];
+      rf[u][0] = rf[u][1] = float4{0.f, 0.f, 0.f, 0.f};
+      if (s_c < a.C && bb < b1) {
+        const float* p = a.dY + (bb * a.C + s_c) * 16 + 8 * (s_lane >> 5);
+        rf[u][0] = ld4(p);
+        rf[u][1] = ld4(p + 4);
       }
     }
   };
@@ -340,11 +323,19 @@ __global__ __launch_bounds__(256, 2) void cin_wgrad_mfma(CinWgradArgs a) {
       unsigned char* base = wbuf + buf * 2 * SLAB;
 #pragma unroll
       for (int u = 0; u < kWgStep; ++u) {
-        reinterpret_cast<uint4*>(base)[(u * 4 + s_mb) * 64 + s_lane] = rh[u];
-        if (SPLIT) reinterpret_cast<uint4*>(base + SLAB)[(u * 4 + s_mb) * 64 + s_lane] = rl[u];
+        const float v[8] = {rf[u][0].x, rf[u][0].y, rf[u][0].z, rf[u][0].w, rf[u][1].x, rf[u][1].y, rf[u][1].z, rf[u][1].w};
+        bf16x8 h, l;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          h[j] = static_cast<__bf16>(v[j]);
+          if (SPLIT) l[j] = static_cast<__bf16>(v[j] - static_cast<float>(h[j]));
+        }
+        reinterpret_cast<bf16x8*>(base)[(u * 4 + s_mb) * 64 + s_lane] = h;
+        if (SPLIT) reinterpret_cast<bf16x8*>(base + SLAB)[(u * 4 + s_mb) * 64 + s_lane] = l;
       }
     }
   };
+  float4 hb[kWgStep][2] = {}, xb[kWgStep][2] = {};
   auto load_b = [&](int64_t step) {
 #pragma unroll
     for (int u = 0; u < kWgStep; ++u) {
@@ -528,9 +519,7 @@ static int wgrad_slices(int64_t B, int KT) {
 size_t cin_mfma_wgrad_workspace_bytes(int64_t B, int C, int H, int F) {
   const int MB = (C + 31) / 32, FP = ((F + 7) / 8) * 8;
   const int KT = (H * FP + 31) / 32;
-  const size_t dy = 2 * sizeof(__bf16) * static_cast<size_t>(B) * MB * 64 * 8;
-  const size_t slabs = sizeof(float) * static_cast<size_t>(wgrad_slices(B, KT)) * MB * 32 * KT * 32;
-  return dy + slabs + 512;
+  return sizeof(float) * static_cast<size_t>(wgrad_slices(B, KT)) * MB * 32 * KT * 32 + 512;
 }
 
 // true: cin_mfma_wgrad also produces the bias gradient (a free padding column exists)
@@ -542,16 +531,10 @@ int cin_mfma_wgrad(const float* dY, const float* x0, const float* hidden, int64_
   DFM_REQUIRE(!db || cin_mfma_wgrad_has_bias(F), "no padding column for the bias gradient (F = %d)", F);
   const int MB = (C + 31) / 32, FP = ((F + 7) / 8) * 8;
   const int KT = (H * FP + 31) / 32;
-  const size_t nfrag = static_cast<size_t>(B) * MB * 64 * 8;
-  __bf16* hi = static_cast<__bf16*>(workspace);
-  __bf16* lo = hi + ((nfrag + 127) / 128) * 128;
-  float* slabs = reinterpret_cast<float*>(lo + ((nfrag + 127) / 128) * 128);
-  hipLaunchKernelGGL(cin_pack_dy, dim3(static_cast<unsigned>((nfrag + 255) / 256)), dim3(256), 0, st, dY, B, C, MB,
-                     hi, lo);
-  DFM_LAUNCH_CHECK();
+  float* slabs = static_cast<float*>(workspace);
   const int slices = wgrad_slices(B, KT);
   CinWgradArgs a;
-  a.dy_hi = hi; a.dy_lo = lo; a.x0 = x0; a.hidden = hidden; a.hidden_stride = hidden_stride; a.slabs = slabs;
+  a.dY = dY; a.C = C; a.x0 = x0; a.hidden = hidden; a.hidden_stride = hidden_stride; a.slabs = slabs;
   a.B = B; a.F = F; a.H = H; a.MB = MB; a.KT = KT; a.slices = slices; a.FP = FP;
   a.bias_col = db ? 1 : 0;
   const dim3 grid((KT + 3) / 4, slices);
