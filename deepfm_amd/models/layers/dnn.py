@@ -48,7 +48,7 @@ class _LinearBnReluDropoutFn(torch.autograd.Function):
     subtracts the batch mean), so none is computed."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, gamma, beta, bn: nn.BatchNorm1d, p: float, seed, salt: int):
+    def forward(ctx, x, weight, bias, gamma, beta, bn: nn.BatchNorm1d, p: float, seed, salt: int, direct: bool):
         lib = _lib.load()
         x = x.contiguous()
         M, K = x.shape
@@ -76,7 +76,7 @@ class _LinearBnReluDropoutFn(torch.autograd.Function):
                 z.data_ptr(), M, N, gamma.data_ptr(), beta.data_ptr(), rm, rv, nb, float(bn.momentum), float(bn.eps),
                 float(p), _lib.ptr(seed), salt, out.data_ptr(), stats.data_ptr(), ws.data_ptr(), _lib.stream_handle()))
         ctx.save_for_backward(x, weight, z, gamma, beta, stats)
-        ctx.p, ctx.seed, ctx.salt = p, seed, salt
+        ctx.p, ctx.seed, ctx.salt, ctx.direct = p, seed, salt, direct
         ctx.params = (weight, bias, gamma, beta)
         return out
 
@@ -87,7 +87,10 @@ class _LinearBnReluDropoutFn(torch.autograd.Function):
         w_p, b_p, gamma_p, beta_p = ctx.params
         M, N = z.shape
         dz = torch.empty_like(z)
-        tg, tb = _grad_target(gamma_p), _grad_target(beta_p)
+        # the write-into-.grad shortcut only when the caller asked for it (the row-sparse training step,
+        # whose optimizer owns the flat gradient buffer): torch.autograd.grad() / hooks get real gradients
+        target = _grad_target if ctx.direct else (lambda p: None)
+        tg, tb = target(gamma_p), target(beta_p)
         d_gamma = tg if tg is not None else torch.zeros_like(gamma)
         d_beta = tb if tb is not None else torch.zeros_like(beta)
         ws = torch.empty(max(lib.dfm_bn_workspace_bytes(M, N) // 4, 1), dtype=torch.float32, device=z.device)
@@ -96,18 +99,18 @@ class _LinearBnReluDropoutFn(torch.autograd.Function):
             float(ctx.p), _lib.ptr(ctx.seed), ctx.salt, dz.data_ptr(), d_gamma.data_ptr(), d_beta.data_ptr(),
             ws.data_ptr(), _lib.stream_handle()))
         K = x.shape[1]
-        tw = _grad_target(w_p)
+        tw = target(w_p)
         d_w = None if tw is not None else torch.empty_like(weight)
         # dW (N, K) (+)= dz^T x : both operands strided over the batch (the reduction index)
         _gemm(dz, N, False, x, K, False, tw if tw is not None else d_w, N, K, M, accumulate=tw is not None)
         # d bias == 0 exactly (BatchNorm removes the batch mean): leave an existing buffer as is
-        d_b = None if _grad_target(b_p) is not None else torch.zeros_like(b_p)
+        d_b = None if target(b_p) is not None else torch.zeros_like(b_p)
         d_x = None
         if ctx.needs_input_grad[0]:
             d_x = torch.empty_like(x)
             _gemm(dz, N, True, weight, K, False, d_x, M, K, N)                      # dx = dz W
         return (d_x, d_w, d_b, None if tg is not None else d_gamma, None if tb is not None else d_beta,
-                None, None, None, None)
+                None, None, None, None, None)
 
 
 class DNN(nn.Module):
@@ -136,6 +139,9 @@ class DNN(nn.Module):
         self._fusable = use_batch_norm and activation.lower() == "relu"
         self._n_layers = len(hidden_units)
         self._seed = None
+        # set by the row-sparse training step: backward accumulates parameter gradients straight into the
+        # optimizer's flat .grad views and returns None for them (no AccumulateGrad add / zero-fill launches)
+        self.direct_grads = False
 
     def _fused_ok(self, x: torch.Tensor) -> bool:
         if not (self.fused and self._fusable and self.training and x.is_cuda and x.dtype == torch.float32
@@ -150,9 +156,13 @@ class DNN(nn.Module):
         if self._seed is None or self._seed.device != x.device:
             self._seed = torch.randint(1, 2 ** 40, (1,), dtype=torch.int64, device=x.device)
         self._seed.add_(1)
+        # backward regenerates the dropout mask from the seed: with dropout on, each forward keeps its own
+        # copy, so a second forward before the backward (gradient accumulation) cannot change the mask
+        any_drop = any(self.mlp[4 * i + 3].p > 0 for i in range(self._n_layers))
+        seed = self._seed.clone() if any_drop else self._seed
         h = x
         for i in range(self._n_layers):
             lin, bn, _, drop = (self.mlp[4 * i + j] for j in range(4))
             h = _LinearBnReluDropoutFn.apply(h, lin.weight, lin.bias, bn.weight, bn.bias, bn, drop.p,
-                                             self._seed, i)
+                                             seed, i, self.direct_grads)
         return h

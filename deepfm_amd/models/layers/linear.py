@@ -3,8 +3,9 @@
 Used for the model heads (``output_linear`` / ``cin_linear`` / ``dnn_linear``; reference
 deepfm.py:28, xdeepfm.py:33-34, attention_deepfm.py:46).  It IS an ``nn.Linear`` (same
 parameters, init and state_dict keys); only ``forward`` differs, and only for float32 HIP
-tensors — anything else takes ``nn.Linear.forward``.  Like the DNN layers it accumulates its
-parameter gradients straight into existing ``.grad`` buffers.
+tensors — anything else takes ``nn.Linear.forward``.  Like the DNN layers it can accumulate its
+parameter gradients straight into existing ``.grad`` buffers (``direct_grads``, set by the row-sparse
+training step); by default it returns them to autograd.
 """
 
 from __future__ import annotations
@@ -29,7 +30,7 @@ def ones_column(m: int, device: torch.device) -> torch.Tensor:
 
 class _LinearFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, direct=False):
         x = x.contiguous()
         M, K = x.shape
         N = weight.shape[0]
@@ -37,6 +38,7 @@ class _LinearFn(torch.autograd.Function):
         _gemm(x, K, True, weight, K, True, out, M, N, K, bias=bias)
         ctx.save_for_backward(x, weight)
         ctx.params = (weight, bias)
+        ctx.direct = direct
         return out
 
     @staticmethod
@@ -46,12 +48,13 @@ class _LinearFn(torch.autograd.Function):
         g = g.contiguous()
         M, K = x.shape
         N = weight.shape[0]
-        tw = _grad_target(w_p)
+        target = _grad_target if ctx.direct else (lambda p: None)
+        tw = target(w_p)
         d_w = None if tw is not None else torch.empty_like(weight)
         _gemm(g, N, False, x, K, False, tw if tw is not None else d_w, N, K, M, accumulate=tw is not None)
         d_b = None
         if b_p is not None:
-            tb = _grad_target(b_p)
+            tb = target(b_p)
             ones = ones_column(M, g.device)
             d_b = None if tb is not None else torch.empty_like(b_p)
             tgt = (tb if tb is not None else d_b).view(N, 1)
@@ -60,11 +63,13 @@ class _LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             d_x = torch.empty_like(x)
             _gemm(g, N, True, weight, K, False, d_x, M, K, N)
-        return d_x, d_w, d_b
+        return d_x, d_w, d_b, None
 
 
 class MfmaLinear(nn.Linear):
+    direct_grads = False       # see module docstring
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and self.weight.is_contiguous():
-            return _LinearFn.apply(x, self.weight, self.bias)
+            return _LinearFn.apply(x, self.weight, self.bias, self.direct_grads)
         return super().forward(x)

@@ -67,6 +67,9 @@ class RowSparseTrainStep:
         self.dense_grads = {id(p): p.grad for p in self.emb.non_table_parameters() if p.grad is not None}
         self.gather_events = None          # list of (start, end) torch.cuda.Event pairs when timing
         self.emb.pin_plan(dev)             # the step holds raw parameter pointers from here on
+        for m in model.modules():          # DNN / head backward: accumulate straight into the flat .grad views
+            if hasattr(m, "direct_grads"):
+                m.direct_grads = True
 
     # ------------------------------------------------------------------ pieces
     def load_batch(self, ids: torch.Tensor, dense: torch.Tensor, labels: torch.Tensor) -> None:
@@ -136,10 +139,34 @@ class RowSparseTrainStep:
         self.opt.apply()
 
     # ------------------------------------------------------------------ capture / run
-    def capture(self, warmup_iters: int = 3) -> None:
-        """Warm up eagerly on a side stream, then capture graph A (and B)."""
+    def _mutable_state(self) -> List[torch.Tensor]:
+        """Everything a training step writes besides the table rows of the ids it is given: the flat dense
+        parameter / moment / gradient buffers, step count, norm scalars, dropout seed, every module buffer
+        (BatchNorm running statistics) and the static inputs."""
+        opt = self.opt
+        ts = [opt.flat_param, opt.flat_m, opt.flat_v, opt.flat_grad, opt.step_count, opt.sq_norm, opt.clip_coef,
+              self.loss, self.packed]
+        if opt.seed_tick is not None:
+            ts.append(opt.seed_tick)
+        seed = getattr(getattr(self.model, "dnn", None), "_seed", None)
+        if seed is not None:
+            ts.append(seed)
+        ts += list(self.model.buffers())
+        return ts
+
+    def capture(self, warmup_iters: int = 1) -> None:
+        """Capture graph A (and B) after ``warmup_iters`` eager steps.  Side-effect free: the warm-up
+        steps run on an all-padding batch (id 0 everywhere: no table row receives a gradient, so the
+        row-wise Adam touches nothing) and every other piece of state a step writes — dense parameters,
+        Adam moments, step count, dropout seed, BatchNorm running statistics, the static inputs — is
+        restored afterwards, bit for bit."""
         if not self.use_graph:
             return
+        state = self._mutable_state()
+        saved = [t.clone() for t in state]
+        record, self._record = self._record, None
+        if self.n_sparse:
+            self.ids.zero_()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -150,7 +177,6 @@ class RowSparseTrainStep:
                 self._body_b()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        self._gather()
         single = not self.opt.split
         # opt-in (DFM_DP_GRAPH_COLLECTIVE=1): capture the exchange inside the graph — one graph launch
         # per step under data parallelism.  Verified with a single-rank RCCL communicator only
@@ -163,10 +189,8 @@ class RowSparseTrainStep:
         self.graph_a = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph_a, **mode):
             self._body_a()
-            if single:
-                self._body_b()
-            elif fused_exchange:
-                self.opt.exchange()
+            if single or fused_exchange:
+                self.opt.exchange()          # one rank: no device work, selects the local row lists
                 self._body_b()
         if not single and not fused_exchange:
             self.opt.exchange()
@@ -174,6 +198,11 @@ class RowSparseTrainStep:
             self.graph_b = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph_b, **mode):
                 self._body_b()
+        torch.cuda.synchronize()
+        with torch.no_grad():
+            for t, v in zip(state, saved):
+                t.copy_(v)
+        self._record = record
         torch.cuda.synchronize()
 
     def run_from(self, record: torch.Tensor) -> None:

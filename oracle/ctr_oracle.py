@@ -612,6 +612,16 @@ def clip_coef(total_sq_norm: float, max_norm: float) -> F32:
     return F32(min(1.0, max_norm / (norm + 1e-6)))
 
 
+def l2_reg_loss(params: Dict[str, Array], l2: float) -> F32:
+    """BaseCTRModel.get_l2_reg_loss (base.py:78-83): lambda * sum ||p||_2^2 over every parameter of
+    ``model.embedding`` — tables, DENSE-field Linears and projections (state_dict keys ``embedding.*``)."""
+    total = 0.0
+    for k, v in params.items():
+        if k.startswith("embedding."):
+            total += float((v.astype(np.float64) ** 2).sum())
+    return F32(l2 * total)
+
+
 def rowsparse_reduce_fast(ids: Array, g_rows: Array, g_first: Array):
     """Vectorised rowsparse_from_batch (same result up to fp32 summation order inside a
     run of duplicates): used by the CPU-baseline timing and the large-shape checks."""
@@ -628,12 +638,14 @@ def rowsparse_reduce_fast(ids: Array, g_rows: Array, g_first: Array):
 
 def deepfm_train_step_rowsparse(fields, params: Dict[str, Array], state: Dict[str, Array],
                                 batch, labels: Array, cfg: dict, hp: dict, step: int,
-                                exact_order: bool = False) -> F32:
+                                exact_order: bool = False, info: Optional[dict] = None) -> F32:
     """One DeepFM training step in the build's row-sparse mode, in place on ``params`` /
     ``state`` (``m/<key>``, ``v/<key>`` Adam moments): forward (embedding.py:76-126,
     fm.py:18-23, dnn.py:45-59, deepfm.py:30-42), BCE + L2 on the non-table embedding
     parameters (trainer.py:221-225), backward, lazy L2 on touched rows, global-norm clip
-    (trainer.py:232-235), Adam (trainer.py:237).  hp: lr, l2, max_grad_norm, betas, eps."""
+    (trainer.py:232-235), Adam (trainer.py:237).  hp: lr, l2, max_grad_norm, betas, eps.
+    ``info`` (optional) receives logits, the squared global gradient norm, the clip coefficient, the
+    per-field row gradients (ids, rows incl. the L2 term, first-order) and the dense gradients."""
     emb_p = _sub(params, "embedding.")
     fo, fe, fl = embedding_forward(fields, emb_p, batch, cfg["fm_dim"])
     n_hidden = len(cfg["hidden_units"])
@@ -671,6 +683,8 @@ def deepfm_train_step_rowsparse(fields, params: Dict[str, Array], state: Dict[st
     for g in grads.values():
         sq += float((g.astype(np.float64) ** 2).sum())
     coef = clip_coef(sq, hp["max_grad_norm"]) if hp.get("max_grad_norm") else F32(1.0)
+    if info is not None:
+        info.update(logits=logits, sq_norm=sq, coef=coef, rows=rows, grads=grads)
     b1, b2 = hp.get("betas", (0.9, 0.999))
     eps = hp.get("eps", 1e-8)
     for k, g in grads.items():

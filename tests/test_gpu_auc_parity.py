@@ -45,11 +45,9 @@ def test_deepfm_auc_matches_the_reference_run():
     d_labels = torch.from_numpy(labels).cuda()
     step.load_batch(d_ids[:, :T.BATCH], d_dense[:, :T.BATCH], d_labels[:T.BATCH])
     start = {k: v.clone() for k, v in model.state_dict().items()}
-    step.capture()                                                       # its warm-up trains: rewind
-    model.load_state_dict(start)
-    for t in opt.exp_avg + opt.exp_avg_sq + [opt.flat_m, opt.flat_v]:
-        t.zero_()
-    opt.step_count.zero_()
+    step.capture()                                                       # side-effect free
+    for k, v in model.state_dict().items():
+        assert torch.equal(v, start[k]), k
 
     def evaluate():
         model.eval()

@@ -39,7 +39,7 @@ def _relu_masks_agree(fused, plain, x):
     with torch.no_grad():
         for i in range(len(fa.mlp) // 4):
             lin, bn, act, drop = (fa.mlp[4 * i + j] for j in range(4))
-            ha = _LinearBnReluDropoutFn.apply(ha, lin.weight, lin.bias, bn.weight, bn.bias, bn, 0.0, None, i)
+            ha = _LinearBnReluDropoutFn.apply(ha, lin.weight, lin.bias, bn.weight, bn.bias, bn, 0.0, None, i, False)
             hb = pb.mlp[4 * i + 2](pb.mlp[4 * i + 1](pb.mlp[4 * i](hb)))
             if not torch.equal(ha > 0, hb > 0):
                 return False
@@ -112,6 +112,7 @@ def test_direct_accumulation_into_existing_grad_buffers():
     x = torch.randn(256, 32, device="cuda")
     g = torch.randn(256, 8, device="cuda")
     (plain(x) * g).sum().backward()
+    fused.direct_grads = True           # what RowSparseTrainStep sets on the model's DNN and heads
     for p in fused.parameters():
         p.grad = torch.zeros_like(p)
     for _ in range(2):
@@ -119,6 +120,70 @@ def test_direct_accumulation_into_existing_grad_buffers():
     for (k, pa), (_, pb) in zip(fused.named_parameters(), plain.named_parameters()):
         zero_grad = k.endswith(".bias") and int(k.split(".")[1]) % 4 == 0
         assert_close(npy(pa.grad), 2 * npy(pb.grad), rtol=1e-4, what=k, floor=1e-3 if zero_grad else 0.0)
+
+
+def test_default_backward_returns_gradients_to_autograd():
+    """Without ``direct_grads`` the layer is an ordinary autograd citizen: torch.autograd.grad() returns
+    the parameter gradients and existing .grad buffers are left alone."""
+    fused, plain = _pair(32, [16, 8], 0.0)
+    x = torch.randn(256, 32, device="cuda")
+    g = torch.randn(256, 8, device="cuda")
+    (plain(x) * g).sum().backward()
+    for p in fused.parameters():
+        p.grad = torch.full_like(p, 7.0)
+    params = list(fused.parameters())
+    grads = torch.autograd.grad((fused(x) * g).sum(), params)
+    for (k, pa), ga, (_, pb) in zip(fused.named_parameters(), grads, plain.named_parameters()):
+        zero_grad = k.endswith(".bias") and int(k.split(".")[1]) % 4 == 0
+        assert ga is not None, k
+        assert_close(npy(ga), npy(pb.grad), rtol=1e-4, what=k, floor=1e-3 if zero_grad else 0.0)
+        assert float((pa.grad - 7.0).abs().max()) == 0.0, f".grad of {k} was written"
+
+
+def test_two_forwards_then_backward_keeps_the_first_mask():
+    """Backward regenerates the dropout mask from the forward's seed: a second train-mode forward
+    between a forward and its backward must not change the gradients (bitwise)."""
+    fused, _ = _pair(64, [128, 32], 0.3)
+    x = torch.randn(512, 64, device="cuda")
+    g = torch.randn(512, 32, device="cuda")
+    fused(x)                                            # creates the device seed
+    seed0 = fused._seed.clone()
+    results = []
+    for extra_forward in (False, True):
+        fused._seed.copy_(seed0)
+        fused.zero_grad(set_to_none=True)
+        xi = x.clone().requires_grad_()
+        y = fused(xi)
+        if extra_forward:
+            y2 = fused(x)
+            assert not torch.equal(y2 != 0, y.detach() != 0)        # a different mask
+        (y * g).sum().backward()
+        results.append([npy(xi.grad).copy()] + [npy(p.grad).copy() for p in fused.parameters()])
+    for a, b in zip(*results):
+        assert np.array_equal(a, b)
+
+
+def test_fixed_input_bounded_outliers():
+    """One FIXED input at the headline tower shape, no re-drawing: a pre-activation within an ulp of 0 may
+    take the other side of the ReLU kink than torch's modules (different fp32 summation order), so a
+    bounded fraction of gradient elements may differ — but a kernel that flips masks systematically
+    would blow the bound.  Outputs are held to the normal bar."""
+    from tests.helpers import assert_close_mostly
+    B, in_dim, hidden = 4096, 624, [256, 128, 64]
+    fused, plain = _pair(in_dim, hidden, 0.0)
+    x = torch.randn(B, in_dim, device="cuda", generator=torch.Generator(device="cuda").manual_seed(4242)) * 2 + 0.5
+    xa, xb = x.clone().requires_grad_(), x.clone().requires_grad_()
+    ya, yb = fused(xa), plain(xb)
+    # |y| of a flipped element is itself ~1e-7: the relative bar cannot see it, the outputs all pass
+    assert_close(npy(ya), npy(yb), rtol=1e-4, what="output")
+    g = torch.randn(B, hidden[-1], device="cuda", generator=torch.Generator(device="cuda").manual_seed(7))
+    (ya * g).sum().backward()
+    (yb * g).sum().backward()
+    assert_close_mostly(npy(xa.grad), npy(xb.grad), 2e-3, what="d_x")
+    for (k, pa), (_, pb) in zip(fused.named_parameters(), plain.named_parameters()):
+        if k.endswith(".bias") and int(k.split(".")[1]) % 4 == 0:
+            continue
+        assert_close_mostly(npy(pa.grad), npy(pb.grad), 2e-3, what=k)
 
 
 def test_fused_bce_matches_torch_and_oracle():

@@ -292,10 +292,9 @@ def test_fused_step_graph_replay_is_bitwise_equal_to_eager():
         start = copy.deepcopy(model.state_dict())
         step.load_batch(torch.from_numpy(ids[0]).cuda(), torch.from_numpy(dense[0]).cuda(), torch.from_numpy(labels[0]).cuda())
         step.capture()
-        model.load_state_dict(start)
-        for t in opt.exp_avg + opt.exp_avg_sq:
-            t.zero_()
-        opt.step_count.zero_(); opt.flat_m.zero_(); opt.flat_v.zero_()
+        for k, v in model.state_dict().items():
+            assert torch.equal(v, start[k]), f"capture() changed {k}"
+        assert int(opt.step_count) == 0 and not opt.flat_m.any()
         for i in range(4):
             step.load_batch(torch.from_numpy(ids[i]).cuda(), torch.from_numpy(dense[i]).cuda(), torch.from_numpy(labels[i]).cuda())
             step.run()

@@ -177,3 +177,130 @@ def test_rowsparse_matches_dense():
     keep = ids != 0
     np.add.at(dense, ids[keep], g2[keep])
     assert_close(r2, dense[uniq], 1e-5, what="row grads")
+
+
+# ------------------------------------------------------------------ train-step tail (a14, f-1)
+# Goldens: tools/make_golden.py::case_train_steps — the reference's layer classes driven by the body of
+# Trainer._train_epoch (trainer.py:212-240): BCE + get_l2_reg_loss (base.py:78-83), clip_grad_norm_,
+# torch.optim.Adam.  Every batch touches every table row, so the row-wise lazy step of the oracle and
+# the reference's dense step are the same computation.
+
+TRAIN_CASES = ["train_steps_deepfm", "train_steps_deepfm_l2clip"]
+
+
+def _is_pre_bn_bias(k: str) -> bool:
+    return k.startswith("dnn.mlp.") and k.endswith(".bias") and int(k.split(".")[2]) % 4 == 0
+
+
+def train_case_state(g):
+    params = {k: v.copy() for k, v in group(g, "init/").items() if not k.endswith("num_batches_tracked")}
+    state = {}
+    for k, v in params.items():
+        if "running_" not in k:
+            state["m/" + k], state["v/" + k] = np.zeros_like(v), np.zeros_like(v)
+    return params, state
+
+
+ADAM_EPS = 1e-8
+
+
+def ill_conditioned(g, t, k):
+    """Elements whose reference gradient (after clipping) came within 100 * eps of Adam's eps in any
+    step up to t: there the update lr * m / (sqrt(v) + eps) amplifies fp32 summation-order noise of the
+    gradient (|dg| ~ 1e-9) to a visible fraction of lr.  They are exact-zero gradients in exact
+    arithmetic (dead ReLU units behind BatchNorm); everything else is well conditioned."""
+    bad = None
+    for u in range(t + 1):
+        coef = min(1.0, float(g["clip"]) / (float(g[f"step{u}/grad_norm"]) + 1e-6))
+        small = np.abs(g[f"step{u}/grad/{k}"]) * coef < 100 * ADAM_EPS
+        bad = small if bad is None else (bad | small)
+    return bad
+
+
+def assert_step_params(got, g, t, lr, what="", rtol=1e-4, frac=0.02):
+    """Parameters after step t+1 against the reference's: 1e-4 relative plus ``frac`` (2 %) of one
+    Adam step (lr) absolute, on every well-conditioned element (see ill_conditioned); Linear biases in
+    front of train-mode BatchNorm are skipped whole (identically-zero gradient)."""
+    want = group(g, f"step{t}/param/")
+    for k, w in want.items():
+        if "running_" in k or k.endswith("num_batches_tracked") or _is_pre_bn_bias(k):
+            continue
+        ok = ~ill_conditioned(g, t, k)
+        assert ok.mean() > 0.5, k          # dead ReLU units (exact-zero gradients) are the rest
+        assert_close(np.where(ok, got[k], 0), np.where(ok, w, 0), rtol=rtol, atol_scale=0.0, floor=lr * frac,
+                     what=f"{what} step {t} {k}")
+
+
+@pytest.mark.parametrize("case", TRAIN_CASES)
+def test_l2_reg_loss_vs_reference(case):
+    g = load(case)
+    params = group(g, "init/")
+    assert abs(float(O.l2_reg_loss(params, float(g["l2"]))) - float(g["step0/l2_term"])) <= 1e-5 * float(g["step0/l2_term"])
+
+
+@pytest.mark.parametrize("case", TRAIN_CASES)
+def test_train_steps_vs_reference(case):
+    g = load(case)
+    fields, c = fields_of(g), cfg_of(g)
+    hp = dict(lr=float(g["lr"]), l2=float(g["l2"]), max_grad_norm=float(g["clip"]))
+    params, state = train_case_state(g)
+    ocfg = dict(fm_dim=c["fm_dim"], hidden_units=c["hidden_units"])
+    for t in range(int(g["steps"])):
+        info = {}
+        l2_before = O.l2_reg_loss(params, hp["l2"])
+        bce = O.deepfm_train_step_rowsparse(fields, params, state, group(g, f"step{t}/batch/"), g[f"step{t}/labels"],
+                                            ocfg, hp, t + 1, exact_order=True, info=info)
+        assert_close(info["logits"].reshape(-1), g[f"step{t}/logits"], 2e-5, what=f"logits {t}")
+        assert abs(float(bce) - float(g[f"step{t}/bce"])) < 2e-5 * float(g[f"step{t}/bce"]) + 1e-6
+        assert abs(float(l2_before) - float(g[f"step{t}/l2_term"])) <= 2e-5 * float(g[f"step{t}/l2_term"])
+        # clip_grad_norm_'s total norm (trainer.py:232-235): over ALL parameters incl. the L2 gradient
+        norm = np.sqrt(info["sq_norm"])
+        assert abs(norm - float(g[f"step{t}/grad_norm"])) < 2e-5 * float(g[f"step{t}/grad_norm"])
+        assert abs(float(info["coef"]) - min(1.0, hp["max_grad_norm"] / (float(g[f"step{t}/grad_norm"]) + 1e-6))) < 1e-5
+        assert_step_params(params, g, t, hp["lr"], "oracle")
+    # Adam moments after the last step
+    # Adam moments after the last step.  exp_avg is a signed sum of the clipped gradients and may cancel to
+    # ~0, so the bound is tied to the gradients that went in (by the third step the
+    # two fp32 trajectories differ by ~1e-4..1e-3 relative in individual gradient elements): 1e-3 of the largest |coef * g| the tensor saw
+    # (exp_avg) / of its square (exp_avg_sq), plus 1e-4 relative.
+    coefs = [min(1.0, hp["max_grad_norm"] / (float(g[f"step{t}/grad_norm"]) + 1e-6)) for t in range(int(g["steps"]))]
+    for k in group(g, "adam_m/"):
+        if _is_pre_bn_bias(k):
+            continue
+        gmax = max(float(np.abs(g[f"step{t}/grad/{k}"]).max()) * coefs[t] for t in range(len(coefs)))
+        # + Adam's eps (its square): gradients of that size are summation noise on both sides
+        for kind, bound in (("m", 1e-3 * gmax + ADAM_EPS), ("v", 2e-3 * gmax * gmax + ADAM_EPS ** 2)):
+            want = g[f"adam_{kind}/{k}"].astype(np.float64)
+            err = np.abs(state[f"{kind}/{k}"].astype(np.float64) - want)
+            assert (err <= 1e-4 * np.abs(want) + bound + 1e-30).all(), (kind, k, float(err.max()))
+    # the padding row never moves (gradient 0, L2 gradient 2*l2*0)
+    for k, v in params.items():
+        if "embeddings.C" in k:
+            assert not v[0].any()
+
+
+def test_adam_and_clip_vs_torch():
+    """oracle.adam_update / clip_coef against torch.optim.Adam + clip_grad_norm_ — the third-party code
+    the reference's trainer calls (trainer.py:67-70, 232-237) — on random tensors, 5 steps."""
+    import torch
+    rng = np.random.default_rng(5)
+    shapes = [(7, 3), (11,), (4, 4, 2)]
+    w = [rng.standard_normal(s).astype(np.float32) for s in shapes]
+    tp = [torch.nn.Parameter(torch.from_numpy(a.copy())) for a in w]
+    opt = torch.optim.Adam(tp, lr=3e-3)
+    m = [np.zeros_like(a) for a in w]
+    v = [np.zeros_like(a) for a in w]
+    for step in range(1, 6):
+        gs = [(rng.standard_normal(s) * (3.0 if step % 2 else 0.01)).astype(np.float32) for s in shapes]
+        for p, gg in zip(tp, gs):
+            p.grad = torch.from_numpy(gg.copy())
+        total = torch.nn.utils.clip_grad_norm_(tp, 1.0)
+        opt.step()
+        sq = sum(float((gg.astype(np.float64) ** 2).sum()) for gg in gs)
+        assert abs(np.sqrt(sq) - float(total)) < 1e-5 * float(total)
+        coef = O.clip_coef(sq, 1.0)
+        assert abs(float(coef) - min(1.0, 1.0 / (float(total) + 1e-6))) < 1e-6
+        for a, mm, vv, gg in zip(w, m, v, gs):
+            O.adam_update(a, mm, vv, gg * coef, step, 3e-3)
+        for a, p in zip(w, tp):
+            assert_close(a, p.detach().numpy(), rtol=1e-5, atol_scale=1e-6, what=f"adam step {step}")

@@ -323,8 +323,81 @@ def case_model(name, kind, fields, fm_dim, hidden, B, seed, **kw):
     save(name, **arrays)
 
 
+def covering_batch(fields, B: int, rng: np.random.Generator):
+    """Every row 1..V-1 of every SPARSE table occurs at least once (then the reference's dense
+    Adam + full-table L2 and a row-wise lazy step coincide: no untouched row exists, and the
+    padding row 0 has gradient 0 and stays 0), plus duplicates and padding ids."""
+    batch = {}
+    for f in fields:
+        if f["type"] == "sparse":
+            V = f["vocab"]
+            assert B >= V - 1
+            x = np.concatenate([np.arange(1, V, dtype=np.int64),
+                                rng.integers(0, V, size=B - (V - 1), dtype=np.int64)])
+            batch[f["name"]] = rng.permutation(x)
+        else:
+            batch[f["name"]] = rng.random(B).astype(np.float32) * 2 - 1
+    return batch
+
+
+def case_train_steps(name, fields, hidden, B, steps, seed, lr, l2, clip, scale=0.25):
+    """The body of the reference's ``Trainer._train_epoch`` (trainer.py:212-240) run for ``steps``
+    batches on the reference's own layer classes: BCEWithLogitsLoss (trainer.py:59) + the L2 term of
+    ``BaseCTRModel.get_l2_reg_loss`` (base.py:78-83: lambda * sum ||p||_2^2 over embedding.parameters()),
+    ``optimizer.zero_grad`` / ``backward`` / ``clip_grad_norm_(model.parameters(), clip)``
+    (trainer.py:228-235) / ``torch.optim.Adam(model.parameters(), lr)`` (trainer.py:67-70, 237)."""
+    rng = np.random.default_rng(seed)
+    torch.manual_seed(seed)
+    model = _RefComposite("deepfm", to_schema(fields), 16, hidden)
+    randomize_(model, rng, scale=scale)
+    model.train()
+    criterion = nn.BCEWithLogitsLoss()
+    optimizer = torch.optim.Adam(model.parameters(), lr=lr)
+    import json
+    cfg = dict(kind="deepfm", fm_dim=16, hidden_units=hidden)
+    arrays = dict(fields=fields_meta(fields), cfg=np.array(json.dumps(cfg)), steps=np.int64(steps),
+                  lr=np.float64(lr), l2=np.float64(l2), clip=np.float64(clip))
+    arrays.update(sd_np(model, "init/"))
+    for t in range(steps):
+        batch = covering_batch(fields, B, rng)
+        labels = (rng.random(B) < 0.3).astype(np.float32)
+        logits = model(tb(batch)).squeeze(1)
+        bce = criterion(logits, torch.from_numpy(labels))
+        l2_loss = torch.tensor(0.0)
+        for p in model.embedding.parameters():
+            l2_loss = l2_loss + p.norm(2).pow(2)
+        l2_term = l2 * l2_loss
+        loss = bce + l2_term
+        optimizer.zero_grad()
+        loss.backward()
+        arrays.update(grads_np(model, f"step{t}/grad/"))        # before clipping: d(bce + l2)/dp
+        total_norm = nn.utils.clip_grad_norm_(model.parameters(), clip)
+        optimizer.step()
+        arrays.update({f"step{t}/batch/" + k: v for k, v in batch.items()})
+        arrays[f"step{t}/labels"] = labels
+        arrays[f"step{t}/logits"] = logits.detach().numpy().copy()
+        arrays[f"step{t}/bce"] = np.float32(bce.item())
+        arrays[f"step{t}/l2_term"] = np.float32(l2_term.item())
+        arrays[f"step{t}/loss"] = np.float32(loss.item())
+        arrays[f"step{t}/grad_norm"] = np.float32(float(total_norm))
+        arrays.update(sd_np(model, f"step{t}/param/"))
+    names = [k for k, _ in model.named_parameters()]
+    for i, k in enumerate(names):                               # torch Adam state is keyed by position
+        st = optimizer.state_dict()["state"][i]
+        arrays["adam_m/" + k] = st["exp_avg"].numpy().copy()
+        arrays["adam_v/" + k] = st["exp_avg_sq"].numpy().copy()
+    save(name, **arrays)
+
+
 def main():
     torch.set_num_threads(4)
+    # train-step tail: BCE + L2 + clip + Adam as the reference's trainer runs them
+    case_train_steps("train_steps_deepfm", criteo_fields(12, 16), [64, 32], 64, 3, 501,
+                     lr=1e-3, l2=1e-5, clip=1.0)                       # reference defaults (config.py:30,64,70)
+    case_train_steps("train_steps_deepfm_l2clip", criteo_fields(9, 16), [64, 32], 48, 3, 502,
+                     lr=1e-2, l2=1e-2, clip=0.25)                      # L2 and clipping both bite
+    if os.environ.get("GOLDEN_ONLY") == "train":
+        return
     # FeatureEmbedding
     case_embedding("emb_movielens_mean", movielens_fields("mean"), 16, 64, 101)
     case_embedding("emb_movielens_sum", movielens_fields("sum"), 16, 32, 102)
