@@ -47,6 +47,8 @@ def parse():
                     help="do not attach HIP events to the gather dispatches (roofline fields become null)")
     ap.add_argument("--unpacked", action="store_true", help="keep the tables as separate contiguous tensors")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--gather-shape", type=int, default=0,
+                    help="tuning aid: force a launch shape of the gather (dfm_gather_set_shape); 0 = automatic")
     ap.add_argument("--h2d", action="store_true",
                     help="batches start in HOST memory and go through the packed H2D ring (PCIe-inclusive rate; "
                          "reported in DESIGN.md, never the headline value)")
@@ -182,6 +184,7 @@ def main():
     import ctypes as C
     from deepfm_amd import _lib
     lib = _lib.load()
+    _lib.check(lib.dfm_gather_set_shape(args.gather_shape))
     for i in range(args.warmup):
         run(i, False)
     if world > 1:

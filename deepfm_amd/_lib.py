@@ -84,6 +84,7 @@ SIGNATURES = {
     "dfm_embedding_forward_staged": (_I, [_P, C.POINTER(_P), C.POINTER(_P), _P, _P, _L, _P, _P, _P, _P, _P, _P]),
     "dfm_gather_timing_begin": (_I, [_I]),
     "dfm_gather_timing_end": (_I, [C.POINTER(C.c_float), _I, C.POINTER(_I)]),
+    "dfm_gather_set_shape": (_I, [_I]),
     "dfm_embedding_backward_dense": (_I, [_P, C.POINTER(_P), _L, _P, _P, _P, C.POINTER(FieldGrad), _P, _P]),
     "dfm_embedding_backward_dense_fields": (_I, [_P, C.POINTER(_P), _L, _P, _P, _P, C.POINTER(FieldGrad), _P]),
     "dfm_rowplan_build": (_I, [C.POINTER(_P), C.POINTER(C.c_int32), _I, _L, _P, _P, _P, _P, _P, _P]),

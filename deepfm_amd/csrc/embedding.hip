@@ -4,11 +4,14 @@
 // autograd (dense V x d gradients, nn.Embedding(sparse=False), embedding.py:35-40).
 //
 // Two forward paths:
-//   * emb_fwd_uniform<D,W>  — every field SPARSE or DENSE with dim == fm_dim == D and no
-//     projection (the Criteo shape).  ONE launch gathers all tables: a wave owns one field
-//     for 64/(D/4) consecutive samples, so ids are read as one coalesced line, rows as
-//     16-byte pieces, and the field table is read with scalar loads.  first_order and the
-//     FM value are reduced across the block's waves through LDS in a fixed order.
+//   * emb_fwd_uniform<D,W,US,UD>  — every field SPARSE or DENSE with dim == fm_dim == D and no
+//     projection (the Criteo shape).  ONE launch gathers all tables: a workgroup of W waves owns
+//     64/(D/4) consecutive samples, a wave US sparse + UD dense fields of them per pass, so ids are
+//     read as one coalesced line and rows as 16-byte pieces, ALL loads of a pass in flight at once
+//     (the kernel is one dependent chain kernarg -> ids -> rows -> stores; round-2 stamps:
+//     profiles/r02_gather_microbench.txt).  field_embeddings is written with non-temporal stores.
+//     first_order and the FM value are reduced across the block's waves through LDS in a fixed
+//     order (W == 1: no LDS, no barrier).
 //   * emb_fwd_general — any schema (mixed dims, projections, SEQUENCE bags): one thread
 //     per (sample, field).  Correctness path for MovieLens-shaped schemas.
 #include "tail_bodies.h"
@@ -20,6 +23,7 @@
 
 using namespace dfm;
 
+
 struct dfm_embedding_plan {
   int num_fields = 0;
   int fm_dim = 0;
@@ -28,11 +32,6 @@ struct dfm_embedding_plan {
   int max_dim = 0;
   std::vector<dfm_field> h_fields;
   std::vector<int32_t> h_sparse, h_dense, h_proj;
-  // device-resident slot tables of the uniform gather (DFM_GATHER_ARGS=device)
-  void* d_slots = nullptr;
-  void* h_shadow = nullptr;        // last uploaded contents
-  void* h_ring = nullptr;          // pinned staging ring
-  int ring_pos = 0;
   dfm_field* d_fields = nullptr;
   int32_t* d_sparse = nullptr;
   int32_t* d_dense = nullptr;
@@ -71,17 +70,23 @@ struct UniformArgs {
   DenseSlot de[kMaxDenseSlots];
 };
 
-template <int D, int W, bool HAS_SPARSE, bool HAS_DENSE>
+typedef float v4f __attribute__((ext_vector_type(4)));
+// field_embeddings is consumed by later kernels, never re-read here: streaming (nt) stores keep it from
+// displacing the XCD's L2 contents and shorten the end-of-kernel write-back (-0.8 us at B = 4096)
+__device__ __forceinline__ void st4_stream(float* p, const float4& v) {
+  v4f t = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(t, reinterpret_cast<v4f*>(p));
+}
+
+template <int D, int W, int US, int UD>
 __device__ __forceinline__ void emb_fwd_uniform_body(
     const UniformArgs& args, int ns, int nd, int64_t B, int F, float* __restrict__ first_order,
     float* __restrict__ fe, float* __restrict__ fm_out, float* __restrict__ fm_sum, int32_t* error_flag,
-    int ablate = 0, const float* __restrict__ extra_src = nullptr, float* __restrict__ extra_dst = nullptr) {
+    const float* __restrict__ extra_src = nullptr, float* __restrict__ extra_dst = nullptr) {
   constexpr int LPR = D / 4;        // lanes per row (16 B each)
   constexpr int SPW = kWave / LPR;  // samples per wave == samples per block
-  constexpr int US = HAS_SPARSE ? 4 : 0;  // sparse slots in flight per wave
-  constexpr int UD = HAS_DENSE ? 2 : 0;   // dense slots in flight per wave
   const int lane = lane_id();
-  const int wave = wave_id_uniform();
+  const int wave = W == 1 ? 0 : wave_id_uniform();
   const int s = lane / LPR, q = lane % LPR;
   const int64_t b = static_cast<int64_t>(blockIdx.x) * SPW + s;
   const bool live = b < B;
@@ -92,27 +97,28 @@ __device__ __forceinline__ void emb_fwd_uniform_body(
   float fo = 0.f;
   bool bad = false;
 
-  // One straight-line block per iteration: every slot, then every id / dense value, then
-  // every row, then the arithmetic, and only then the (predicated) stores — so no branch
-  // sits between a load and its first use and the waits stay counted, not vmcnt(0).
-  // Slots past the end are clamped to slot 0 (a duplicate, cache-hitting load) and masked.
-  const int sp_iters = HAS_SPARSE ? (ns + W * 4 - 1) / (W * 4) : 0;
-  const int de_iters = (HAS_DENSE && !(ablate & 2)) ? (nd + W * 2 - 1) / (W * 2) : 0;
-  if (ablate & 2) nd = 0;
-  const int iters = sp_iters > de_iters ? sp_iters : de_iters;
+  // One straight-line block per pass: every slot, then every id / dense value, then every row, then
+  // the arithmetic, and only then the (predicated) stores — so no branch sits between a load and
+  // its first use and the waits stay counted, not vmcnt(0).  Slots past the end are clamped to
+  // slot 0 (a duplicate, cache-hitting load) and masked.
+  const int sp_iters = US ? (ns + W * US - 1) / (W * US) : 0;
+  const int de_iters = UD ? (nd + W * UD - 1) / (W * UD) : 0;
+  // W == 1 (the host launches it only when one pass covers the plan): slot indices are compile-time
+  // constants, so every slot field is an immediate-offset scalar load from the kernel arguments
+  const int iters = W == 1 ? 1 : (sp_iters > de_iters ? sp_iters : de_iters);
   for (int it = 0; it < iters; ++it) {
     bool oks[US + 1], okd[UD + 1];
     SparseSlot sl[US + 1];
     DenseSlot dl[UD + 1];
 #pragma unroll
     for (int u = 0; u < US; ++u) {
-      const int i = wave + (it * US + u) * W;
+      const int i = W == 1 ? u : wave + (it * US + u) * W;
       oks[u] = i < ns;
       sl[u] = args.sp[oks[u] ? i : 0];
     }
 #pragma unroll
     for (int u = 0; u < UD; ++u) {
-      const int i = wave + (it * UD + u) * W;
+      const int i = W == 1 ? u : wave + (it * UD + u) * W;
       okd[u] = i < nd;
       dl[u] = args.de[okd[u] ? i : 0];
     }
@@ -129,6 +135,16 @@ __device__ __forceinline__ void emb_fwd_uniform_body(
 #pragma unroll
     for (int u = 0; u < UD; ++u)
       if (dl[u].x_out && live && q == 0 && okd[u]) dl[u].x_out[b] = x[u];
+    float4 row[US + 1];
+    float w1v[US + 1];
+#pragma unroll
+    for (int u = 0; u < US; ++u) {
+      const bool oob = static_cast<uint64_t>(id[u]) >= static_cast<uint64_t>(sl[u].vocab);
+      bad |= oob && oks[u];
+      id[u] = oob ? 0 : id[u];
+      row[u] = ld4(sl[u].w2 + id[u] * sl[u].stride2 + q * 4);
+      w1v[u] = sl[u].w1[id[u] * sl[u].stride1];   // same address on the row's lanes: one request
+    }
     float4 dw[UD + 1], db[UD + 1];
     float dw1[UD + 1], db1[UD + 1];
 #pragma unroll
@@ -138,29 +154,7 @@ __device__ __forceinline__ void emb_fwd_uniform_body(
       dw1[u] = dl[u].w1[0];
       db1[u] = dl[u].b1[0];
     }
-    float4 row[US + 1];
-    float w1v[US + 1];
-#pragma unroll
-    for (int u = 0; u < US; ++u) {
-      const bool oob = static_cast<uint64_t>(id[u]) >= static_cast<uint64_t>(sl[u].vocab);
-      bad |= oob && oks[u];
-      id[u] = oob ? 0 : id[u];
-      row[u] = ld4(sl[u].w2 + id[u] * sl[u].stride2 + q * 4);
-      w1v[u] = (ablate & 1) ? 0.f : sl[u].w1[id[u] * sl[u].stride1];   // same address on the row's lanes: one request
-    }
-    float4 ed[UD + 1];
-#pragma unroll
-    for (int u = 0; u < UD; ++u) {
-      const float m = okd[u] ? 1.f : 0.f;
-      float4 e;
-      e.x = fmaf(x[u], dw[u].x, db[u].x); e.y = fmaf(x[u], dw[u].y, db[u].y);
-      e.z = fmaf(x[u], dw[u].z, db[u].z); e.w = fmaf(x[u], dw[u].w, db[u].w);
-      ed[u] = e;
-      S.x = fmaf(m, e.x, S.x); S.y = fmaf(m, e.y, S.y); S.z = fmaf(m, e.z, S.z); S.w = fmaf(m, e.w, S.w);
-      SQ.x = fmaf(m * e.x, e.x, SQ.x); SQ.y = fmaf(m * e.y, e.y, SQ.y);
-      SQ.z = fmaf(m * e.z, e.z, SQ.z); SQ.w = fmaf(m * e.w, e.w, SQ.w);
-      fo = fmaf(m, fmaf(x[u], dw1[u], db1[u]), fo);
-    }
+    float* out = fe + b * F * D + q * 4;
 #pragma unroll
     for (int u = 0; u < US; ++u) {
       const float m = oks[u] ? 1.f : 0.f;
@@ -169,64 +163,178 @@ __device__ __forceinline__ void emb_fwd_uniform_body(
       SQ.x = fmaf(m * e.x, e.x, SQ.x); SQ.y = fmaf(m * e.y, e.y, SQ.y);
       SQ.z = fmaf(m * e.z, e.z, SQ.z); SQ.w = fmaf(m * e.w, e.w, SQ.w);
       fo = fmaf(m, w1v[u], fo);
+      if (live && oks[u]) st4_stream(out + sl[u].field * D, e);
     }
 #pragma unroll
-    for (int u = 0; u < UD; ++u)
-      if (live && okd[u]) st4(fe + (b * F + dl[u].field) * D + q * 4, ed[u]);
-#pragma unroll
-    for (int u = 0; u < US; ++u)
-      if (live && oks[u]) st4(fe + (b * F + sl[u].field) * D + q * 4, row[u]);
+    for (int u = 0; u < UD; ++u) {
+      const float m = okd[u] ? 1.f : 0.f;
+      float4 e;
+      e.x = fmaf(x[u], dw[u].x, db[u].x); e.y = fmaf(x[u], dw[u].y, db[u].y);
+      e.z = fmaf(x[u], dw[u].z, db[u].z); e.w = fmaf(x[u], dw[u].w, db[u].w);
+      S.x = fmaf(m, e.x, S.x); S.y = fmaf(m, e.y, S.y); S.z = fmaf(m, e.z, S.z); S.w = fmaf(m, e.w, S.w);
+      SQ.x = fmaf(m * e.x, e.x, SQ.x); SQ.y = fmaf(m * e.y, e.y, SQ.y);
+      SQ.z = fmaf(m * e.z, e.z, SQ.z); SQ.w = fmaf(m * e.w, e.w, SQ.w);
+      fo = fmaf(m, fmaf(x[u], dw1[u], db1[u]), fo);
+      if (live && okd[u]) st4_stream(out + dl[u].field * D, e);
+    }
   }
   if (bad && error_flag) atomicOr(error_flag, 1);
-  if (ablate & 4) return;
   if (q != 0) fo = 0.f;  // every lane of a row loaded the same first-order value: count it once
-  // ---- fixed-order reduction over the block's waves --------------------------------------
-  __shared__ float red[W][9][kWave];
-  red[wave][0][lane] = S.x;  red[wave][1][lane] = S.y;  red[wave][2][lane] = S.z;
-  red[wave][3][lane] = S.w;  red[wave][4][lane] = SQ.x; red[wave][5][lane] = SQ.y;
-  red[wave][6][lane] = SQ.z; red[wave][7][lane] = SQ.w; red[wave][8][lane] = fo;
-  __syncthreads();
-  if (wave == 0) {
-    float acc[9];
+  float acc[9] = {S.x, S.y, S.z, S.w, SQ.x, SQ.y, SQ.z, SQ.w, fo};
+  if (W > 1) {
+    // ---- fixed-order reduction over the block's waves ------------------------------------
+    __shared__ float red[W][9][kWave];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) red[wave][c][lane] = acc[c];
+    __syncthreads();
+    if (wave != 0) return;
 #pragma unroll
     for (int c = 0; c < 9; ++c) acc[c] = red[0][c][lane];
     for (int w = 1; w < W; ++w) {
 #pragma unroll
       for (int c = 0; c < 9; ++c) acc[c] += red[w][c][lane];
     }
-    // 0.5 * sum_d (S_d^2 - SQ_d)   (fm.py:20-22)
-    float t = (acc[0] * acc[0] - acc[4]) + (acc[1] * acc[1] - acc[5]) +
-              (acc[2] * acc[2] - acc[6]) + (acc[3] * acc[3] - acc[7]);
-#pragma unroll
-    for (int m = 1; m < LPR; m <<= 1) t += __shfl_xor(t, m, kWave);
-    if (live && q == 0) {
-      first_order[b] = acc[8];
-      if (fm_out) fm_out[b] = 0.5f * t;
-    }
-    // S[b, :] = sum_f e[b, f, :] for the FM backward g * (S - e)
-    if (live && fm_sum) st4(fm_sum + b * D + q * 4, make_float4(acc[0], acc[1], acc[2], acc[3]));
-    if (live && q == 0 && extra_dst) extra_dst[b] = extra_src[b];      // per-sample payload (labels)
   }
+  // 0.5 * sum_d (S_d^2 - SQ_d)   (fm.py:20-22)
+  float t = (acc[0] * acc[0] - acc[4]) + (acc[1] * acc[1] - acc[5]) +
+            (acc[2] * acc[2] - acc[6]) + (acc[3] * acc[3] - acc[7]);
+#pragma unroll
+  for (int m = 1; m < LPR; m <<= 1) t += __shfl_xor(t, m, kWave);
+  if (live && q == 0) {
+    first_order[b] = acc[8];
+    if (fm_out) fm_out[b] = 0.5f * t;
+  }
+  // S[b, :] = sum_f e[b, f, :] for the FM backward g * (S - e)
+  if (live && fm_sum) st4(fm_sum + b * D + q * 4, make_float4(acc[0], acc[1], acc[2], acc[3]));
+  if (live && q == 0 && extra_dst) extra_dst[b] = extra_src[b];      // per-sample payload (labels)
 }
 
-// slot tables in the kernel-argument segment ...
-template <int D, int W, bool HAS_SPARSE, bool HAS_DENSE>
+// --------------------------------------------------------------------------------------------------
+// emb_fwd_pair<D, NS, ND, STAGE>: the same gather compiled for an EXACT field count (the Criteo shape:
+// NS = 26 SPARSE + ND = 13 DENSE).  A workgroup of TWO waves owns 64/(D/4) samples; wave w takes the
+// slots 2u + w.  Every slot index and both counts are compile-time constants: slot fields are
+// immediate-offset scalar loads, there is no run-time selection, masking or branch between a load and
+// its use (staging is a template flag), and all of a wave's loads are in flight in three rounds:
+// ids + dense values -> rows + first-order scalars + dense weights -> math + streaming stores.
+// Measured against the 8-wave shape on the same tables: profiles/r02_gather_shapes.csv.
+template <int D, int NS, int ND, bool STAGE, int WAVE>
+__device__ __forceinline__ void emb_fwd_pair_wave(
+    const UniformArgs& args, int64_t B, int F, float* __restrict__ fe, int32_t* error_flag, float (&acc)[9]) {
+  constexpr int LPR = D / 4;
+  constexpr int SPW = kWave / LPR;
+  constexpr int HS = (NS - WAVE + 1) / 2, HD = (ND - WAVE + 1) / 2;   // this wave's slots: 2u + WAVE
+  const int lane = lane_id();
+  const int s = lane / LPR, q = lane % LPR;
+  const int64_t b = static_cast<int64_t>(blockIdx.x) * SPW + s;
+  const bool live = b < B;
+  const int64_t bc = live ? b : B - 1;
+  int64_t id[HS + 1];
+  float x[HD + 1];
+#pragma unroll
+  for (int u = 0; u < HS; ++u) id[u] = args.sp[2 * u + WAVE].ids[bc];
+#pragma unroll
+  for (int u = 0; u < HD; ++u) x[u] = args.de[2 * u + WAVE].x[bc];
+  float4 row[HS + 1];
+  float w1v[HS + 1];
+  bool bad = false;
+#pragma unroll
+  for (int u = 0; u < HS; ++u) {
+    const SparseSlot& sl = args.sp[2 * u + WAVE];
+    const bool oob = static_cast<uint64_t>(id[u]) >= static_cast<uint64_t>(sl.vocab);
+    bad |= oob;
+    const int64_t i = oob ? 0 : id[u];
+    row[u] = ld4(sl.w2 + i * sl.stride2 + q * 4);
+    w1v[u] = sl.w1[i * sl.stride1];
+  }
+  float4 dw[HD + 1], db[HD + 1];
+  float dw1[HD + 1], db1[HD + 1];
+#pragma unroll
+  for (int u = 0; u < HD; ++u) {
+    const DenseSlot& dl = args.de[2 * u + WAVE];
+    dw[u] = ld4(dl.w2 + q * 4);
+    db[u] = ld4(dl.b2 + q * 4);
+    dw1[u] = dl.w1[0];
+    db1[u] = dl.b1[0];
+  }
+  if (STAGE && live && q == 0) {
+#pragma unroll
+    for (int u = 0; u < HS; ++u) args.sp[2 * u + WAVE].ids_out[b] = id[u];
+#pragma unroll
+    for (int u = 0; u < HD; ++u) args.de[2 * u + WAVE].x_out[b] = x[u];
+  }
+  float4 S = make_float4(0.f, 0.f, 0.f, 0.f), SQ = make_float4(0.f, 0.f, 0.f, 0.f);
+  float fo = 0.f;
+  float* out = fe + b * F * D + q * 4;
+#pragma unroll
+  for (int u = 0; u < HS; ++u) {
+    const float4 e = row[u];
+    S.x += e.x; S.y += e.y; S.z += e.z; S.w += e.w;
+    SQ.x = fmaf(e.x, e.x, SQ.x); SQ.y = fmaf(e.y, e.y, SQ.y);
+    SQ.z = fmaf(e.z, e.z, SQ.z); SQ.w = fmaf(e.w, e.w, SQ.w);
+    fo += w1v[u];
+    if (live) st4_stream(out + args.sp[2 * u + WAVE].field * D, e);
+  }
+#pragma unroll
+  for (int u = 0; u < HD; ++u) {
+    float4 e;
+    e.x = fmaf(x[u], dw[u].x, db[u].x); e.y = fmaf(x[u], dw[u].y, db[u].y);
+    e.z = fmaf(x[u], dw[u].z, db[u].z); e.w = fmaf(x[u], dw[u].w, db[u].w);
+    S.x += e.x; S.y += e.y; S.z += e.z; S.w += e.w;
+    SQ.x = fmaf(e.x, e.x, SQ.x); SQ.y = fmaf(e.y, e.y, SQ.y);
+    SQ.z = fmaf(e.z, e.z, SQ.z); SQ.w = fmaf(e.w, e.w, SQ.w);
+    fo += fmaf(x[u], dw1[u], db1[u]);
+    if (live) st4_stream(out + args.de[2 * u + WAVE].field * D, e);
+  }
+  if (bad && error_flag) atomicOr(error_flag, 1);
+  if (q != 0) fo = 0.f;
+  acc[0] = S.x; acc[1] = S.y; acc[2] = S.z; acc[3] = S.w;
+  acc[4] = SQ.x; acc[5] = SQ.y; acc[6] = SQ.z; acc[7] = SQ.w; acc[8] = fo;
+}
+
+template <int D, int NS, int ND, bool STAGE>
+__global__ __launch_bounds__(128) void emb_fwd_pair(
+    UniformArgs args, int64_t B, int F, float* __restrict__ first_order, float* __restrict__ fe,
+    float* __restrict__ fm_out, float* __restrict__ fm_sum, int32_t* error_flag,
+    const float* __restrict__ extra_src, float* __restrict__ extra_dst) {
+  constexpr int LPR = D / 4;
+  constexpr int SPW = kWave / LPR;
+  __shared__ float red[9][kWave];
+  const int lane = lane_id();
+  float acc[9];
+  if (wave_id_uniform() == 1) {
+    emb_fwd_pair_wave<D, NS, ND, STAGE, 1>(args, B, F, fe, error_flag, acc);
+#pragma unroll
+    for (int c = 0; c < 9; ++c) red[c][lane] = acc[c];
+    __syncthreads();
+    return;
+  }
+  emb_fwd_pair_wave<D, NS, ND, STAGE, 0>(args, B, F, fe, error_flag, acc);
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < 9; ++c) acc[c] += red[c][lane];      // fixed order: wave 0 + wave 1
+  const int s = lane / LPR, q = lane % LPR;
+  const int64_t b = static_cast<int64_t>(blockIdx.x) * SPW + s;
+  const bool live = b < B;
+  float t = (acc[0] * acc[0] - acc[4]) + (acc[1] * acc[1] - acc[5]) +
+            (acc[2] * acc[2] - acc[6]) + (acc[3] * acc[3] - acc[7]);
+#pragma unroll
+  for (int m = 1; m < LPR; m <<= 1) t += __shfl_xor(t, m, kWave);
+  if (live && q == 0) {
+    first_order[b] = acc[8];
+    if (fm_out) fm_out[b] = 0.5f * t;
+    if (STAGE && extra_dst) extra_dst[b] = extra_src[b];
+  }
+  if (live && fm_sum) st4(fm_sum + b * D + q * 4, make_float4(acc[0], acc[1], acc[2], acc[3]));
+}
+
+// slot tables in the kernel-argument segment (first touch measured at 0-40 ns: the segment is hot
+// when the waves start)
+template <int D, int W, int US, int UD>
 __global__ __launch_bounds__(W * 64) void emb_fwd_uniform(
     UniformArgs args, int ns, int nd, int64_t B, int F, float* __restrict__ first_order,
-    float* __restrict__ fe, float* __restrict__ fm_out, float* __restrict__ fm_sum, int32_t* error_flag, int ablate,
+    float* __restrict__ fe, float* __restrict__ fm_out, float* __restrict__ fm_sum, int32_t* error_flag,
     const float* __restrict__ extra_src, float* __restrict__ extra_dst) {
-  emb_fwd_uniform_body<D, W, HAS_SPARSE, HAS_DENSE>(args, ns, nd, B, F, first_order, fe, fm_out, fm_sum, error_flag, ablate,
-                                                    extra_src, extra_dst);
-}
-// ... or in device memory owned by the plan (refreshed only when a pointer changes)
-template <int D, int W, bool HAS_SPARSE, bool HAS_DENSE>
-__global__ __launch_bounds__(W * 64) void emb_fwd_uniform_mem(
-    const UniformArgs* __restrict__ args, int ns, int nd, int64_t B, int F,
-    float* __restrict__ first_order, float* __restrict__ fe, float* __restrict__ fm_out,
-    float* __restrict__ fm_sum, int32_t* error_flag, int ablate, const float* __restrict__ extra_src,
-    float* __restrict__ extra_dst) {
-  emb_fwd_uniform_body<D, W, HAS_SPARSE, HAS_DENSE>(*args, ns, nd, B, F, first_order, fe, fm_out, fm_sum, error_flag, ablate,
-                                                    extra_src, extra_dst);
+  emb_fwd_uniform_body<D, W, US, UD>(args, ns, nd, B, F, first_order, fe, fm_out, fm_sum, error_flag, extra_src, extra_dst);
 }
 
 // ======================================================================================
@@ -499,9 +607,6 @@ extern "C" int dfm_embedding_plan_create(const dfm_field* fields, int num_fields
 
 extern "C" int dfm_embedding_plan_destroy(dfm_embedding_plan* plan) {
   if (!plan) return DFM_OK;
-  (void)hipFree(plan->d_slots);
-  if (plan->h_ring) (void)hipHostFree(plan->h_ring);
-  free(plan->h_shadow);
   (void)hipFree(plan->d_fields);
   (void)hipFree(plan->d_sparse);
   (void)hipFree(plan->d_dense);
@@ -526,7 +631,6 @@ static int fill_ptrs(const dfm_embedding_plan* plan, const void* const* inputs, 
   return DFM_OK;
 }
 
-// timing-only ablation mask for tools/microbench_gather (0 in every product call)
 // Per-launch kernel timing for bench.py: when armed, the uniform gather is launched with
 // hipExtLaunchKernelGGL, whose start/stop events are recorded by the command processor exactly
 // around the dispatch (the same interval rocprofv3's kernel trace reports) instead of around the
@@ -536,25 +640,20 @@ struct GatherTimer {
   std::vector<hipEvent_t> start, stop;
   int used = 0;
 } g_gather_timer;
+int g_gather_shape = 0;   // 0 = automatic; tools only (dfm_gather_set_shape)
 }  // namespace
 
-static int g_ablate = [] { const char* e = getenv("DFM_GATHER_ABLATE"); return e ? atoi(e) : 0; }();
-
-static bool gather_args_in_mem() {
-  static bool v = [] {
-    const char* e = getenv("DFM_GATHER_ARGS");
-    return e && !strcmp(e, "device");
-  }();
-  return v;
-}
-
-static int gather_waves() {
-  static int w = [] {
-    const char* e = getenv("DFM_GATHER_WAVES");
-    const int v = e ? atoi(e) : 8;
-    return (v == 4 || v == 8 || v == 16) ? v : 8;
-  }();
-  return w;
+// Launch shapes (W waves per workgroup, US sparse + UD dense slots in flight per wave and pass):
+//   1: W = 1, 26 + 13 — a lane group owns its sample across all fields: no LDS, no barrier
+//   2: W = 2, 13 + 7
+//   3: W = 4,  8 + 4
+//   4: W = 8,  4 + 2  (round 1's shape; more slots than a pass holds simply take more passes)
+//   5: emb_fwd_pair — two waves, compile-time field counts (26 SPARSE + 13 DENSE, D = 16 / 32)
+// Automatic choice: 5 where it applies, else 4.  Shapes 1-3 exist for tools/time_gather.py.
+extern "C" int dfm_gather_set_shape(int shape) {
+  DFM_REQUIRE(shape >= 0 && shape <= 5, "gather shape %d outside [0, 5]", shape);
+  g_gather_shape = shape;
+  return DFM_OK;
 }
 
 template <int D>
@@ -580,55 +679,47 @@ static int launch_uniform(const dfm_embedding_plan* plan, const PtrTable& in, in
   }
   const dim3 grid(static_cast<unsigned>((B + SPW - 1) / SPW));
   const int F = plan->num_fields;
-  const UniformArgs* d_args = nullptr;
-  if (gather_args_in_mem()) {
-    constexpr int kRing = 8;
-    auto* mp = const_cast<dfm_embedding_plan*>(plan);
-    if (!mp->d_slots) {
-      DFM_HIP_TRY(hipMalloc(&mp->d_slots, sizeof(UniformArgs)));
-      DFM_HIP_TRY(hipHostMalloc(&mp->h_ring, sizeof(UniformArgs) * kRing, hipHostMallocDefault));
-      mp->h_shadow = calloc(1, sizeof(UniformArgs));
-    }
-    const size_t used = sizeof(SparseSlot) * kMaxSparseSlots + sizeof(DenseSlot) * nd;
-    if (memcmp(mp->h_shadow, &args, used) != 0) {     // a pointer changed: refresh the device copy
-      void* stage = static_cast<char*>(mp->h_ring) + sizeof(UniformArgs) * (mp->ring_pos++ % kRing);
-      memcpy(stage, &args, sizeof(UniformArgs));
-      memcpy(mp->h_shadow, &args, sizeof(UniformArgs));
-      DFM_HIP_TRY(hipMemcpyAsync(mp->d_slots, stage, sizeof(UniformArgs), hipMemcpyHostToDevice, st));
-    }
-    d_args = static_cast<const UniformArgs*>(mp->d_slots);
-  }
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   if (g_gather_timer.used < static_cast<int>(g_gather_timer.start.size())) {
     ev0 = g_gather_timer.start[g_gather_timer.used];
     ev1 = g_gather_timer.stop[g_gather_timer.used];
     ++g_gather_timer.used;
   }
-#define DFM_GATHER_LAUNCH(WV, HS, HD)                                                                   \
-  do {                                                                                                  \
-    if (ev0 && !d_args)                                                                                 \
-      hipExtLaunchKernelGGL((emb_fwd_uniform<D, WV, HS, HD>), grid, dim3(WV * 64), 0, st, ev0, ev1, 0,  \
-                            args, ns, nd, B, F, fo, fe, fm_out, fm_sum, err, g_ablate, extra_src,      \
-                            extra_dst);                                                                 \
-    else if (d_args)                                                                                         \
-      hipLaunchKernelGGL((emb_fwd_uniform_mem<D, WV, HS, HD>), grid, dim3(WV * 64), 0, st, d_args, ns,  \
-                         nd, B, F, fo, fe, fm_out, fm_sum, err, g_ablate, extra_src, extra_dst);                \
-    else                                                                                                \
-      hipLaunchKernelGGL((emb_fwd_uniform<D, WV, HS, HD>), grid, dim3(WV * 64), 0, st, args, ns, nd, B, \
-                         F, fo, fe, fm_out, fm_sum, err, g_ablate, extra_src, extra_dst);                       \
+#define DFM_GATHER_LAUNCH(WV, US_, UD_)                                                                     \
+  do {                                                                                                      \
+    if (ev0)                                                                                                \
+      hipExtLaunchKernelGGL((emb_fwd_uniform<D, WV, US_, UD_>), grid, dim3(WV * 64), 0, st, ev0, ev1, 0,   \
+                            args, ns, nd, B, F, fo, fe, fm_out, fm_sum, err, extra_src, extra_dst);         \
+    else                                                                                                    \
+      hipLaunchKernelGGL((emb_fwd_uniform<D, WV, US_, UD_>), grid, dim3(WV * 64), 0, st, args, ns, nd, B,  \
+                         F, fo, fe, fm_out, fm_sum, err, extra_src, extra_dst);                             \
   } while (0)
-#define DFM_GATHER_PICK(WV)                                    \
-  do {                                                         \
-    if (ns > 0 && nd > 0) DFM_GATHER_LAUNCH(WV, true, true);   \
-    else if (ns > 0) DFM_GATHER_LAUNCH(WV, true, false);       \
-    else DFM_GATHER_LAUNCH(WV, false, true);                   \
+#define DFM_PAIR_LAUNCH(NS_, ND_, STG)                                                                       \
+  do {                                                                                                      \
+    if (ev0)                                                                                                \
+      hipExtLaunchKernelGGL((emb_fwd_pair<D, NS_, ND_, STG>), grid, dim3(128), 0, st, ev0, ev1, 0, args,   \
+                            B, F, fo, fe, fm_out, fm_sum, err, extra_src, extra_dst);                       \
+    else                                                                                                    \
+      hipLaunchKernelGGL((emb_fwd_pair<D, NS_, ND_, STG>), grid, dim3(128), 0, st, args, B, F, fo, fe,     \
+                         fm_out, fm_sum, err, extra_src, extra_dst);                                        \
   } while (0)
-  switch (gather_waves()) {
-    case 4: DFM_GATHER_PICK(4); break;
-    case 16: DFM_GATHER_PICK(16); break;
-    default: DFM_GATHER_PICK(8);
+  int shape = g_gather_shape;
+  // automatic: the exact-count two-wave kernel for the Criteo field counts (D = 16 / 32), else 8 waves
+  const bool pair_ok = (D == 16 || D == 32) && ns == 26 && nd == 13;
+  if (shape == 0) shape = pair_ok ? 5 : 4;
+  if (shape == 5 && !pair_ok) shape = 4;
+  switch (shape) {
+    case 1: DFM_GATHER_LAUNCH(1, 26, 13); break;
+    case 2: DFM_GATHER_LAUNCH(2, 13, 7); break;
+    case 3: DFM_GATHER_LAUNCH(4, 8, 4); break;
+    case 5:
+      if constexpr (D == 16 || D == 32) {
+        if (stage_out) DFM_PAIR_LAUNCH(26, 13, true); else DFM_PAIR_LAUNCH(26, 13, false);
+      }
+      break;
+    default: DFM_GATHER_LAUNCH(8, 4, 2);
   }
-#undef DFM_GATHER_PICK
+#undef DFM_PAIR_LAUNCH
 #undef DFM_GATHER_LAUNCH
   DFM_LAUNCH_CHECK();
   return DFM_OK;

@@ -188,6 +188,8 @@ class RowSparseTrainStep:
         mode = dict(capture_error_mode="thread_local")
         self.graph_a = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph_a, **mode):
+            if os.environ.get("DFM_EXP_GATHER_IN_GRAPH") == "1":      # timing experiment only
+                self._gather()
             self._body_a()
             if single or fused_exchange:
                 self.opt.exchange()          # one rank: no device work, selects the local row lists
@@ -225,7 +227,7 @@ class RowSparseTrainStep:
             if self.gather_events is None:
                 self.gather_events = []
             self.gather_events.append((start, end))
-        else:
+        elif not (os.environ.get("DFM_EXP_GATHER_IN_GRAPH") == "1" and self.graph_a is not None):
             self._gather()
         if self.graph_a is not None:
             self.graph_a.replay()

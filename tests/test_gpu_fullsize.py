@@ -87,8 +87,13 @@ def test_headline_config_two_graph_steps_vs_oracle():
     ocfg = dict(fm_dim=D, hidden_units=cfg.dnn.hidden_units)
     dense_h, labels_h = npy(dense), npy(labels)
 
-    ill = {}                                       # |clipped gradient| within 100x of Adam's eps: ill-conditioned
+    lr, (b1, b2), eps = hp["lr"], (0.9, 0.999), 1e-8
+    k2s = {n: f"embedding.second_order_embeddings.{n}.weight" for n in names}
+    k1s = {n: f"embedding.first_order_embeddings.{n}.weight" for n in names}
+    sel = {n: torch.from_numpy(uniq[n]).cuda() for n in names}
+    n_checked = 0
     for t in range(2):
+        prev = {n: npy(model.embedding.packed[n]["buffer"][sel[n]]) for n in names}
         step.run_from(records[t])
         torch.cuda.synchronize()
         batch = {n: small_ids[n][t] for n in names}
@@ -98,44 +103,94 @@ def test_headline_config_two_graph_steps_vs_oracle():
         assert_close(npy(step.logits), info["logits"].reshape(-1), what=f"logits step {t}")
         assert abs(float(step.loss) - float(oloss)) < 1e-4 * float(oloss)
         assert abs(float(opt.sq_norm) - info["sq_norm"]) < 1e-4 * info["sq_norm"]
-        assert abs(float(opt.clip_coef) - float(info["coef"])) < 1e-5
-        for n, (u, r2, r1) in info["rows"].items():
-            m = ill.setdefault(n, np.zeros((len(uniq[n]) + 1, D + 1), bool))
-            m[u, :D] |= np.abs(r2) * float(info["coef"]) < 1e-6
-            m[u, D] |= np.abs(r1) * float(info["coef"]) < 1e-6
+        coef = float(info["coef"])
+        assert abs(float(opt.clip_coef) - coef) < 1e-5
         assert int(model.embedding._err.item()) == 0
-
-    # ---- touched rows: weights (1e-4 + 2 % of one Adam step on well-conditioned elements) and moments
-    lr = hp["lr"]
-    n_checked = 0
-    for j, n in enumerate(names):
-        buf = model.embedding.packed[n]["buffer"]
-        u = uniq[n]
-        got = npy(buf[torch.from_numpy(u).cuda()])
-        k2, k1 = f"embedding.second_order_embeddings.{n}.weight", f"embedding.first_order_embeddings.{n}.weight"
-        want_w = np.concatenate([params[k2][1:], params[k1][1:]], axis=1)               # (n_u, 17)
-        ok = ~ill[n][1:]
-        assert ok.mean() > 0.9, (n, ok.mean())
-        assert_close(np.where(ok, got[:, :D + 1], 0), np.where(ok, want_w, 0), rtol=1e-4, atol_scale=0.0,
-                     floor=0.02 * lr, what=f"{n} rows")
-        moved = np.abs(got[:, :D] - npy(before[n][torch.from_numpy(u).cuda()])[:, :D]).max(axis=1)
-        assert (moved > 0.5 * lr).all(), "a touched row did not take its Adam step"
-        assert_close(got[:, D + 4:2 * D + 4], state["m/" + k2][1:], rtol=1e-3, atol_scale=1e-4, what=f"{n} exp_avg")
-        assert_close(got[:, 2 * D + 4:3 * D + 4], state["v/" + k2][1:], rtol=2e-3, atol_scale=1e-4, what=f"{n} exp_avg_sq")
-        # ---- untouched rows: bit-unchanged records (weights AND moments)
-        changed = (buf != before[n]).any(dim=1).nonzero().view(-1)
-        assert np.array_equal(npy(changed), u), f"{n}: rows changed that the batches did not touch (or vice versa)"
-        n_checked += len(u)
+        bc1, bc2 = 1 - b1 ** (t + 1), 1 - b2 ** (t + 1)
+        kinked = set()
+        for j, n in enumerate(names):
+            got = npy(model.embedding.packed[n]["buffer"][sel[n]])                       # (n_u, 64) records
+            u_t = info["rows"][n][0]                                                    # compact ids this step touched
+            hit = np.zeros(len(uniq[n]), bool)
+            hit[u_t - 1] = True
+            # (1) Adam moments are LINEAR in the gradient: well conditioned, held to the oracle directly.
+            #     They pin gather -> forward -> backward -> row reduction -> lazy L2 -> clip at full size.
+            m2, v2 = got[:, D + 4:2 * D + 4], got[:, 2 * D + 4:3 * D + 4]
+            m1, v1 = got[:, D + 1], got[:, D + 2]
+            want_m2 = state["m/" + k2s[n]][1:]
+            # ReLU kinks: a hidden pre-activation within rounding of 0 may take the other side than in the
+            # oracle's summation order; that changes ONE sample's d(embedding) by a few percent.  Rows fed
+            # by such a sample are collected (kinked, at most 0.3 % of the batch over all fields) and left
+            # out; every other row is held to the oracle.
+            bad_rows = np.flatnonzero((np.abs(m2 - want_m2) > 1e-4 * np.abs(want_m2) + 2e-5 * np.abs(want_m2).max()).any(axis=1))
+            for r in bad_rows:
+                pos = np.flatnonzero(ids_h[t, j] == uniq[n][r])
+                assert len(pos) >= 1, f"{n} step {t}: exp_avg differs for a row outside the batch"
+                assert np.abs(m2[r] - want_m2[r]).max() < 0.05 * np.abs(want_m2).max(), (n, t, int(uniq[n][r]))
+                kinked.update(pos.tolist())
+            keep = np.ones(len(uniq[n]), bool)
+            keep[bad_rows] = False
+            assert_close(m2[keep], want_m2[keep], rtol=1e-4, atol_scale=2e-5, what=f"{n} exp_avg step {t}")
+            assert_close(v2[keep], state["v/" + k2s[n]][1:][keep], rtol=2e-4, atol_scale=2e-5, what=f"{n} exp_avg_sq step {t}")
+            assert_close(m1, state["m/" + k1s[n]][1:, 0], rtol=1e-4, atol_scale=2e-5, what=f"{n} exp_avg(1st) step {t}")
+            assert_close(v1, state["v/" + k1s[n]][1:, 0], rtol=2e-4, atol_scale=2e-5, what=f"{n} exp_avg_sq(1st) step {t}")
+            # (2) the weight update IS ill conditioned wherever |g| ~ eps (at B = 4096 most row-gradient
+            #     elements are 1e-9..1e-6): it is checked as Adam's formula (trainer.py:67-70, 237) applied to
+            #     the kernel's own moments, and against the oracle's weights on the well-conditioned elements.
+            w_prev = np.concatenate([prev[n][:, :D], prev[n][:, D:D + 1]], axis=1).astype(np.float64)
+            m = np.concatenate([m2, m1[:, None]], axis=1).astype(np.float64)
+            v = np.concatenate([v2, v1[:, None]], axis=1).astype(np.float64)
+            w_formula = w_prev - (lr / bc1) * m / (np.sqrt(v) / np.sqrt(bc2) + eps)
+            w_got = np.concatenate([got[:, :D], got[:, D:D + 1]], axis=1)
+            assert np.abs(w_got[hit] - w_formula[hit]).max() < 1e-3 * lr, f"{n}: weights are not Adam(m, v) at step {t}"
+            assert np.array_equal(got[~hit], prev[n][~hit]), f"{n}: a record outside step {t}'s batch changed"
+            want_w = np.concatenate([params[k2s[n]][1:], params[k1s[n]][1:]], axis=1)
+            r2, r1 = info["rows"][n][1], info["rows"][n][2]
+            well = np.zeros(want_w.shape, bool)
+            well[u_t - 1] = np.abs(np.concatenate([r2, r1[:, None]], axis=1)) * coef > 1e-6
+            well[~keep] = False
+            assert_close(np.where(well, w_got, 0), np.where(well, want_w, 0), rtol=1e-4, atol_scale=0.0, floor=0.02 * lr,
+                         what=f"{n} rows step {t}")
+            n_checked += int(hit.sum())
+            # teacher forcing: the next step of the oracle starts from the kernel's state, so that step 1 is
+            # checked on its own and not through the ill-conditioned part of step 0
+            params[k2s[n]][1:], params[k1s[n]][1:, 0] = got[:, :D], got[:, D]
+            state["m/" + k2s[n]][1:], state["v/" + k2s[n]][1:] = m2, v2
+            state["m/" + k1s[n]][1:, 0], state["v/" + k1s[n]][1:, 0] = m1, v1
+        assert len(kinked) <= 0.003 * B, f"step {t}: {len(kinked)} samples disagree with the oracle (ReLU-kink allowance: 12)"
+        # ---- dense parameters: moments against the oracle, then teacher forcing.  A kinked sample moves the
+        # gradient row of the flipped unit by ~1/B of its magnitude: bounded outliers (<= 1 % of a tensor,
+        # each within 1 % of the tensor's gradient scale), everything else at the normal bar.
+        osd = opt.state_dict()["state"]
+        got_p = {k: npy(v) for k, v in model.state_dict().items()}
+        for k in list(params):
+            if "embeddings.C" in k or "running_" in k:
+                continue
+            pre_bn_bias = k.startswith("dnn.mlp.") and k.endswith(".bias") and int(k.split(".")[2]) % 4 == 0
+            gm, gv = npy(osd[k]["exp_avg"]), npy(osd[k]["exp_avg_sq"])
+            if not pre_bn_bias:                     # identically-zero gradient in front of BatchNorm: noise
+                gscale = float(np.abs(info["grads"][k]).max()) * coef
+                em = np.abs(gm - state["m/" + k])
+                out_m = em > 1e-4 * np.abs(state["m/" + k]) + 1e-3 * gscale       # batch sums of 4096 cancelling terms
+                assert out_m.mean() <= (0.01 if kinked else 0.0) and em.max() <= 1e-2 * gscale, (k, t, out_m.mean(), em.max())
+                ev = np.abs(gv - state["v/" + k])
+                out_v = ev > 2e-4 * np.abs(state["v/" + k]) + 2e-6 * gscale ** 2
+                assert out_v.mean() <= (0.01 if kinked else 0.0), (k, t, out_v.mean())
+                well = (np.abs(info["grads"][k]) * coef > 1e-6) & ~out_m
+                # 2 % of one Adam step; a kinked sample may push a few small-gradient elements further
+                # (the step is lr * g / |g|-like): at most 0.1 % of a tensor, none beyond 20 % of a step
+                err = np.abs(np.where(well, got_p[k].astype(np.float64) - params[k], 0))
+                bound = 1e-4 * np.abs(params[k]) + 0.02 * lr
+                assert (err > bound).mean() <= (1e-3 if kinked else 0.0) and err.max() <= 0.2 * lr, \
+                    (k, t, float((err > bound).mean()), float(err.max()))
+            params[k][...], state["m/" + k][...], state["v/" + k][...] = got_p[k], gm, gv
+        for k in params:
+            if "running_" in k:
+                params[k][...] = got_p[k]
     assert n_checked > 2 * S * B * 0.95
-    # ---- dense parameters
-    got = {k: npy(v) for k, v in model.state_dict().items()}
-    for k, want in params.items():
-        if "embeddings.C" in k or "running_" in k:
-            continue
-        if k.startswith("dnn.mlp.") and k.endswith(".bias") and int(k.split(".")[2]) % 4 == 0:
-            continue                                # identically-zero gradient in front of BatchNorm
-        g_small = np.zeros(want.shape, bool)
-        if k in info["grads"]:
-            g_small = np.abs(info["grads"][k]) * float(info["coef"]) < 1e-6
-        assert_close(np.where(g_small, 0, got[k]), np.where(g_small, 0, want), rtol=1e-4, atol_scale=0.0,
-                     floor=0.05 * lr, what=k)
+
+    # ---- untouched rows: bit-unchanged records (weights AND moments), all 26 x 10^6 of them
+    for n in names:
+        buf = model.embedding.packed[n]["buffer"]
+        changed = (buf != before[n]).any(dim=1).nonzero().view(-1)
+        assert np.array_equal(npy(changed), uniq[n]), f"{n}: rows changed that the batches did not touch (or vice versa)"

@@ -1,25 +1,34 @@
 #!/usr/bin/env python3
 """Group a rocprofv3 --kernel-trace CSV by (kernel name, grid size): calls, avg / min / median us.
-usage: tools/ktrace_groups.py <dir-or-kernel_trace.csv> [name-filter]"""
+usage: tools/ktrace_groups.py <dir-or-kernel_trace.csv> [name-filter] [--runs]
+--runs: one group per RUN of consecutive dispatches of the same (kernel, grid) in time order (the same
+kernel timed in several contexts, separated by any other kernel, gives several lines)."""
 import csv
 import glob
 import os
 import statistics
 import sys
 
-path = sys.argv[1]
-flt = sys.argv[2] if len(sys.argv) > 2 else ""
+runs = "--runs" in sys.argv
+argv = [a for a in sys.argv if a != "--runs"]
+path = argv[1]
+flt = argv[2] if len(argv) > 2 else ""
 if os.path.isdir(path):
     path = sorted(glob.glob(os.path.join(path, "**", "*kernel_trace.csv"), recursive=True))[0]
 groups = {}
 order = []
-for r in csv.DictReader(open(path)):
+rows = sorted(csv.DictReader(open(path)), key=lambda r: int(r["Start_Timestamp"]))
+run_id, last = 0, None
+for r in rows:
     name = r["Kernel_Name"]
+    ident = (name, r.get("Grid_Size_X", r.get("Grid_Size", 0)))
+    if ident != last:
+        run_id, last = run_id + 1, ident
     if flt and flt not in name:
         continue
     grid = int(r.get("Grid_Size_X", r.get("Grid_Size", 0)) or 0)
     wg = int(r.get("Workgroup_Size_X", r.get("Workgroup_Size", 0)) or 0)
-    key = (name, grid, wg)
+    key = (name, grid, wg, run_id if runs else 0)
     if key not in groups:
         groups[key] = []
         order.append(key)
