@@ -9,9 +9,12 @@ embed_dim 16), batch 4096 per GPU, data-parallel over N GPUs of one node.
 A step = one pass of the hot path over one batch already resident in HBM:
 fused embedding gather -> FM + DNN forward -> BCE(+L2) -> backward -> row gradients ->
 (DP exchange) -> clip + row-wise Adam on touched rows + dense Adam.
-Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
+Rank 0 prints ONE JSON line (contract in the task statement) with extra objects:
 `roofline` for the embedding gather kernel (HIP events around every launch of it inside
-the timed region) and `cpu_baseline` (the numpy oracle's same step on the host cores).
+the timed region), `cpu_baseline` (the numpy oracle's same step on the host cores) and, at
+N = 1, `extra_configs`: BASELINE.json configurations 3 (xDeepFM, CIN [128,128,128]) and 4
+(AttentionDeepFM, embed_dim 32, 4 heads) timed the same way after the headline, each with the
+roofline of its own dominant layer (CIN: algorithmic TFLOP/s against the dense bf16 MFMA peak).
 """
 
 from __future__ import annotations
@@ -30,6 +33,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_ACHIEVABLE_GBS = 6300.0   # same guide: what a streaming kernel reaches
+BF16_MFMA_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA peak (never the 2:1-sparsity figure)
 
 
 def parse():
@@ -47,6 +52,9 @@ def parse():
                     help="do not attach HIP events to the gather dispatches (roofline fields become null)")
     ap.add_argument("--unpacked", action="store_true", help="keep the tables as separate contiguous tensors")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-extra-configs", action="store_true",
+                    help="skip BASELINE.json configurations 3 and 4 (xDeepFM / AttentionDeepFM) after the headline")
+    ap.add_argument("--extra-steps", type=int, default=60, help="timed steps of each extra configuration")
     ap.add_argument("--gather-shape", type=int, default=0,
                     help="tuning aid: force a launch shape of the gather (dfm_gather_set_shape); 0 = automatic")
     ap.add_argument("--h2d", action="store_true",
@@ -111,6 +119,127 @@ def cpu_baseline(model, fields, cfg, hp, ids, dense, labels, seconds):
             "host_cpus": os.cpu_count()}
 
 
+def build_step(name, V, D, B, dev, args, cin_sizes=None):
+    """Model of BASELINE.json's shape + row-sparse optimizer + the fastest step class that takes it."""
+    from deepfm_amd.config import ExperimentConfig
+    from deepfm_amd.models import create_model
+    from deepfm_amd.training.fused_step import FusedDeepFMStep
+    from deepfm_amd.training.rowsparse import RowSparseAdam
+    from deepfm_amd.training.step import RowSparseTrainStep
+    from tests.helpers import schema_from_fields
+    from tools_shared import criteo_fields
+    fields = criteo_fields(V, D)
+    cfg = ExperimentConfig()
+    cfg.feature.fm_embed_dim = D
+    if cin_sizes:
+        cfg.cin.layer_sizes = list(cin_sizes)
+    torch.manual_seed(0)                      # identical replicas on every rank
+    with torch.device(dev):
+        model = create_model(name, schema_from_fields(fields), cfg)
+    model.train()
+    if not args.unpacked:
+        model.embedding.pack_tables_()        # 256-B row records: [w2 | w1 m1 v1 | m2 | v2]
+    model.embedding.set_grad_mode("rowsparse")
+    hp = dict(lr=cfg.training.lr, l2=cfg.feature.embedding_l2_reg, max_grad_norm=cfg.training.gradient_clip_norm)
+    opt = RowSparseAdam(model, lr=hp["lr"], l2=hp["l2"], max_grad_norm=hp["max_grad_norm"])
+    fused = FusedDeepFMStep.eligible(model) and not args.autograd
+    step = (FusedDeepFMStep if fused else RowSparseTrainStep)(model, opt, B, use_graph=not args.no_graph)
+    return model, opt, step, fields, cfg, hp, fused
+
+
+def event_ms(fn, iters, warm=3):
+    """Average duration of fn() from HIP events on the current stream (one pair around each call)."""
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    pairs = []
+    for _ in range(iters):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        pairs.append((a, b))
+    torch.cuda.synchronize()
+    ts = [a.elapsed_time(b) for a, b in pairs]
+    return sum(ts) / len(ts), min(ts)
+
+
+def extra_config(name, args, dev, lib):
+    """One of BASELINE.json's configurations 3 / 4 on one GPU: the same timed loop as the headline
+    (batches resident in HBM, packed records, HIP graph), then the roofline of the model's own
+    interaction layer from HIP events around isolated launches of it at the same shapes."""
+    B, V = args.batch, args.vocab
+    D = 32 if name == "attention_deepfm" else 16
+    cin_sizes = [128, 128, 128] if name == "xdeepfm" else None
+    model, opt, step, fields, cfg, hp, fused = build_step(name, V, D, B, dev, args, cin_sizes)
+    n_sparse, n_dense = 26, 13
+    warm, steps = 10, args.extra_steps
+    ids, dense, labels = make_pool(warm + steps, n_sparse, n_dense, B, V, 101, dev)     # every batch used once
+    records = step.pack_batches(ids, dense, labels)
+    step.load_packed(records[0])
+    step.capture()
+    for i in range(warm):
+        step.run_from(records[i])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(warm, warm + steps):
+        step.run_from(records[i])
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    out = {
+        "workload": (f"{'xDeepFM' if name == 'xdeepfm' else 'AttentionDeepFM'} synthetic Criteo-shape: {n_sparse} sparse x {V} "
+                     f"vocab, {n_dense} dense, embed_dim {D}, batch {B}"
+                     + (f", cin.layer_sizes={cin_sizes}" if cin_sizes else f", attention.num_heads={cfg.attention.num_heads}")),
+        "ms_per_step": el / steps * 1e3, "samples_per_s": steps * B / el, "steps": steps, "warmup": warm,
+        "step": type(step).__name__, "hip_graph": not args.no_graph, "final_loss": float(step.loss.item()),
+    }
+    # ---- the interaction layer alone, at the step's shapes, on this stream
+    fe = step.fe.detach().clone().requires_grad_()
+    if name == "xdeepfm":
+        layer = model.cin
+        flops_f = 2.0 * D * sum(c * h * 39 for c, h in zip(layer.layer_sizes, [39] + list(layer.next_sizes[:-1]))) * B
+        flops_b = 2.0 * flops_f
+    else:
+        layer = model.attention
+    g = torch.randn_like(layer(fe).detach())
+
+    def fwd():
+        with torch.no_grad():
+            layer(fe)
+
+    def fwd_bwd():
+        fe.grad = None
+        layer(fe).backward(g)
+    f_ms, f_min = event_ms(fwd, 20)
+    t_ms, t_min = event_ms(fwd_bwd, 20)
+    if name == "xdeepfm":
+        out["roofline"] = {
+            "kernel": "cin_fwd_mfma (whole stack, one launch) / + cin_dgrad_mfma + cin_wgrad_mfma x3 (fwd+bwd)",
+            "bound": "mfma", "unit": "TFLOP/s", "peak": BF16_MFMA_PEAK_TFLOPS,
+            "mode": {0: "bf16x3 split (parity: 1e-4)", 1: "plain bf16", 2: "fp32 VALU"}[lib.dfm_cin_get_mode()],
+            "algorithmic_flops_fwd": flops_f, "algorithmic_flops_fwd_bwd": flops_f + flops_b,
+            "fwd_ms": f_ms, "fwd_ms_min": f_min, "fwd_bwd_ms": t_ms, "fwd_bwd_ms_min": t_min,
+            "achieved_fwd": flops_f / (f_ms * 1e-3) / 1e12, "frac_fwd": flops_f / (f_ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS,
+            "achieved": (flops_f + flops_b) / (t_ms * 1e-3) / 1e12,
+            "frac": (flops_f + flops_b) / (t_ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS,
+            "issued_over_algorithmic": 3.0 if lib.dfm_cin_get_mode() == 0 else 1.0,
+            "timer": "HIP events around 20 isolated launches of the layer (forward: repack + 1 kernel) at the step's shapes",
+        }
+    else:
+        io_bytes = 2.0 * 39 * D * 4 * B           # SURVEY.md 8d: x in + out per sample
+        out["roofline"] = {
+            "kernel": "field self-attention block (QKV GEMM, attn_core_fwd, out GEMM, LayerNorm; + backward)",
+            "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+            "algorithmic_bytes_fwd": io_bytes, "fwd_ms": f_ms, "fwd_ms_min": f_min, "fwd_bwd_ms": t_ms,
+            "fwd_bwd_ms_min": t_min, "achieved": io_bytes / (f_ms * 1e-3) / 1e9,
+            "frac": io_bytes / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "timer": "HIP events around 20 isolated launches of the layer at the step's shapes",
+        }
+    del step, opt, model, records, ids, dense, labels, fe, g
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -136,30 +265,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29577")
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
 
-    from deepfm_amd.config import ExperimentConfig
-    from deepfm_amd.models import create_model
-    from deepfm_amd.training.rowsparse import RowSparseAdam
-    from deepfm_amd.training.step import RowSparseTrainStep
-    from tests.helpers import schema_from_fields
-    from tools_shared import criteo_fields
-
     B, V, D = args.batch, args.vocab, args.dim
-    fields = criteo_fields(V, D)
     n_sparse, n_dense = 26, 13
-    cfg = ExperimentConfig()
-    cfg.feature.fm_embed_dim = D
-    torch.manual_seed(0)                      # identical replicas on every rank
-    with torch.device(dev):
-        model = create_model("deepfm", schema_from_fields(fields), cfg)
-    model.train()
-    if not args.unpacked:
-        model.embedding.pack_tables_()        # 256-B row records: [w2 | w1 m1 v1 | m2 | v2]
-    model.embedding.set_grad_mode("rowsparse")
-    hp = dict(lr=cfg.training.lr, l2=cfg.feature.embedding_l2_reg, max_grad_norm=cfg.training.gradient_clip_norm)
-    opt = RowSparseAdam(model, lr=hp["lr"], l2=hp["l2"], max_grad_norm=hp["max_grad_norm"])
-    from deepfm_amd.training.fused_step import FusedDeepFMStep
-    fused = FusedDeepFMStep.eligible(model) and not args.autograd
-    step = (FusedDeepFMStep if fused else RowSparseTrainStep)(model, opt, B, use_graph=not args.no_graph)
+    switches = {k: v for k, v in os.environ.items() if k.startswith("DFM_") or k.startswith("DEEPFM_AMD_")}
+    model, opt, step, fields, cfg, hp, fused = build_step("deepfm", V, D, B, dev, args)
 
     total = args.steps + args.warmup
     ids, dense, labels = make_pool(total, n_sparse, n_dense, B, V, 1 + rank, dev)
@@ -216,7 +325,7 @@ def main():
     achieved = algo_bytes / gather_avg_s / 1e9 if gather_us else None
 
     pmc = None
-    pmc_path = os.path.join(ROOT, "profiles", "r01_gather_pmc.json")
+    pmc_path = os.path.join(ROOT, "profiles", "r02_gather_pmc.json")
     if os.path.exists(pmc_path) and B == 4096 and V == 1_000_000 and D == 16:
         with open(pmc_path) as fh:
             pmc = json.load(fh)
@@ -248,13 +357,16 @@ def main():
                 "final_loss": loss,
             },
             "roofline": {
-                "kernel": f"emb_fwd_uniform<{D},8> (fused gather of all {n_sparse + n_dense} fields)",
+                "kernel": f"emb_fwd_pair<{D},{n_sparse},{n_dense}> (fused gather of all {n_sparse + n_dense} fields, staged inputs)",
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS if achieved else None,
-                "traffic": pmc["traffic_bytes_per_launch"] if pmc else None,
+                "frac_of_achievable_6p3": achieved / HBM_ACHIEVABLE_GBS if achieved else None,
+                # NOT measured in this run: PMC counters need their own rocprofv3 passes (see `rocprof`)
+                "traffic": None,
+                "traffic_from_profile": pmc["traffic_bytes_per_launch"] if pmc else None,
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "avg_launch_us": gather_avg_s * 1e6 if gather_us else None,
                 "min_launch_us": min(gather_us) if gather_us else None,
@@ -264,9 +376,15 @@ def main():
                 "rocprof": pmc,
             },
         }
+        out["config"]["env_switches"] = switches          # every DFM_* variable seen at run time
+        out["config"]["cin_mode"] = lib.dfm_cin_get_mode()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model, fields, cfg, hp, ids[:8], dense[:8], labels[:8],
                                                args.cpu_seconds)
+        if world == 1 and not args.no_extra_configs and not args.h2d:
+            del step, opt, model, records
+            torch.cuda.empty_cache()
+            out["extra_configs"] = [extra_config(n, args, dev, lib) for n in ("xdeepfm", "attention_deepfm")]
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()

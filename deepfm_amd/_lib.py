@@ -85,6 +85,8 @@ SIGNATURES = {
     "dfm_gather_timing_begin": (_I, [_I]),
     "dfm_gather_timing_end": (_I, [C.POINTER(C.c_float), _I, C.POINTER(_I)]),
     "dfm_gather_set_shape": (_I, [_I]),
+    "dfm_cin_set_mode": (_I, [_I]),
+    "dfm_cin_get_mode": (_I, []),
     "dfm_embedding_backward_dense": (_I, [_P, C.POINTER(_P), _L, _P, _P, _P, C.POINTER(FieldGrad), _P, _P]),
     "dfm_embedding_backward_dense_fields": (_I, [_P, C.POINTER(_P), _L, _P, _P, _P, C.POINTER(FieldGrad), _P]),
     "dfm_rowplan_build": (_I, [C.POINTER(_P), C.POINTER(C.c_int32), _I, _L, _P, _P, _P, _P, _P, _P]),

@@ -69,18 +69,12 @@ int cin_mfma_forward(const CinMfmaArgs& args, int D, bool split, hipStream_t st)
 }  // namespace dfm
 
 namespace {
-// DFM_CIN_MODE: "split" (default: bf16 x 3, parity grade), "bf16" (plain bf16 MFMA, throughput
-// mode with its own tolerance), "fp32" (general exact kernels only)
-int cin_mode() {
-  static int mode = [] {
-    const char* e = getenv("DFM_CIN_MODE");
-    if (!e) return 0;
-    if (!strcmp(e, "bf16")) return 1;
-    if (!strcmp(e, "fp32")) return 2;
-    return 0;
-  }();
-  return mode;
-}
+// arithmetic of the MFMA path, set by dfm_cin_set_mode: 0 = bf16 x 3 split (default, parity grade:
+// 1e-4), 1 = plain bf16 MFMA (throughput mode with its own, looser tolerance), 2 = general exact-fp32
+// kernels only.  An explicit API call, not an environment variable: nothing outside the caller's
+// code can change what a training run computes.
+int g_cin_mode = 0;
+int cin_mode() { return g_cin_mode; }
 
 struct Layout {
   int L = 0, F = 0, D = 0, out_dim = 0;
@@ -125,6 +119,13 @@ int make_layout(const int32_t* sizes, int L, int split_half, int F, int D, int64
 }
 constexpr int kWgradSlices = 8;
 }  // namespace
+
+extern "C" int dfm_cin_set_mode(int mode) {
+  DFM_REQUIRE(mode >= 0 && mode <= 2, "CIN mode %d outside [0, 2]", mode);
+  g_cin_mode = mode;
+  return DFM_OK;
+}
+extern "C" int dfm_cin_get_mode(void) { return g_cin_mode; }
 
 extern "C" int dfm_cin_output_dim(const int32_t* layer_sizes, int num_layers, int split_half) {
   Layout lo;
@@ -198,7 +199,6 @@ extern "C" int dfm_cin_forward(const float* d_x0, int64_t batch, int num_fields,
     memset(&args, 0, sizeof(args));
     args.x0 = d_x0; args.out = d_out; args.B = batch; args.F = num_fields; args.L = lo.L;
     args.out_dim = lo.out_dim;
-    { const char* e = getenv("DFM_CIN_ABLATE"); args.ablate = e ? atoi(e) : 0; }
     bf16_t* hi = static_cast<bf16_t*>(d_workspace);
     bf16_t* lop = hi + ((packed_total_elems(lo) + 63) / 64) * 64;
     size_t off = 0;

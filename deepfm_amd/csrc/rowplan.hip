@@ -266,7 +266,12 @@ __global__ __launch_bounds__(256) void rowgrad_kernel(
 }
 
 // timing-only ablation (0 in every product call): 1 = skip the sort, 2 = skip the run-head / output phase
-static int g_rp_ablate = [] { const char* e = getenv("DFM_ROWPLAN_ABLATE"); return e ? atoi(e) : 0; }();
+// timing-only ablation of the sort (tools/rp_ablate.sh): exists only in a -DDFM_TUNING_ABLATE=<mask> build,
+// never in the shipped library
+#ifndef DFM_TUNING_ABLATE
+#define DFM_TUNING_ABLATE 0
+#endif
+static constexpr int g_rp_ablate = DFM_TUNING_ABLATE;
 
 extern "C" {
 

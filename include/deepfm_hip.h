@@ -235,6 +235,13 @@ int dfm_fm_forward(const float* d_field_emb, int64_t batch, int num_fields, int 
 int dfm_fm_backward(const float* d_field_emb, const float* d_g_out, int64_t batch, int num_fields,
                     int dim, float* d_g_field, dfm_stream_t stream);
 
+/* Arithmetic of the matrix-core CIN path: 0 = bf16 x 3 split products (default; meets the 1e-4 bar
+ * against cin.py:66-105), 1 = plain bf16 (throughput mode, its own looser tolerance), 2 = exact-fp32
+ * VALU kernels only.  Process-wide; bench.py records it and refuses to report headline numbers in a
+ * non-default mode. */
+int dfm_cin_set_mode(int mode);
+int dfm_cin_get_mode(void);
+
 /* ---------------------------------------------------------------------------------
  * CIN  (reference deepfm/models/layers/cin.py:26-105)
  *   per layer i:  Z[b,h*F+f,d] = hidden_i[b,h,d] * x0[b,f,d]          (cin.py:84-87, never stored)

@@ -38,6 +38,58 @@ def test_attention_vs_golden(case):
         assert_close(npy(p.grad), g["grad/" + k], what=k, floor=2e-5 if k.endswith("W_k.bias") else 0.0)
 
 
+@pytest.mark.parametrize("case", CASES)
+def test_per_sample_lds_kernel_vs_golden(case):
+    """csrc/attention.hip (one fused LDS kernel per sample: the path for F > 64 or a head_dim outside
+    {4, 8, 16, 32}) forced on the golden shapes with ``gemm_path = False``."""
+    g = load(case)
+    att = _module(g)
+    for block in att.layers:
+        block.gemm_path = False
+    x = torch.from_numpy(g["x"]).cuda().requires_grad_()
+    out = att(x)
+    assert_close(npy(out), g["out"], what="attn out")
+    (out * torch.from_numpy(g["upstream"]).cuda()).sum().backward()
+    assert_close(npy(x.grad), g["d_x"], what="attn d_x")
+    for k, p in att.named_parameters():
+        assert_close(npy(p.grad), g["grad/" + k], what=k, floor=2e-5 if k.endswith("W_k.bias") else 0.0)
+
+
+@pytest.mark.parametrize("shape", [
+    dict(B=33, F=39, D=32, heads=1, A=64, layers=1, residual=True),     # head_dim 64
+    dict(B=17, F=5, D=8, heads=4, A=8, layers=2, residual=True),        # head_dim 2
+    dict(B=9, F=70, D=8, heads=2, A=16, layers=1, residual=False),      # F > 64
+    dict(B=12, F=11, D=10, heads=3, A=36, layers=1, residual=True),     # head_dim 12, embed_dim % 4 != 0
+])
+def test_shapes_the_core_kernel_rejects_vs_oracle(shape):
+    """Reference-valid configurations (attention.py:26-50 accepts any head_dim / field count) that
+    ``dfm_attention_core_supported`` turns down run on csrc/attention.hip: forward and every gradient
+    against the oracle (itself pinned by the attention goldens)."""
+    from deepfm_amd import _lib
+    from deepfm_amd.models.layers.attention import MultiHeadSelfAttention
+    c = shape
+    torch.manual_seed(c["F"])
+    att = MultiHeadSelfAttention(c["D"], c["heads"], c["A"], c["layers"], c["residual"]).cuda()
+    core = _lib.load().dfm_attention_core_supported(c["F"], c["A"], c["heads"])
+    assert not (core and c["D"] % 4 == 0 and c["A"] % 4 == 0 and c["D"] <= 64), "shape would take the GEMM + core path"
+    with torch.no_grad():
+        for p in att.parameters():
+            p.uniform_(-0.4, 0.4)
+    params = {k: npy(v) for k, v in att.state_dict().items()}
+    rng = np.random.default_rng(c["B"])
+    x = rng.standard_normal((c["B"], c["F"], c["D"])).astype(np.float32)
+    up = rng.standard_normal(x.shape).astype(np.float32)
+    t = torch.from_numpy(x).cuda().requires_grad_()
+    out = att(t)
+    (out * torch.from_numpy(up).cuda()).sum().backward()
+    assert_close(npy(out), O.attention_forward(x, params, c["heads"], c["layers"], c["residual"]), what="out")
+    d_x, grads = O.attention_backward(x, params, c["heads"], c["layers"], c["residual"], up)
+    assert_close(npy(t.grad), d_x, what="d_x")
+    for k, p in att.named_parameters():
+        # W_k.bias: softmax-invariant (exact-zero gradient); a final LayerNorm-free block has none either
+        assert_close(npy(p.grad), grads[k], what=k, floor=1e-4 if k.endswith("W_k.bias") else 0.0)
+
+
 def test_indivisible_heads_raise():
     from deepfm_amd.models.layers.attention import MultiHeadSelfAttention
     with pytest.raises(ValueError):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Time the CIN / attention layers at the BASELINE.json config-3/4 shapes (B=4096) on the GPU.
-usage: python tools/time_layers.py [cin|attn] [iters]   (DFM_CIN_MODE=split|bf16|fp32 picks the CIN path)"""
+usage: python tools/time_layers.py [cin|attn] [iters] [split|bf16|fp32]   (third argument: CIN arithmetic, dfm_cin_set_mode)"""
 import os
 import sys
 import time
@@ -25,6 +25,9 @@ def main():
     what = sys.argv[1] if len(sys.argv) > 1 else "cin"
     iters = int(sys.argv[2]) if len(sys.argv) > 2 else 10
     B = int(os.environ.get("B", 4096))
+    mode = sys.argv[3] if len(sys.argv) > 3 else "split"
+    from deepfm_amd import _lib
+    _lib.check(_lib.load().dfm_cin_set_mode({"split": 0, "bf16": 1, "fp32": 2}[mode]))
     torch.manual_seed(0)
     if what == "cin":
         from deepfm_amd.models.layers.cin import CIN
@@ -43,7 +46,7 @@ def main():
         out = layer(x)
         out.sum().backward()
     t = bench(fb, max(iters // 2, 2))
-    print(f"{what} mode={os.environ.get('DFM_CIN_MODE', 'split')} B={B}: fwd {f:.3f} ms ({flops_f / f / 1e9:.1f} TFLOP/s alg), "
+    print(f"{what} mode={mode} B={B}: fwd {f:.3f} ms ({flops_f / f / 1e9:.1f} TFLOP/s alg), "
           f"fwd+bwd {t:.3f} ms ({(flops_f + flops_b) / t / 1e9:.1f} TFLOP/s alg)")
 
 

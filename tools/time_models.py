@@ -51,7 +51,7 @@ def run(name, dim, steps, B=4096, V=1_000_000):
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / steps * 1e3
     print(f"{name:18s} embed_dim {dim:2d}: {ms:7.3f} ms/step  {B / ms * 1e3 / 1e6:6.2f} M samples/s  "
-          f"({cls.__name__}, loss {float(step.loss):.4f}, CIN mode {os.environ.get('DFM_CIN_MODE', 'split')})", flush=True)
+          f"({cls.__name__}, loss {float(step.loss):.4f})", flush=True)
     del step, opt, model
     torch.cuda.empty_cache()
 
