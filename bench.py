@@ -55,6 +55,8 @@ def parse():
     ap.add_argument("--no-extra-configs", action="store_true",
                     help="skip BASELINE.json configurations 3 and 4 (xDeepFM / AttentionDeepFM) after the headline")
     ap.add_argument("--extra-steps", type=int, default=60, help="timed steps of each extra configuration")
+    ap.add_argument("--timing-stride", type=int, default=8,
+                    help="the gather is timed (eagerly launched, events on the dispatch) on every n-th step of the timed region")
     ap.add_argument("--gather-shape", type=int, default=0,
                     help="tuning aid: force a launch shape of the gather (dfm_gather_set_shape); 0 = automatic")
     ap.add_argument("--h2d", action="store_true",
@@ -265,6 +267,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29577")
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
 
+    import ctypes as C
+    from deepfm_amd import _lib
+    lib = _lib.load()
+    _lib.check(lib.dfm_gather_set_shape(args.gather_shape))        # before any capture: the graphs keep the kernel
     B, V, D = args.batch, args.vocab, args.dim
     n_sparse, n_dense = 26, 13
     switches = {k: v for k, v in os.environ.items() if k.startswith("DFM_") or k.startswith("DEEPFM_AMD_")}
@@ -274,7 +280,7 @@ def main():
     ids, dense, labels = make_pool(total, n_sparse, n_dense, B, V, 1 + rank, dev)
     records = step.pack_batches(ids, dense, labels)      # one record per batch, resident in HBM
     step.load_packed(records[0])
-    step.capture()
+    step.capture(timed_variant=True)
 
     feed = None
     if args.h2d:
@@ -288,23 +294,26 @@ def main():
 
     def run(i, timed):
         # the gather reads batch i from its record and refreshes the step's static inputs on the way
-        step.run_from(next(feed) if feed is not None else records[i])
+        step.run_from(next(feed) if feed is not None else records[i], eager_gather=timed and not args.no_graph)
 
-    import ctypes as C
-    from deepfm_amd import _lib
-    lib = _lib.load()
-    _lib.check(lib.dfm_gather_set_shape(args.gather_shape))
     for i in range(args.warmup):
         run(i, False)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    # every gather launch of the timed region carries HIP start/stop events around the dispatch
-    if not args.no_gather_timing:
-        _lib.check(lib.dfm_gather_timing_begin(args.steps))
+    # The gather runs inside the step's graph.  Every `stride`-th step of the timed region launches it eagerly
+    # instead, in front of a gather-less copy of the graph, with HIP start/stop events attached to the
+    # dispatch (hipExtLaunchKernel): the same kernel, arguments and position in the step, timed like
+    # rocprofv3's kernel trace times it.  (--no-graph: every step is eager and timed.)
+    timing = not args.no_gather_timing
+    stride = 1 if args.no_graph else args.timing_stride
+    timed_steps = [i for i in range(args.warmup, total) if timing and (i - args.warmup) % stride == 0]
+    if timed_steps:
+        _lib.check(lib.dfm_gather_timing_begin(len(timed_steps)))
+    timed_set = set(timed_steps)
     t0 = time.perf_counter()
     for i in range(args.warmup, total):
-        run(i, False)
+        run(i, i in timed_set)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -315,10 +324,10 @@ def main():
         elapsed = float(t.item())
     loss = float(step.loss.item())
 
-    us = (C.c_float * args.steps)()
+    us = (C.c_float * max(len(timed_steps), 1))()
     n_timed = C.c_int(0)
-    if not args.no_gather_timing:
-        _lib.check(lib.dfm_gather_timing_end(us, args.steps, C.byref(n_timed)))
+    if timed_steps:
+        _lib.check(lib.dfm_gather_timing_end(us, len(timed_steps), C.byref(n_timed)))
     gather_us = [float(us[i]) for i in range(n_timed.value)]
     gather_avg_s = (sum(gather_us) / len(gather_us)) * 1e-6 if gather_us else float("nan")
     algo_bytes = gather_bytes_per_sample(n_sparse, n_dense, D) * B
@@ -371,8 +380,9 @@ def main():
                 "avg_launch_us": gather_avg_s * 1e6 if gather_us else None,
                 "min_launch_us": min(gather_us) if gather_us else None,
                 "launches_timed": len(gather_us),
-                "timer": "HIP start/stop events attached to every gather dispatch of the timed region "
-                         "(hipExtLaunchKernelGGL, on the launch stream)",
+                "timer": f"HIP start/stop events attached to the gather dispatch (hipExtLaunchKernel, on the launch stream) on "
+                         f"every {stride}-th step of the timed region; on those steps the gather is launched eagerly in front of "
+                         "a gather-less copy of the step's graph, on all others it is a node of the graph",
                 "rocprof": pmc,
             },
         }

@@ -82,6 +82,8 @@ SIGNATURES = {
     "dfm_embedding_workspace_bytes": (_SZ, [_P, _L]),
     "dfm_embedding_forward": (_I, [_P, C.POINTER(_P), _L, _P, _P, _P, _P, _P, _P, _P, _P]),
     "dfm_embedding_forward_staged": (_I, [_P, C.POINTER(_P), C.POINTER(_P), _P, _P, _L, _P, _P, _P, _P, _P, _P]),
+    "dfm_embedding_forward_staged_update": (_I, [_P, _P, _P, C.POINTER(_P), C.POINTER(_P), _P, _P, _L, _P, _P, _P, _P, _P]),
+    "dfm_graph_last_node": (_I, [_P, C.POINTER(_P)]),
     "dfm_gather_timing_begin": (_I, [_I]),
     "dfm_gather_timing_end": (_I, [C.POINTER(C.c_float), _I, C.POINTER(_I)]),
     "dfm_gather_set_shape": (_I, [_I]),

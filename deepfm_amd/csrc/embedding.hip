@@ -656,72 +656,104 @@ extern "C" int dfm_gather_set_shape(int shape) {
   return DFM_OK;
 }
 
-template <int D>
-static int launch_uniform(const dfm_embedding_plan* plan, const PtrTable& in, int64_t B,
-                          float* fo, float* fe, float* fm_out, float* fm_sum, int32_t* err, hipStream_t st,
-                          void* const* stage_out = nullptr, const float* extra_src = nullptr,
-                          float* extra_dst = nullptr) {
-  constexpr int SPW = kWave / (D / 4);
+// One gather launch, fully described: the kernel, its geometry and its argument values.  The same
+// description either goes to the stream (optionally with start/stop events attached to the dispatch) or
+// rewrites the kernel node of an instantiated graph (dfm_embedding_forward_staged_update).
+struct GatherLaunch {
+  const void* func = nullptr;
+  dim3 grid, block;
   UniformArgs args;
-  memset(&args, 0, sizeof(args));
+  int ns = 0, nd = 0, F = 0;
+  int64_t B = 0;
+  float *fo = nullptr, *fe = nullptr, *fm_out = nullptr, *fm_sum = nullptr;
+  int32_t* err = nullptr;
+  const float* extra_src = nullptr;
+  float* extra_dst = nullptr;
+  bool pair = false;
+  void* params[12];
+  void bind() {
+    int n = 0;
+    params[n++] = &args;
+    if (!pair) { params[n++] = &ns; params[n++] = &nd; }
+    params[n++] = &B; params[n++] = &F; params[n++] = &fo; params[n++] = &fe; params[n++] = &fm_out;
+    params[n++] = &fm_sum; params[n++] = &err; params[n++] = &extra_src; params[n++] = &extra_dst;
+  }
+};
+
+template <int D>
+static int describe_uniform(const dfm_embedding_plan* plan, const PtrTable& in, int64_t B,
+                            float* fo, float* fe, float* fm_out, float* fm_sum, int32_t* err,
+                            void* const* stage_out, const float* extra_src, float* extra_dst, GatherLaunch* g) {
+  constexpr int SPW = kWave / (D / 4);
+  memset(&g->args, 0, sizeof(g->args));
   const int ns = static_cast<int>(plan->h_sparse.size()), nd = static_cast<int>(plan->h_dense.size());
   for (int i = 0; i < ns; ++i) {
     const int f = plan->h_sparse[i];
     const dfm_field& fd = plan->h_fields[f];
-    args.sp[i] = SparseSlot{static_cast<const int64_t*>(in.p[f]), fd.w2, fd.w1, fd.vocab, f, fd.stride2, fd.stride1,
-                            stage_out ? static_cast<int64_t*>(stage_out[f]) : nullptr};
+    g->args.sp[i] = SparseSlot{static_cast<const int64_t*>(in.p[f]), fd.w2, fd.w1, fd.vocab, f, fd.stride2, fd.stride1,
+                               stage_out ? static_cast<int64_t*>(stage_out[f]) : nullptr};
   }
   for (int i = 0; i < nd; ++i) {
     const int f = plan->h_dense[i];
     const dfm_field& fd = plan->h_fields[f];
-    args.de[i] = DenseSlot{static_cast<const float*>(in.p[f]), fd.w2, fd.b2, fd.w1, fd.b1, f, 0,
-                           stage_out ? static_cast<float*>(stage_out[f]) : nullptr};
+    g->args.de[i] = DenseSlot{static_cast<const float*>(in.p[f]), fd.w2, fd.b2, fd.w1, fd.b1, f, 0,
+                              stage_out ? static_cast<float*>(stage_out[f]) : nullptr};
   }
-  const dim3 grid(static_cast<unsigned>((B + SPW - 1) / SPW));
-  const int F = plan->num_fields;
+  g->ns = ns; g->nd = nd; g->B = B; g->F = plan->num_fields;
+  g->fo = fo; g->fe = fe; g->fm_out = fm_out; g->fm_sum = fm_sum; g->err = err;
+  g->extra_src = extra_src; g->extra_dst = extra_dst;
+  g->grid = dim3(static_cast<unsigned>((B + SPW - 1) / SPW));
+  int shape = g_gather_shape;
+  // automatic: the exact-count two-wave kernel for the Criteo field counts (D = 16 / 32), else 8 waves
+  const bool pair_ok = (D == 16 || D == 32) && ns == 26 && nd == 13;
+  if (shape == 0) shape = pair_ok ? 5 : 4;
+  if (shape == 5 && !pair_ok) shape = 4;
+  g->pair = shape == 5;
+#define DFM_UNIFORM_KERNEL(WV, US_, UD_)                                               \
+  do {                                                                                 \
+    g->func = reinterpret_cast<const void*>(&emb_fwd_uniform<D, WV, US_, UD_>);        \
+    g->block = dim3(WV * 64);                                                          \
+  } while (0)
+  switch (shape) {
+    case 1: DFM_UNIFORM_KERNEL(1, 26, 13); break;
+    case 2: DFM_UNIFORM_KERNEL(2, 13, 7); break;
+    case 3: DFM_UNIFORM_KERNEL(4, 8, 4); break;
+    case 5:
+      if constexpr (D == 16 || D == 32) {
+        g->func = stage_out ? reinterpret_cast<const void*>(&emb_fwd_pair<D, 26, 13, true>)
+                            : reinterpret_cast<const void*>(&emb_fwd_pair<D, 26, 13, false>);
+        g->block = dim3(128);
+      }
+      break;
+    default: DFM_UNIFORM_KERNEL(8, 4, 2);
+  }
+#undef DFM_UNIFORM_KERNEL
+  g->bind();
+  return DFM_OK;
+}
+
+static int describe_gather(const dfm_embedding_plan* plan, const PtrTable& in, int64_t B, float* fo, float* fe,
+                           float* fm_out, float* fm_sum, int32_t* err, void* const* stage_out,
+                           const float* extra_src, float* extra_dst, GatherLaunch* g) {
+#define DFM_DESCRIBE(DD) \
+  case DD: return describe_uniform<DD>(plan, in, B, fo, fe, fm_out, fm_sum, err, stage_out, extra_src, extra_dst, g)
+  switch (plan->fm_dim) {
+    DFM_DESCRIBE(4); DFM_DESCRIBE(8); DFM_DESCRIBE(16); DFM_DESCRIBE(32); DFM_DESCRIBE(64); DFM_DESCRIBE(128); DFM_DESCRIBE(256);
+    default: break;
+  }
+#undef DFM_DESCRIBE
+  return fail(DFM_ERR_UNSUPPORTED, "no uniform gather for fm_dim %d", plan->fm_dim);
+}
+
+static int launch_gather(GatherLaunch* g, hipStream_t st) {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   if (g_gather_timer.used < static_cast<int>(g_gather_timer.start.size())) {
     ev0 = g_gather_timer.start[g_gather_timer.used];
     ev1 = g_gather_timer.stop[g_gather_timer.used];
     ++g_gather_timer.used;
   }
-#define DFM_GATHER_LAUNCH(WV, US_, UD_)                                                                     \
-  do {                                                                                                      \
-    if (ev0)                                                                                                \
-      hipExtLaunchKernelGGL((emb_fwd_uniform<D, WV, US_, UD_>), grid, dim3(WV * 64), 0, st, ev0, ev1, 0,   \
-                            args, ns, nd, B, F, fo, fe, fm_out, fm_sum, err, extra_src, extra_dst);         \
-    else                                                                                                    \
-      hipLaunchKernelGGL((emb_fwd_uniform<D, WV, US_, UD_>), grid, dim3(WV * 64), 0, st, args, ns, nd, B,  \
-                         F, fo, fe, fm_out, fm_sum, err, extra_src, extra_dst);                             \
-  } while (0)
-#define DFM_PAIR_LAUNCH(NS_, ND_, STG)                                                                       \
-  do {                                                                                                      \
-    if (ev0)                                                                                                \
-      hipExtLaunchKernelGGL((emb_fwd_pair<D, NS_, ND_, STG>), grid, dim3(128), 0, st, ev0, ev1, 0, args,   \
-                            B, F, fo, fe, fm_out, fm_sum, err, extra_src, extra_dst);                       \
-    else                                                                                                    \
-      hipLaunchKernelGGL((emb_fwd_pair<D, NS_, ND_, STG>), grid, dim3(128), 0, st, args, B, F, fo, fe,     \
-                         fm_out, fm_sum, err, extra_src, extra_dst);                                        \
-  } while (0)
-  int shape = g_gather_shape;
-  // automatic: the exact-count two-wave kernel for the Criteo field counts (D = 16 / 32), else 8 waves
-  const bool pair_ok = (D == 16 || D == 32) && ns == 26 && nd == 13;
-  if (shape == 0) shape = pair_ok ? 5 : 4;
-  if (shape == 5 && !pair_ok) shape = 4;
-  switch (shape) {
-    case 1: DFM_GATHER_LAUNCH(1, 26, 13); break;
-    case 2: DFM_GATHER_LAUNCH(2, 13, 7); break;
-    case 3: DFM_GATHER_LAUNCH(4, 8, 4); break;
-    case 5:
-      if constexpr (D == 16 || D == 32) {
-        if (stage_out) DFM_PAIR_LAUNCH(26, 13, true); else DFM_PAIR_LAUNCH(26, 13, false);
-      }
-      break;
-    default: DFM_GATHER_LAUNCH(8, 4, 2);
-  }
-#undef DFM_PAIR_LAUNCH
-#undef DFM_GATHER_LAUNCH
-  DFM_LAUNCH_CHECK();
+  if (ev0) DFM_HIP_TRY(hipExtLaunchKernel(g->func, g->grid, g->block, g->params, 0, st, ev0, ev1, 0));
+  else     DFM_HIP_TRY(hipLaunchKernel(g->func, g->grid, g->block, g->params, 0, st));
   return DFM_OK;
 }
 
@@ -736,16 +768,10 @@ extern "C" int dfm_embedding_forward(const dfm_embedding_plan* plan, const void*
   if (int rc = fill_ptrs(plan, inputs, &in)) return rc;
   hipStream_t st = as_stream(stream);
   if (plan->uniform && (d_flat_emb == nullptr || d_flat_emb == d_field_emb)) {
-    switch (plan->fm_dim) {
-      case 4:   return launch_uniform<4>(plan, in, batch, d_first_order, d_field_emb, d_fm_out, d_fm_sum, d_error_flag, st);
-      case 8:   return launch_uniform<8>(plan, in, batch, d_first_order, d_field_emb, d_fm_out, d_fm_sum, d_error_flag, st);
-      case 16:  return launch_uniform<16>(plan, in, batch, d_first_order, d_field_emb, d_fm_out, d_fm_sum, d_error_flag, st);
-      case 32:  return launch_uniform<32>(plan, in, batch, d_first_order, d_field_emb, d_fm_out, d_fm_sum, d_error_flag, st);
-      case 64:  return launch_uniform<64>(plan, in, batch, d_first_order, d_field_emb, d_fm_out, d_fm_sum, d_error_flag, st);
-      case 128: return launch_uniform<128>(plan, in, batch, d_first_order, d_field_emb, d_fm_out, d_fm_sum, d_error_flag, st);
-      case 256: return launch_uniform<256>(plan, in, batch, d_first_order, d_field_emb, d_fm_out, d_fm_sum, d_error_flag, st);
-      default: break;
-    }
+    GatherLaunch g;
+    if (int rc = describe_gather(plan, in, batch, d_first_order, d_field_emb, d_fm_out, d_fm_sum, d_error_flag,
+                                 nullptr, nullptr, nullptr, &g)) return rc;
+    return launch_gather(&g, st);
   }
   DFM_REQUIRE(d_fm_out == nullptr && d_fm_sum == nullptr, "fused FM outputs need a uniform plan");
   DFM_REQUIRE(d_flat_emb && d_flat_emb != d_field_emb, "general plan needs a separate flat_embeddings buffer");
@@ -854,17 +880,40 @@ extern "C" int dfm_embedding_forward_staged(const dfm_embedding_plan* plan, cons
   if (int rc = fill_ptrs(plan, inputs, &in)) return rc;
   for (int f = 0; f < plan->num_fields; ++f)
     DFM_REQUIRE(stage_out[f] != nullptr && stage_out[f] != inputs[f], "stage_out[%d] must be a distinct buffer", f);
-  hipStream_t st = as_stream(stream);
-#define DFM_STAGED(DD)                                                                                          \
-  case DD:                                                                                                      \
-    return launch_uniform<DD>(plan, in, batch, d_first_order, d_field_emb, d_fm_out, d_fm_sum, d_error_flag, st, \
-                              stage_out, d_extra_src, d_extra_dst)
-  switch (plan->fm_dim) {
-    DFM_STAGED(4); DFM_STAGED(8); DFM_STAGED(16); DFM_STAGED(32); DFM_STAGED(64); DFM_STAGED(128); DFM_STAGED(256);
-    default: break;
-  }
-#undef DFM_STAGED
-  return fail(DFM_ERR_UNSUPPORTED, "no uniform gather for fm_dim %d", plan->fm_dim);
+  GatherLaunch g;
+  if (int rc = describe_gather(plan, in, batch, d_first_order, d_field_emb, d_fm_out, d_fm_sum, d_error_flag,
+                               stage_out, d_extra_src, d_extra_dst, &g)) return rc;
+  return launch_gather(&g, as_stream(stream));
+}
+
+// The staged gather was captured into a graph (dfm_graph_last_node right after the call returns its
+// node): point the node of the INSTANTIATED graph at another batch record / other buffers.  Host-side
+// only (hipGraphExecKernelNodeSetParams), nothing is enqueued; takes effect at the next launch of the
+// exec.  The caller must not update an exec whose previous launch may still be pending (the training
+// step alternates two execs for that reason).
+extern "C" int dfm_embedding_forward_staged_update(const dfm_embedding_plan* plan, void* graph_exec, void* node,
+                                                  const void* const* inputs, void* const* stage_out,
+                                                  const float* d_extra_src, float* d_extra_dst, int64_t batch,
+                                                  float* d_first_order, float* d_field_emb, float* d_fm_out,
+                                                  float* d_fm_sum, int32_t* d_error_flag) {
+  DFM_REQUIRE(plan && graph_exec && node && inputs && stage_out && d_first_order && d_field_emb, "null argument");
+  DFM_REQUIRE(plan->uniform, "staged gather needs a uniform plan");
+  DFM_REQUIRE(batch > 0 && batch < (int64_t(1) << 31), "batch %lld out of range", (long long)batch);
+  PtrTable in;
+  if (int rc = fill_ptrs(plan, inputs, &in)) return rc;
+  GatherLaunch g;
+  if (int rc = describe_gather(plan, in, batch, d_first_order, d_field_emb, d_fm_out, d_fm_sum, d_error_flag,
+                               stage_out, d_extra_src, d_extra_dst, &g)) return rc;
+  hipKernelNodeParams p;
+  memset(&p, 0, sizeof(p));
+  p.func = const_cast<void*>(g.func);
+  p.gridDim = g.grid;
+  p.blockDim = g.block;
+  p.sharedMemBytes = 0;
+  p.kernelParams = g.params;
+  p.extra = nullptr;
+  DFM_HIP_TRY(hipGraphExecKernelNodeSetParams(static_cast<hipGraphExec_t>(graph_exec), static_cast<hipGraphNode_t>(node), &p));
+  return DFM_OK;
 }
 
 extern "C" int dfm_gather_timing_begin(int launches) {

@@ -26,6 +26,23 @@ int dfm_debug_empty_launch(dfm_stream_t stream) {
   return DFM_OK;
 }
 
+// ---- graph plumbing -------------------------------------------------------------------------------
+// While `stream` is being captured: the node the next captured operation would depend on, i.e. the node
+// of the operation enqueued last (call it right after the launch whose node is wanted).
+int dfm_graph_last_node(dfm_stream_t stream, void** node_out) {
+  DFM_REQUIRE(node_out, "null argument");
+  hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
+  unsigned long long id = 0;
+  hipGraph_t graph = nullptr;
+  const hipGraphNode_t* deps = nullptr;
+  size_t n = 0;
+  DFM_HIP_TRY(hipStreamGetCaptureInfo_v2(dfm::as_stream(stream), &status, &id, &graph, &deps, &n));
+  DFM_REQUIRE(status == hipStreamCaptureStatusActive, "stream is not being captured");
+  DFM_REQUIRE(n == 1 && deps, "expected exactly one dependency node, found %zu", n);
+  *node_out = deps[0];
+  return DFM_OK;
+}
+
 int dfm_abi_version(void) { return DFM_ABI_VERSION; }
 
 const char* dfm_last_error(void) { return dfm::last_error_buf(); }

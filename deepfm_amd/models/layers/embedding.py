@@ -302,6 +302,20 @@ class FeatureEmbedding(nn.Module):
                 plan, src, self._ptr_array(stage_out), extra_src_ptr or None, _lib.ptr(extra_dst), B, fo.data_ptr(),
                 fe.data_ptr(), _lib.ptr(fm_out), _lib.ptr(fm_sum), self._err.data_ptr(), _lib.stream_handle()))
 
+    def forward_staged_update(self, graph_exec: int, node, src_ptrs: List[int], stage_out: List[torch.Tensor], B: int,
+                              fo: torch.Tensor, fe: torch.Tensor, fm_out: Optional[torch.Tensor] = None,
+                              fm_sum: Optional[torch.Tensor] = None, extra_src_ptr: int = 0,
+                              extra_dst: Optional[torch.Tensor] = None) -> None:
+        """``forward_staged`` was captured into a HIP graph: point its kernel node (``node`` from
+        ``dfm_graph_last_node``) inside the instantiated graph ``graph_exec`` at another batch record.
+        Host-side only; the exec must not have a launch pending."""
+        plan = self._ensure_plan(fe.device)
+        src = (C.c_void_p * len(src_ptrs))(*src_ptrs)
+        _lib.check(_lib.load().dfm_embedding_forward_staged_update(
+            plan, C.c_void_p(graph_exec), node, src, self._ptr_array(stage_out), extra_src_ptr or None,
+            _lib.ptr(extra_dst), B, fo.data_ptr(), fe.data_ptr(), _lib.ptr(fm_out), _lib.ptr(fm_sum),
+            self._err.data_ptr()))
+
     def _launch_forward(self, inputs: List[torch.Tensor], B: int, want_fm: bool = False):
         dev = inputs[0].device
         self._ensure_plan(dev)

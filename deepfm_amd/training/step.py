@@ -1,28 +1,53 @@
-"""One training step of a BaseCTRModel on the HIP path, optionally as a HIP graph.
+"""One training step of a BaseCTRModel on the HIP path, as ONE HIP graph per step.
 
 Step = the body of the reference's ``Trainer._train_epoch`` (trainer.py:212-240):
 forward -> BCEWithLogits (+ L2 term) -> backward -> clip -> Adam, with the embedding
 tables in row-sparse mode (``RowSparseAdam``).  Layout of one step on the stream:
 
-    [eager]  fused embedding gather (``dfm_embedding_forward``)  <- optionally bracketed by
-             HIP events so bench.py can time exactly this kernel in the timed region
-    [graph A] row plan (side stream), interaction layers + DNN forward, loss, backward, row gradients
-    [eager]  data-parallel exchange (RCCL all-reduce / all-gather), world_size > 1 only
-    [graph B] merge + clip + row-wise Adam + dense Adam
+    [graph A] fused embedding gather, reading the batch from its packed record and refreshing the
+              step's static inputs on the way (``dfm_embedding_forward_staged``); row plan,
+              interaction layers + DNN forward, loss, backward, row gradients;
+              one rank: merge + clip + row-wise Adam + dense Adam as well
+    [eager]   data-parallel exchange (RCCL all-gather), world_size > 1 only
+    [graph B] merge + clip + row-wise Adam + dense Adam, world_size > 1 only
 
-With one rank A and B are a single graph.  No host synchronisation inside a step.
+The batch changes every step and a graph's kernel arguments are frozen at capture, so the gather's
+kernel NODE is re-pointed at the next batch record from the host before every launch
+(``dfm_embedding_forward_staged_update`` -> hipGraphExecKernelNodeSetParams; nothing is enqueued).  An
+exec must not be updated while a launch of it may still be pending, so graph A is instantiated TWICE
+and the two execs alternate: while one runs, the other — whose previous launch finished a whole step
+ago — is updated and queued.  Measured on one MI355X: 0.216 ms/step against 0.225 with the gather
+launched eagerly in front of the graph (two eager <-> graph transitions of ~10 us each disappear).
+No host synchronisation inside a step beyond waiting for the launch before the previous one.
+
+Timing the gather kernel: event-record NODES around it inside the graph cost ~5.5 us of device timeline
+each and read 3 us more than the kernel runs (measured), so they are not used.  ``capture(timed_variant=
+True)`` additionally captures the step WITHOUT its gather; ``run(eager_gather=True)`` then launches the
+gather eagerly in front of that copy, where ``dfm_gather_timing_begin`` can attach start/stop events to
+the dispatch itself.  bench.py does this on every 8th step of its timed region.
 """
 
 from __future__ import annotations
 
+import ctypes as C
 import os
 from typing import List, Optional
 
 import torch
 
+from deepfm_amd import _lib
 from deepfm_amd.data.schema import FeatureType
 from deepfm_amd.training.losses import bce_with_logits_mean
 from deepfm_amd.training.rowsparse import RowSparseAdam
+
+
+class _GraphSlot:
+    """One instantiated copy of graph A: exec + the gather's kernel node."""
+
+    def __init__(self) -> None:
+        self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self.node = C.c_void_p()
+        self.done: Optional[torch.cuda.Event] = None      # recorded after the slot's latest launch
 
 
 class RowSparseTrainStep:
@@ -35,17 +60,24 @@ class RowSparseTrainStep:
         specs = list(model.schema.fields.values())
         self.n_sparse = sum(s.feature_type is FeatureType.SPARSE for s in specs)
         self.n_dense = sum(s.feature_type is FeatureType.DENSE for s in specs)
-        # static, packed inputs in ONE buffer [ids (S,B) int64 | dense (Dn,B) f32 | labels (B) f32]: a
-        # whole batch is loaded with a single device-to-device copy; the per-field (B,) views keep
-        # the reference's dict contract
+        # packed record layout [ids (S,B) int64 | dense (Dn,B) f32 | labels (B) f32]; three buffers of it:
+        #   packed : the step's STATIC inputs (read by the row plan, the embedding backward, the loss) —
+        #            written by the gather itself from the record it reads
+        #   inbox  : where load_batch / load_packed put a batch that is not already a device record
+        #   pad    : all-padding batch (id 0 everywhere) used by capture()'s warm-up
         ns, nd = max(self.n_sparse, 1), max(self.n_dense, 1)
         self.packed_bytes = ns * batch_size * 8 + nd * batch_size * 4 + batch_size * 4
         self.packed = torch.zeros(self.packed_bytes, dtype=torch.uint8, device=dev)
+        self.inbox = torch.zeros(self.packed_bytes, dtype=torch.uint8, device=dev)
+        self.pad = torch.zeros(self.packed_bytes, dtype=torch.uint8, device=dev)
         o1 = ns * batch_size * 8
         o2 = o1 + nd * batch_size * 4
-        self.ids = self.packed[:o1].view(torch.int64).view(ns, batch_size)
-        self.dense = self.packed[o1:o2].view(torch.float32).view(nd, batch_size)
-        self.labels = self.packed[o2:].view(torch.float32)
+
+        def views(buf):
+            return (buf[:o1].view(torch.int64).view(ns, batch_size), buf[o1:o2].view(torch.float32).view(nd, batch_size),
+                    buf[o2:].view(torch.float32))
+        self.ids, self.dense, self.labels = views(self.packed)
+        self.in_ids, self.in_dense, self.in_labels = views(self.inbox)
         self.inputs: List[torch.Tensor] = []
         self._rec_offsets: List[int] = []          # byte offset of every field's input inside a batch record
         si = di = 0
@@ -55,34 +87,42 @@ class RowSparseTrainStep:
             else:
                 self.inputs.append(self.dense[di]); self._rec_offsets.append(o1 + di * batch_size * 4); di += 1
         self._rec_labels = o2
-        self._record: Optional[torch.Tensor] = None   # batch record the next gather reads (run_from)
+        self._record: torch.Tensor = self.inbox       # batch record the next gather reads
         F, D = len(specs), self.emb.fm_embed_dim
         self.fo = torch.empty(batch_size, 1, dtype=torch.float32, device=dev)
         self.fe = torch.empty(batch_size, F, D, dtype=torch.float32, device=dev)
         self.loss = torch.zeros((), dtype=torch.float32, device=dev)
         self.use_graph = use_graph
-        self.side = torch.cuda.Stream(device=dev)   # row plan (needs only the ids) overlaps fwd/bwd
-        self.graph_a: Optional[torch.cuda.CUDAGraph] = None
+        self.side = torch.cuda.Stream(device=dev)   # row plan on a side stream (DFM_ROWPLAN_SIDE_STREAM=1 only)
+        self.slots: List[_GraphSlot] = []
+        self._turn = 0
         self.graph_b: Optional[torch.cuda.CUDAGraph] = None
+        self.body_graph: Optional[torch.cuda.CUDAGraph] = None     # graph A without the gather (timed variant)
         self.dense_grads = {id(p): p.grad for p in self.emb.non_table_parameters() if p.grad is not None}
-        self.gather_events = None          # list of (start, end) torch.cuda.Event pairs when timing
         self.emb.pin_plan(dev)             # the step holds raw parameter pointers from here on
         for m in model.modules():          # DNN / head backward: accumulate straight into the flat .grad views
             if hasattr(m, "direct_grads"):
                 m.direct_grads = True
 
-    # ------------------------------------------------------------------ pieces
+    # kept for callers that ask whether a graph exists (tools, tests)
+    @property
+    def graph_a(self) -> Optional[torch.cuda.CUDAGraph]:
+        return self.slots[0].graph if self.slots else None
+
+    # ------------------------------------------------------------------ inputs
     def load_batch(self, ids: torch.Tensor, dense: torch.Tensor, labels: torch.Tensor) -> None:
-        """ids (S,B) int64, dense (Dn,B) float32, labels (B,) — device-to-device copies."""
+        """ids (S,B) int64, dense (Dn,B) float32, labels (B,) — device-to-device copies into the inbox
+        record; the next ``run()`` trains on it."""
         if self.n_sparse:
-            self.ids.copy_(ids, non_blocking=True)
+            self.in_ids.copy_(ids, non_blocking=True)
         if self.n_dense:
-            self.dense.copy_(dense, non_blocking=True)
-        self.labels.copy_(labels, non_blocking=True)
+            self.in_dense.copy_(dense, non_blocking=True)
+        self.in_labels.copy_(labels, non_blocking=True)
+        self._record = self.inbox
 
     def pack_batches(self, ids: torch.Tensor, dense: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
         """(n, S, B) int64, (n, Dn, B) f32, (n, B) f32 -> (n, packed_bytes) uint8 records for
-        ``load_packed`` (done once, outside any timed region)."""
+        ``run_from`` (done once, outside any timed region)."""
         n = labels.shape[0]
         parts = []
         if self.n_sparse:
@@ -97,22 +137,23 @@ class RowSparseTrainStep:
         return torch.cat(parts, dim=1).contiguous()
 
     def load_packed(self, record: torch.Tensor) -> None:
-        """One device-to-device copy of a pack_batches() record into the static inputs."""
-        self.packed.copy_(record, non_blocking=True)
+        """One device-to-device copy of a pack_batches() record into the inbox."""
+        self.inbox.copy_(record, non_blocking=True)
+        self._record = self.inbox
 
+    # ------------------------------------------------------------------ pieces
     def _gather_args(self) -> dict:
         """Extra outputs of the gather (subclasses: the fused step adds the FM value and S)."""
         return {}
 
-    def _gather(self) -> None:
-        rec = self._record
-        if rec is None:
-            self.emb.forward_into(self.inputs, self.B, self.fo, self.fe, **self._gather_args())
-            return
-        base = rec.data_ptr()
-        self.emb.forward_staged([base + o for o in self._rec_offsets], self.inputs, self.B, self.fo, self.fe,
-                                extra_src_ptr=base + self._rec_labels, extra_dst=self.labels, **self._gather_args())
-        self._record = None
+    def _gather_call(self, record: torch.Tensor):
+        base = record.data_ptr()
+        return ([base + o for o in self._rec_offsets], self.inputs, self.B, self.fo, self.fe), \
+            dict(extra_src_ptr=base + self._rec_labels, extra_dst=self.labels, **self._gather_args())
+
+    def _gather(self, record: Optional[torch.Tensor] = None) -> None:
+        a, kw = self._gather_call(self._record if record is None else record)
+        self.emb.forward_staged(*a, **kw)
 
     def _body_a(self) -> None:
         self.opt.zero_grad()
@@ -154,24 +195,23 @@ class RowSparseTrainStep:
         ts += list(self.model.buffers())
         return ts
 
-    def capture(self, warmup_iters: int = 1) -> None:
-        """Capture graph A (and B) after ``warmup_iters`` eager steps.  Side-effect free: the warm-up
+    def capture(self, warmup_iters: int = 1, timed_variant: bool = False) -> None:
+        """Capture the step's graphs after ``warmup_iters`` eager steps (``timed_variant``: also a copy of
+        graph A without the gather, for ``run(eager_gather=True)``).  Side-effect free: the warm-up
         steps run on an all-padding batch (id 0 everywhere: no table row receives a gradient, so the
         row-wise Adam touches nothing) and every other piece of state a step writes — dense parameters,
         Adam moments, step count, dropout seed, BatchNorm running statistics, the static inputs — is
         restored afterwards, bit for bit."""
         if not self.use_graph:
             return
+        lib = _lib.load()
         state = self._mutable_state()
         saved = [t.clone() for t in state]
-        record, self._record = self._record, None
-        if self.n_sparse:
-            self.ids.zero_()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(warmup_iters):
-                self._gather()
+                self._gather(self.pad)
                 self._body_a()
                 self.opt.exchange()
                 self._body_b()
@@ -186,14 +226,27 @@ class RowSparseTrainStep:
         # thread_local capture mode: another thread (the RCCL watchdog polling its events under
         # data parallelism) must not invalidate the capture
         mode = dict(capture_error_mode="thread_local")
-        self.graph_a = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph_a, **mode):
-            if os.environ.get("DFM_EXP_GATHER_IN_GRAPH") == "1":      # timing experiment only
-                self._gather()
+        def body():
             self._body_a()
             if single or fused_exchange:
                 self.opt.exchange()          # one rank: no device work, selects the local row lists
                 self._body_b()
+        self.slots = []
+        for _ in range(2):
+            slot = _GraphSlot()
+            # keep_graph: the captured graph stays alive, so the gather's node handle stays valid for
+            # hipGraphExecKernelNodeSetParams on the exec instantiated from it
+            slot.graph = torch.cuda.CUDAGraph(keep_graph=True)
+            with torch.cuda.graph(slot.graph, **mode):
+                self._gather(self.pad)
+                _lib.check(lib.dfm_graph_last_node(_lib.stream_handle(), C.byref(slot.node)))
+                body()
+            slot.graph.instantiate()
+            self.slots.append(slot)
+        if timed_variant:
+            self.body_graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.body_graph, **mode):
+                body()
         if not single and not fused_exchange:
             self.opt.exchange()
             torch.cuda.synchronize()
@@ -204,40 +257,47 @@ class RowSparseTrainStep:
         with torch.no_grad():
             for t, v in zip(state, saved):
                 t.copy_(v)
-        self._record = record
         torch.cuda.synchronize()
 
-    def run_from(self, record: torch.Tensor) -> None:
-        """One step on a ``pack_batches()`` record without the separate load: the (eager) gather reads
-        its inputs from the record and refreshes the static input buffers — ids, dense values,
-        labels — that the captured part of the step reads."""
+    def run_from(self, record: torch.Tensor, eager_gather: bool = False) -> None:
+        """One step on a ``pack_batches()`` record: the gather reads its inputs from the record and
+        refreshes the static input buffers — ids, dense values, labels — the rest of the step reads."""
         if record.numel() != self.packed_bytes or record.dtype != torch.uint8 or not record.is_contiguous():
             raise ValueError("run_from expects one contiguous pack_batches() record")
         if record.data_ptr() % 16:
             raise ValueError("batch records must be 16-byte aligned")
         self._record = record
-        self.run()
+        self.run(eager_gather)
 
-    def run(self, time_gather: bool = False) -> None:
-        if time_gather:
-            start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            start.record()
+    def run(self, eager_gather: bool = False) -> None:
+        if not self.slots:
             self._gather()
-            end.record()
-            if self.gather_events is None:
-                self.gather_events = []
-            self.gather_events.append((start, end))
-        elif not (os.environ.get("DFM_EXP_GATHER_IN_GRAPH") == "1" and self.graph_a is not None):
-            self._gather()
-        if self.graph_a is not None:
-            self.graph_a.replay()
-            if self.graph_b is not None:
-                # the replay produced the row gradients; the Python-side flag was only set while
-                # the graph was being captured
-                self.emb.rowsparse.has_grad = True
-                self.opt.exchange()
-                self.graph_b.replay()
-        else:
             self._body_a()
             self.opt.exchange()
             self._body_b()
+            return
+        if eager_gather:
+            if self.body_graph is None:
+                raise RuntimeError("run(eager_gather=True) needs capture(timed_variant=True)")
+            self._gather()                 # eager: dfm_gather_timing_begin may attach events to this dispatch
+            self.body_graph.replay()
+            done = None
+        else:
+            slot = self.slots[self._turn]
+            self._turn ^= 1
+            if slot.done is not None:
+                slot.done.synchronize()    # its previous launch (two steps ago) has left the device
+            else:
+                slot.done = torch.cuda.Event()
+            a, kw = self._gather_call(self._record)
+            self.emb.forward_staged_update(slot.graph.raw_cuda_graph_exec(), slot.node, *a, **kw)
+            slot.graph.replay()
+            done = slot.done
+        if self.graph_b is not None:
+            # the replay produced the row gradients; the Python-side flag was only set while
+            # the graph was being captured
+            self.emb.rowsparse.has_grad = True
+            self.opt.exchange()
+            self.graph_b.replay()
+        if done is not None:
+            done.record()

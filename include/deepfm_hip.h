@@ -115,6 +115,20 @@ int dfm_embedding_forward_staged(const dfm_embedding_plan* plan, const void* con
                                  int64_t batch, float* d_first_order, float* d_field_emb, float* d_fm_out,
                                  float* d_fm_sum, int32_t* d_error_flag, dfm_stream_t stream);
 
+/* dfm_embedding_forward_staged captured inside a graph (e.g. by torch.cuda.graph): rewrites the kernel
+ * node of the INSTANTIATED graph (`graph_exec`: hipGraphExec_t, `node`: hipGraphNode_t from
+ * dfm_graph_last_node right after the captured call) so that its next launch reads another batch
+ * record.  Same arguments as the captured call; host-side only, nothing is enqueued.  Do not update
+ * an exec whose previous launch may still be pending. */
+int dfm_embedding_forward_staged_update(const dfm_embedding_plan* plan, void* graph_exec, void* node,
+                                        const void* const* inputs, void* const* stage_out,
+                                        const float* d_extra_src, float* d_extra_dst, int64_t batch,
+                                        float* d_first_order, float* d_field_emb, float* d_fm_out,
+                                        float* d_fm_sum, int32_t* d_error_flag);
+
+/* Graph plumbing: the node of the operation captured last on `stream` (call right after the launch). */
+int dfm_graph_last_node(dfm_stream_t stream, void** node_out);
+
 /* Kernel-accurate timing of the uniform gather (measurement aid, bench.py): after
  * dfm_gather_timing_begin(n) the next n dfm_embedding_forward launches of a uniform plan carry HIP
  * start/stop events recorded around the dispatch itself (hipExtLaunchKernelGGL), on the stream the

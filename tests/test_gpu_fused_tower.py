@@ -305,6 +305,38 @@ def test_fused_step_graph_replay_is_bitwise_equal_to_eager():
         assert np.array_equal(results[0][k], results[1][k]), f"graph != eager: {k}"
 
 
+def test_graph_node_updates_and_eager_gather_variant_are_bitwise_equal_to_eager():
+    """The step as ONE graph whose gather node is re-pointed at a new record before every launch
+    (two alternating execs), mixed with the timed variant (gather launched eagerly in front of the
+    gather-less copy of the graph), from device records at changing addresses: bit-identical to the
+    eager step.  7 steps: both execs are updated several times and the host runs ahead of the device."""
+    from tools_shared import criteo_fields
+    B, n = 778, 7                                            # odd batch: ragged tail workgroup
+    rng = np.random.default_rng(19)
+    fields = criteo_fields(300, 16)
+    ids, dense, labels = _pool(fields, n, B, rng)
+    results = []
+    for mode in ("eager", "graph", "mixed"):
+        _, _, model, hp, opt, Step = _fused_pair(B, seed=8)
+        step = Step(model, opt, B, use_graph=mode != "eager")
+        recs = step.pack_batches(torch.from_numpy(ids).cuda(), torch.from_numpy(dense).cuda(), torch.from_numpy(labels).cuda())
+        step.capture(timed_variant=True)
+        losses = []
+        for i in range(n):
+            if mode == "mixed" and i % 3 == 1:
+                step.run_from(recs[i], eager_gather=True)
+            else:
+                step.run_from(recs[i])
+            losses.append(step.loss.clone())
+        torch.cuda.synchronize()
+        assert torch.equal(step.ids, torch.from_numpy(ids[n - 1]).cuda())      # static inputs: the last batch
+        results.append(({k: npy(v).copy() for k, v in model.state_dict().items()}, [float(l) for l in losses]))
+    for other in results[1:]:
+        assert other[1] == results[0][1], "losses differ"
+        for k in results[0][0]:
+            assert np.array_equal(other[0][k], results[0][0][k]), k
+
+
 def test_fused_step_rejects_ineligible_models():
     from deepfm_amd.config import ExperimentConfig
     from deepfm_amd.models import create_model

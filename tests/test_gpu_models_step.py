@@ -192,7 +192,7 @@ def test_graph_replay_is_bitwise_equal_to_eager_and_deterministic():
             assert torch.equal(v, start[k]), f"capture() changed {k}"
         assert int(opt.step_count) == 0 and not opt.flat_m.any() and not opt.flat_v.any() and not opt.flat_grad.any()
         assert all(not t.any() for t in opt.exp_avg + opt.exp_avg_sq)
-        assert torch.equal(step.ids, torch.from_numpy(ids[0]).cuda())
+        assert torch.equal(step.in_ids, torch.from_numpy(ids[0]).cuda())      # the loaded batch is still in the inbox
         for i in range(4):
             step.load_batch(torch.from_numpy(ids[i]).cuda(), torch.from_numpy(dense[i]).cuda(), torch.from_numpy(labels[i]).cuda())
             step.run()
