@@ -125,7 +125,7 @@ def build_step(name, V, D, B, dev, args, cin_sizes=None):
     """Model of BASELINE.json's shape + row-sparse optimizer + the fastest step class that takes it."""
     from deepfm_amd.config import ExperimentConfig
     from deepfm_amd.models import create_model
-    from deepfm_amd.training.fused_step import FusedDeepFMStep
+    from deepfm_amd.training.fused_step import fused_step_class
     from deepfm_amd.training.rowsparse import RowSparseAdam
     from deepfm_amd.training.step import RowSparseTrainStep
     from tests.helpers import schema_from_fields
@@ -144,8 +144,9 @@ def build_step(name, V, D, B, dev, args, cin_sizes=None):
     model.embedding.set_grad_mode("rowsparse")
     hp = dict(lr=cfg.training.lr, l2=cfg.feature.embedding_l2_reg, max_grad_norm=cfg.training.gradient_clip_norm)
     opt = RowSparseAdam(model, lr=hp["lr"], l2=hp["l2"], max_grad_norm=hp["max_grad_norm"])
-    fused = FusedDeepFMStep.eligible(model) and not args.autograd
-    step = (FusedDeepFMStep if fused else RowSparseTrainStep)(model, opt, B, use_graph=not args.no_graph)
+    cls = None if args.autograd else fused_step_class(model)
+    fused = cls is not None
+    step = (cls or RowSparseTrainStep)(model, opt, B, use_graph=not args.no_graph)
     return model, opt, step, fields, cfg, hp, fused
 
 

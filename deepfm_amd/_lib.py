@@ -55,7 +55,8 @@ class BnBwd(C.Structure):
 
 class FmBwd(C.Structure):
     """struct dfm_fm_bwd"""
-    _fields_ = [("g_fm", C.c_void_p), ("fm_sum", C.c_void_p), ("e", C.c_void_p), ("dim", C.c_int32)]
+    _fields_ = [("g_fm", C.c_void_p), ("fm_sum", C.c_void_p), ("e", C.c_void_p), ("addend", C.c_void_p),
+                ("dim", C.c_int32)]
 
 
 class SlabRef(C.Structure):

@@ -433,9 +433,10 @@ __global__ __launch_bounds__(kHeadThreads) void head_bce_kernel(
 //   blocks [0, dw_blocks): dW tiles x splits;  the rest: dx tiles
 // =====================================================================================
 struct FmBwd {
-  const float* g_fm;     // (M)      d loss / d fm value
+  const float* g_fm;     // (M)      d loss / d fm value, or null (no FM term)
   const float* fm_sum;   // (M, D)   sum_f e
   const float* e;        // (M, K)   field embeddings
+  const float* addend;   // (M, K)   gradient of another consumer of the embeddings (CIN / attention), or null
   int dim;
 };
 
@@ -483,8 +484,10 @@ __global__ __launch_bounds__(kThreads) void linear_bwd_kernel(
     if (m < M) {
       const int64_t off = static_cast<int64_t>(m) * K + n;
       float v = acc[reg];
-      if (EPI == 2)   // d e = d flat + g_fm * (S - e)   (fm.py:18-23 backward)
-        v += fmb.g_fm[m] * (fmb.fm_sum[static_cast<int64_t>(m) * fmb.dim + n % fmb.dim] - fmb.e[off]);
+      if (EPI == 2) {   // d e = d flat + g_fm * (S - e) (fm.py:18-23 backward) + what another layer sent back
+        if (fmb.g_fm) v += fmb.g_fm[m] * (fmb.fm_sum[static_cast<int64_t>(m) * fmb.dim + n % fmb.dim] - fmb.e[off]);
+        if (fmb.addend) v += fmb.addend[off];
+      }
       g_x[off] = v;
     }
   }
@@ -714,8 +717,10 @@ extern "C" int dfm_linear_backward(const float* d_dz, int64_t batch, int out_fea
   if (bn_below && (parts & 2)) DFM_REQUIRE(fill_bn(bn_below, &dbn), "incomplete dfm_bn_bwd");
   FmBwd dfm_ = {};
   if (fm && (parts & 2)) {
-    DFM_REQUIRE(fm->g_fm && fm->fm_sum && fm->e && fm->dim > 0 && K % fm->dim == 0, "incomplete dfm_fm_bwd");
-    dfm_.g_fm = fm->g_fm; dfm_.fm_sum = fm->fm_sum; dfm_.e = fm->e; dfm_.dim = fm->dim;
+    DFM_REQUIRE(fm->g_fm || fm->addend, "dfm_fm_bwd: neither an FM gradient nor an addend");
+    DFM_REQUIRE(!fm->g_fm || (fm->fm_sum && fm->e && fm->dim > 0 && K % fm->dim == 0), "incomplete dfm_fm_bwd");
+    dfm_.g_fm = fm->g_fm; dfm_.fm_sum = fm->fm_sum; dfm_.e = fm->e; dfm_.addend = fm->addend;
+    dfm_.dim = fm->dim > 0 ? fm->dim : 1;
   }
   int splits, k_per_split;
   dw_split_plan(N, K, M, &splits, &k_per_split);

@@ -1,26 +1,30 @@
-"""DeepFM training step on the fused tower kernels (csrc/tower.hip): no autograd, ~25 launches.
+"""Training steps on the fused tower kernels (csrc/tower.hip): no autograd, ~25 launches.
 
-Same step as ``RowSparseTrainStep`` (reference ``Trainer._train_epoch`` body, trainer.py:212-240,
-with the model of deepfm.py:30-42), but the DNN tower, the head and the FM backward run on
-``dfm_linear_bn_forward`` / ``dfm_bn_relu_dropout_apply`` / ``dfm_head_bce`` /
-``dfm_bn_backward_apply`` / ``dfm_linear_backward`` with hand-written backward wiring:
+Same step as ``RowSparseTrainStep`` (reference ``Trainer._train_epoch`` body, trainer.py:212-240), but
+the DNN tower, the head and what flows back into the embeddings run on ``dfm_linear_bn_forward`` /
+``dfm_bn_relu_dropout_apply`` / ``dfm_head_bce`` / ``dfm_bn_backward_apply`` / ``dfm_linear_backward``
+with hand-written backward wiring:
 
-    gather (+ fm value, + S = sum_f e)                                        1 launch (eager, timed)
+    gather (+ fm value, + S = sum_f e)                                        1 launch (graph node)
+    interaction layer forward (xDeepFM: CIN + its head)                       model specific
     per layer: GEMM + batch statistics, BN/ReLU/Dropout apply                 2 launches
     head: logits + BCE + d logits + head grads + last BN's mask               1 launch
-    per layer (top down): BN backward apply, [dW | dx + lower BN mask / FM]   2 launches
+    interaction layer backward (xDeepFM: CIN head, CIN)                       model specific
+    per layer (top down): BN backward apply, [dW | dx + lower BN mask / FM / addend]   2 launches
     embedding backward (dense fields + row gradients), optimizer              unchanged
 
 On an MI355X every dependent launch costs ~4.5 us, and the autograd path needs ~65 of them.
-Eligible: DeepFM with the reference-default tower (BatchNorm + ReLU), hidden sizes multiples of 4
-(last one a multiple of 32, <= 256), uniform embedding schema in ``rowsparse`` mode, training mode.
+``FusedDeepFMStep``  (deepfm.py:30-42): logits = (fo + fm) + output_linear(dnn(flat)).
+``FusedXDeepFMStep`` (xdeepfm.py:36-48): logits = (fo + cin_linear(cin(fe))) + dnn_linear(dnn(flat)).
+Eligible: the reference-default tower (BatchNorm + ReLU), hidden sizes multiples of 4 (last one a
+multiple of 32, <= 256), uniform embedding schema in ``rowsparse`` mode, training mode.
 """
 
 from __future__ import annotations
 
 import ctypes as C
 import os
-from typing import List
+from typing import List, Optional
 
 import torch
 
@@ -33,35 +37,38 @@ def _zeros_bytes(nbytes: int, device) -> torch.Tensor:
     return torch.zeros(max((nbytes + 3) // 4, 1), dtype=torch.int32, device=device)
 
 
-class FusedDeepFMStep(RowSparseTrainStep):
-    @staticmethod
-    def eligible(model) -> bool:
-        from deepfm_amd.models.deepfm import DeepFM
-        if not isinstance(model, DeepFM) or not model.training:
-            return False
-        dnn = model.dnn
-        if not getattr(dnn, "_fusable", False):
-            return False
-        widths = [dnn.mlp[4 * i].out_features for i in range(dnn._n_layers)]
-        if any(w % 4 for w in widths) or widths[-1] % 32 or widths[-1] > 256:
-            return False
-        bn = dnn.mlp[1]
-        if bn.momentum is None or not bn.affine:
-            return False
-        return dnn.mlp[0].in_features % 4 == 0 and model.embedding.grad_mode == "rowsparse"
+def _tower_ok(model) -> bool:
+    if not model.training:
+        return False
+    dnn = getattr(model, "dnn", None)
+    if dnn is None or not getattr(dnn, "_fusable", False):
+        return False
+    widths = [dnn.mlp[4 * i].out_features for i in range(dnn._n_layers)]
+    if any(w % 4 for w in widths) or widths[-1] % 32 or widths[-1] > 256:
+        return False
+    bn = dnn.mlp[1]
+    if bn.momentum is None or not bn.affine:
+        return False
+    return dnn.mlp[0].in_features % 4 == 0 and model.embedding.grad_mode == "rowsparse"
+
+
+class _FusedTowerStep(RowSparseTrainStep):
+    """Tower + head + optimizer wiring shared by the fused steps; subclasses say what else feeds the
+    logit (``_interaction_forward`` -> per-sample scalar) and the embeddings' gradient
+    (``_interaction_backward`` -> the epilogue of the first Linear's d input)."""
+
+    head_name = "output_linear"
 
     def __init__(self, model, optimizer: RowSparseAdam, batch_size: int, use_graph: bool = True) -> None:
         super().__init__(model, optimizer, batch_size, use_graph)
         if not self.eligible(model):
-            raise ValueError("FusedDeepFMStep: model/configuration not eligible (use RowSparseTrainStep)")
+            raise ValueError(f"{type(self).__name__}: model/configuration not eligible (use RowSparseTrainStep)")
         lib = _lib.load()
         dev, B = optimizer.device, batch_size
         dnn = model.dnn
         self.L = dnn._n_layers
         f32 = dict(dtype=torch.float32, device=dev)
         F, D = self.fe.shape[1], self.fe.shape[2]
-        self.fm = torch.empty(B, **f32)
-        self.fm_sum = torch.empty(B, D, **f32)
         self.x0 = self.fe.view(B, F * D)
         self.g_fe = torch.empty(B, F, D, **f32)
         self.logits = torch.empty(B, **f32)
@@ -83,14 +90,23 @@ class FusedDeepFMStep(RowSparseTrainStep):
         self.seed = torch.randint(1, 2 ** 40, (1,), dtype=torch.int64, device=dev)
         optimizer.seed_tick = self.seed          # advanced by the optimizer's norm-finalize kernel
         self.rowplan_side_stream = os.environ.get("DFM_ROWPLAN_SIDE_STREAM") == "1"
-        for p in list(dnn.parameters()) + list(model.output_linear.parameters()):
+        self.head = getattr(model, self.head_name)
+        for p in list(dnn.parameters()) + list(self.head.parameters()):
             if p.grad is None or not p.grad.is_contiguous():
-                raise RuntimeError("FusedDeepFMStep needs RowSparseAdam's flat gradient views on every dense parameter")
+                raise RuntimeError("fused steps need RowSparseAdam's flat gradient views on every dense parameter")
+
+    # ------------------------------------------------------------------ model-specific hooks
+    def _interaction_forward(self) -> Optional[torch.Tensor]:
+        """Runs the model's interaction layer; returns the per-sample scalar added to the logit
+        next to first_order ((B,) tensor) or None."""
+        raise NotImplementedError
+
+    def _interaction_backward(self) -> Optional[_lib.FmBwd]:
+        """Called right after the head (g_logits is known): enqueues the interaction layer's backward
+        and returns what the first Linear's d-input epilogue adds to d field_embeddings."""
+        raise NotImplementedError
 
     # ------------------------------------------------------------------ pieces
-    def _gather_args(self) -> dict:
-        return dict(fm_out=self.fm, fm_sum=self.fm_sum)
-
     def _bn_ctx(self, i: int) -> _lib.BnBwd:
         bn = self.bn[i]
         c = _lib.BnBwd()
@@ -119,6 +135,7 @@ class FusedDeepFMStep(RowSparseTrainStep):
             with torch.cuda.stream(self.side):
                 self.emb.build_rowplan(self.inputs, B)
         # ---- forward ----
+        extra = self._interaction_forward()
         x = self.x0
         for i in range(self.L):
             lin, bn = self.lin[i], self.bn[i]
@@ -134,17 +151,18 @@ class FusedDeepFMStep(RowSparseTrainStep):
                 float(bn.momentum), float(bn.eps), self.drop_p[i], self.seed.data_ptr(), i, self.a[i].data_ptr(), st))
             x = self.a[i]
         # ---- head: logits, d logits, mask of the last BatchNorm (loss + head gradients: next launch) ----
-        head = self.model.output_linear
+        head = self.head
         ctx = self._bn_ctx(self.L - 1)
         _lib.check(lib.dfm_head_bce(
             x.data_ptr(), B, head.in_features, head.weight.data_ptr(), _lib.ptr(head.bias), self.fo.data_ptr(),
-            self.fm.data_ptr(), self.labels.data_ptr(), self.logits.data_ptr(), self.g_logits.data_ptr(),
+            _lib.ptr(extra), self.labels.data_ptr(), self.logits.data_ptr(), self.g_logits.data_ptr(),
             C.byref(ctx), st))
         tail = _lib.HeadTail()
         tail.g_w = head.weight.grad.data_ptr()
         tail.g_b = head.bias.grad.data_ptr() if head.bias is not None else None
         tail.loss = self.loss.data_ptr()
-        # ---- backward, top layer first ----
+        # ---- backward: the interaction layer first (its d embeddings ride in layer 1's epilogue) ----
+        fmb = self._interaction_backward()
         for i in range(self.L - 1, -1, -1):
             lin = self.lin[i]
             n, k = lin.out_features, lin.in_features
@@ -157,12 +175,9 @@ class FusedDeepFMStep(RowSparseTrainStep):
                     self.dy[i].data_ptr(), B, n, xin.data_ptr(), k, lin.weight.data_ptr(), None, C.byref(ctx),
                     None, 3, self.ws_lin[i].data_ptr(), st))
             else:
-                fmb = _lib.FmBwd()
-                fmb.g_fm, fmb.fm_sum, fmb.e = self.g_logits.data_ptr(), self.fm_sum.data_ptr(), self.x0.data_ptr()
-                fmb.dim = self.fe.shape[2]
                 _lib.check(lib.dfm_linear_backward(
                     self.dy[i].data_ptr(), B, n, xin.data_ptr(), k, lin.weight.data_ptr(), self.g_fe.data_ptr(),
-                    None, C.byref(fmb), 3, self.ws_lin[i].data_ptr(), st))
+                    None, C.byref(fmb) if fmb is not None else None, 3, self.ws_lin[i].data_ptr(), st))
         # the batch-split d weight products of all layers -> the flat gradient buffer, one launch
         refs = (_lib.SlabRef * self.L)()
         for i in range(self.L):
@@ -176,3 +191,118 @@ class FusedDeepFMStep(RowSparseTrainStep):
         if not inline:
             cur.wait_stream(self.side)
         self.emb.backward_rowsparse(self.inputs, self.g_logits, self.g_fe, self.dense_grads)
+
+
+class FusedDeepFMStep(_FusedTowerStep):
+    head_name = "output_linear"
+
+    @staticmethod
+    def eligible(model) -> bool:
+        from deepfm_amd.models.deepfm import DeepFM
+        return isinstance(model, DeepFM) and _tower_ok(model)
+
+    def __init__(self, model, optimizer: RowSparseAdam, batch_size: int, use_graph: bool = True) -> None:
+        super().__init__(model, optimizer, batch_size, use_graph)
+        f32 = dict(dtype=torch.float32, device=optimizer.device)
+        self.fm = torch.empty(batch_size, **f32)
+        self.fm_sum = torch.empty(batch_size, self.fe.shape[2], **f32)
+
+    def _gather_args(self) -> dict:
+        return dict(fm_out=self.fm, fm_sum=self.fm_sum)      # FM value and S = sum_f e from the gather itself
+
+    def _interaction_forward(self):
+        return self.fm
+
+    def _interaction_backward(self):
+        fmb = _lib.FmBwd()
+        fmb.g_fm, fmb.fm_sum, fmb.e = self.g_logits.data_ptr(), self.fm_sum.data_ptr(), self.x0.data_ptr()
+        fmb.dim = self.fe.shape[2]
+        return fmb
+
+
+class FusedXDeepFMStep(_FusedTowerStep):
+    """xDeepFM (xdeepfm.py:36-48): the CIN stack and its Linear head called directly on preallocated
+    buffers (``dfm_cin_forward`` / ``dfm_cin_backward``, ``dfm_gemm_f32`` for the 1-wide head), the CIN's
+    d field_embeddings added inside the first tower Linear's d-input epilogue."""
+
+    head_name = "dnn_linear"
+
+    @staticmethod
+    def eligible(model) -> bool:
+        from deepfm_amd.models.xdeepfm import xDeepFM
+        return isinstance(model, xDeepFM) and _tower_ok(model)
+
+    def __init__(self, model, optimizer: RowSparseAdam, batch_size: int, use_graph: bool = True) -> None:
+        super().__init__(model, optimizer, batch_size, use_graph)
+        lib = _lib.load()
+        dev, B = optimizer.device, batch_size
+        f32 = dict(dtype=torch.float32, device=dev)
+        cin = model.cin
+        F, D = self.fe.shape[1], self.fe.shape[2]
+        self.cin = cin
+        self.cin_L = len(cin.layer_sizes)
+        self.cin_sizes = (C.c_int32 * self.cin_L)(*cin.layer_sizes)
+        self.cin_split = 1 if cin.split_half else 0
+        self.cin_out = torch.empty(B, cin.output_dim, **f32)
+        self.cin_lin = torch.empty(B, 1, **f32)
+        self.g_cin_out = torch.empty(B, cin.output_dim, **f32)
+        self.g_cin_fe = torch.empty(B, F, D, **f32)
+        self.cin_saved = torch.empty(max(lib.dfm_cin_saved_bytes(self.cin_sizes, self.cin_L, self.cin_split, B, F, D) // 4, 1), **f32)
+        self.cin_ws_f = torch.empty(max(lib.dfm_cin_forward_workspace_bytes(self.cin_sizes, self.cin_L, self.cin_split, F, D), 16),
+                                    dtype=torch.uint8, device=dev)
+        self.cin_ws_b = torch.empty(max(lib.dfm_cin_backward_workspace_bytes(self.cin_sizes, self.cin_L, self.cin_split, B, F, D) // 4, 1),
+                                    **f32)
+        self.ones = torch.ones(B, 1, **f32)
+        for p in list(cin.parameters()) + list(model.cin_linear.parameters()):
+            if p.grad is None or not p.grad.is_contiguous() or not p.is_contiguous():
+                raise RuntimeError("fused steps need RowSparseAdam's flat gradient views on every dense parameter")
+
+    def _ptrs(self, tensors):
+        arr = (C.c_void_p * len(tensors))()
+        for i, t in enumerate(tensors):
+            arr[i] = t.data_ptr()
+        return arr
+
+    def _interaction_forward(self):
+        from deepfm_amd.models.layers.dnn import _gemm
+        lib, B = _lib.load(), self.B
+        F, D = self.fe.shape[1], self.fe.shape[2]
+        ws = [c.weight for c in self.cin.conv_layers]
+        bs = [c.bias for c in self.cin.conv_layers]
+        _lib.check(lib.dfm_cin_forward(self.fe.data_ptr(), B, F, D, self._ptrs(ws), self._ptrs(bs), self.cin_sizes,
+                                       self.cin_L, self.cin_split, self.cin_out.data_ptr(), self.cin_saved.data_ptr(),
+                                       self.cin_ws_f.data_ptr(), _lib.stream_handle()))
+        head = self.model.cin_linear                       # explicit = cin_linear(cin(fe))   (xdeepfm.py:41-42)
+        K = head.in_features
+        _gemm(self.cin_out, K, True, head.weight, K, True, self.cin_lin, B, 1, K, bias=head.bias)
+        return self.cin_lin
+
+    def _interaction_backward(self):
+        from deepfm_amd.models.layers.dnn import _gemm
+        lib, B = _lib.load(), self.B
+        F, D = self.fe.shape[1], self.fe.shape[2]
+        head = self.model.cin_linear
+        K = head.in_features
+        g = self.g_logits                                                     # (B, 1) = d loss / d logit
+        _gemm(g, 1, True, head.weight, K, False, self.g_cin_out, B, K, 1)    # d cin_out = g w
+        _gemm(g, 1, False, self.cin_out, K, False, head.weight.grad, 1, K, B, accumulate=True)       # dW += g^T cin_out
+        if head.bias is not None:
+            _gemm(g, 1, False, self.ones, 1, False, head.bias.grad.view(1, 1), 1, 1, B, accumulate=True)
+        ws = [c.weight for c in self.cin.conv_layers]
+        g_w = [c.weight.grad for c in self.cin.conv_layers]
+        g_b = [c.bias.grad for c in self.cin.conv_layers]
+        _lib.check(lib.dfm_cin_backward(self.fe.data_ptr(), B, F, D, self._ptrs(ws), self.cin_sizes, self.cin_L,
+                                        self.cin_split, self.cin_saved.data_ptr(), self.g_cin_out.data_ptr(),
+                                        self.g_cin_fe.data_ptr(), self._ptrs(g_w), self._ptrs(g_b),
+                                        self.cin_ws_b.data_ptr(), _lib.stream_handle()))
+        fmb = _lib.FmBwd()
+        fmb.addend = self.g_cin_fe.data_ptr()
+        return fmb
+
+
+def fused_step_class(model):
+    """The fused step that takes ``model``, or None (-> RowSparseTrainStep over autograd)."""
+    for cls in (FusedDeepFMStep, FusedXDeepFMStep):
+        if cls.eligible(model):
+            return cls
+    return None

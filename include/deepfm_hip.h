@@ -387,11 +387,15 @@ typedef struct dfm_bn_bwd {
   int32_t salt;            /* layer index, as passed to dfm_bn_relu_dropout_apply */
 } dfm_bn_bwd;
 
-/* FMInteraction backward folded into the first Linear's d input: d e = d flat + g_fm * (S - e). */
+/* What else flows back into the embeddings, folded into the first Linear's d input:
+ * d e = d flat + g_fm * (S - e)  [FMInteraction backward, fm.py:18-23; g_fm NULL: no FM term]
+ *              + addend          [gradient from another consumer of field_embeddings: CIN
+ *                                 (xdeepfm.py:36-48) or the attention stack; NULL: none]. */
 typedef struct dfm_fm_bwd {
-  const float* g_fm;       /* (batch) d loss / d fm value */
+  const float* g_fm;       /* (batch) d loss / d fm value, or NULL */
   const float* fm_sum;     /* (batch, dim) S = sum_f e (dfm_embedding_forward's d_fm_sum) */
   const float* e;          /* (batch, fields * dim) field embeddings */
+  const float* addend;     /* (batch, fields * dim), or NULL */
   int32_t dim;
 } dfm_fm_bwd;
 

@@ -12,7 +12,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from deepfm_amd.config import ExperimentConfig  # noqa: E402
 from deepfm_amd.models import create_model  # noqa: E402
-from deepfm_amd.training.fused_step import FusedDeepFMStep  # noqa: E402
+from deepfm_amd.training.fused_step import fused_step_class  # noqa: E402
 from deepfm_amd.training.rowsparse import RowSparseAdam  # noqa: E402
 from deepfm_amd.training.step import RowSparseTrainStep  # noqa: E402
 from tests.helpers import schema_from_fields  # noqa: E402
@@ -32,7 +32,7 @@ def run(name, dim, steps, B=4096, V=1_000_000):
     model.embedding.pack_tables_()
     model.embedding.set_grad_mode("rowsparse")
     opt = RowSparseAdam(model, lr=1e-3, l2=1e-5, max_grad_norm=1.0)
-    cls = FusedDeepFMStep if FusedDeepFMStep.eligible(model) else RowSparseTrainStep
+    cls = fused_step_class(model) or RowSparseTrainStep
     step = cls(model, opt, B, use_graph=True)
     g = torch.Generator(device="cuda").manual_seed(1)
     n = 16
