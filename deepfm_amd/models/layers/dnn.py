@@ -155,6 +155,8 @@ class DNN(nn.Module):
             return self.mlp(x)
         if self._seed is None or self._seed.device != x.device:
             self._seed = torch.randint(1, 2 ** 40, (1,), dtype=torch.int64, device=x.device)
+            if torch.distributed.is_available() and torch.distributed.is_initialized():
+                self._seed += 7919 * torch.distributed.get_rank()      # replicas share parameters, not masks
         self._seed.add_(1)
         # backward regenerates the dropout mask from the seed: with dropout on, each forward keeps its own
         # copy, so a second forward before the backward (gradient accumulation) cannot change the mask

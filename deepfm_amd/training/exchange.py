@@ -42,17 +42,34 @@ def allgather_row_lists(local: Sequence[torch.Tensor], out: Sequence[torch.Tenso
         dist.all_gather_into_tensor(dst, src.contiguous(), group=group)
 
 
+_GROUPED: dict = {}     # process group -> bool: the choice made (and logged) on first use
+
+
+def _grouped_supported(group: Optional[dist.ProcessGroup]) -> bool:
+    """One grouped launch needs the backend's coalescing support: RCCL ("nccl") has it (ncclGroupStart /
+    ncclGroupEnd around the all-gathers), gloo does not.  Decided once per group from the backend NAME —
+    never by catching an error of a collective — and logged, so a slower exchange is never silent."""
+    key = group if group is not None else "default"
+    if key not in _GROUPED:
+        backend = dist.get_backend(group)
+        _GROUPED[key] = backend == "nccl"
+        import logging
+        logging.getLogger("deepfm_amd.exchange").info(
+            "gradient exchange over %s: %s", backend,
+            "ONE grouped all-gather per step" if _GROUPED[key] else "one all-gather per tensor (no coalescing support)")
+    return _GROUPED[key]
+
+
 def allgather_step(local: Sequence[torch.Tensor], out: Sequence[torch.Tensor],
                    group: Optional[dist.ProcessGroup] = None) -> None:
     """All tensors of ``local`` all-gathered into ``out`` (``out[i]`` is ``(world * local[i].shape[0], ...)``)
-    as ONE grouped collective launch where the backend supports it (RCCL: ncclGroupStart/End around the
-    all-gathers), else one collective per tensor.  Every tensor must be contiguous."""
-    from torch.distributed import distributed_c10d as c10d
-    try:
-        with c10d._coalescing_manager(group=group):
+    as ONE grouped collective launch on RCCL, one collective per tensor on backends without coalescing
+    (gloo: the CPU tests).  Every tensor must be contiguous.  Errors of the collectives propagate."""
+    if _grouped_supported(group):
+        from torch.distributed import distributed_c10d as c10d
+        with c10d._coalescing_manager(group=group):      # torch's only handle on ncclGroupStart/End
             for dst, src in zip(out, local):
                 dist.all_gather_into_tensor(dst, src, group=group)
-    except (NotImplementedError, RuntimeError, AttributeError):
-        c10d._world.pg_coalesce_state.pop(group or c10d._get_default_group(), None)
+    else:
         for dst, src in zip(out, local):
             dist.all_gather_into_tensor(dst, src, group=group)

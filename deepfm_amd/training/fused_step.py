@@ -88,6 +88,9 @@ class _FusedTowerStep(RowSparseTrainStep):
             self.ws_bn.append(_zeros_bytes(lib.dfm_bn_bwd_workspace_bytes(B, n), dev))
             self.ws_lin.append(_zeros_bytes(lib.dfm_linear_backward_workspace_bytes(B, n, k), dev))
         self.seed = torch.randint(1, 2 ** 40, (1,), dtype=torch.int64, device=dev)
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            # replicas are built from one seed (identical parameters) but must not share dropout masks
+            self.seed += 7919 * torch.distributed.get_rank()
         optimizer.seed_tick = self.seed          # advanced by the optimizer's norm-finalize kernel
         self.rowplan_side_stream = os.environ.get("DFM_ROWPLAN_SIDE_STREAM") == "1"
         self.head = getattr(model, self.head_name)
