@@ -33,7 +33,8 @@ struct CinMfmaArgs {
   float* out;
   int64_t B;
   int F, L, out_dim, hid_rows;
-  int ablate;
+  int pad_;
+  unsigned long long* stamps;
   CinMfmaLayer layer[kCinMaxLayers];
 };
 struct CinBwdLayer {

@@ -32,7 +32,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kCinMaxLayers = 8;
-constexpr int kCinWaves = 4;          // waves per workgroup (share the weight slabs)
+constexpr int kCinWaves = 8;          // waves per workgroup = per CU (share the weight slabs)
 constexpr int kCinCols = 32;          // columns per wave
 
 struct CinMfmaLayer {
@@ -47,7 +47,8 @@ struct CinMfmaArgs {
   float* out;
   int64_t B;
   int F, L, out_dim, hid_rows;  // hid_rows: rows of the per-wave hidden image in LDS
-  int ablate;                   // unused (timing-only switches of an earlier version of the kernel)
+  int pad_;
+  unsigned long long* stamps;   // tools/microbench_cin only (DFM_CIN_STAMPS build): per-wave phase sums
   CinMfmaLayer layer[kCinMaxLayers];
 };
 
@@ -76,10 +77,11 @@ __global__ __launch_bounds__(256) void cin_pack_weights(const float* __restrict_
 
 // ---- the fused forward ----------------------------------------------------------------
 template <int D, int FG, bool SPLIT>
-__global__ __launch_bounds__(kCinWaves * 64, 2) void cin_fwd_mfma(CinMfmaArgs args) {
+__global__ __launch_bounds__(kCinWaves * 64, 1) void cin_fwd_mfma(CinMfmaArgs args) {
   static_assert(kCinCols % D == 0, "a 32-column tile must hold whole samples");
   constexpr int SPT = kCinCols / D;                       // samples per tile
-  constexpr int SLAB = 4 /*MB max*/ * 64 * 16;            // bytes of one hi (or lo) slab
+  // one slab = the A fragments of ONE hidden-row pair: FG k-steps x (up to) 4 row blocks x 64 lanes x 16 B
+  constexpr int SLAB = FG * 4 /*MB max*/ * 64 * 16;       // bytes of one hi (or lo) slab
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   // [2 buffers][hi, lo][MB*64 lanes][16 B]  then per-wave hidden images
   unsigned char* wbuf = lds_raw;
@@ -110,6 +112,11 @@ __global__ __launch_bounds__(kCinWaves * 64, 2) void cin_fwd_mfma(CinMfmaArgs ar
   for (int f = 0; f < FG * 8; ++f)
     if (hf == 0 && f < args.hid_rows) hid[f * kCinCols + n] = x0r[f];
 
+#ifdef DFM_CIN_STAMPS
+  unsigned long long st_work = 0, st_barrier = 0, st_pre = 0, st_epi = 0;
+  const unsigned long long st_begin = wall_clock64();
+  unsigned long long st_mark = st_begin;
+#endif
   for (int li = 0; li < args.L; ++li) {
     const CinMfmaLayer ly = args.layer[li];
     const int MB = ly.MB;
@@ -127,57 +134,66 @@ __global__ __launch_bounds__(kCinWaves * 64, 2) void cin_fwd_mfma(CinMfmaArgs ar
         }
       }
     }
-    const int ksteps = ly.HP * FG;
-    // stage slab 0
-    const int s_mb = tid >> 6, s_lane = tid & 63;
-    auto stage_load = [&](int ks, uint4& vh, uint4& vl) {
-      if (s_mb < MB) {
-        const int64_t e = (static_cast<int64_t>(ks) * MB + s_mb) * 64 + s_lane;
-        vh = reinterpret_cast<const uint4*>(ly.w_hi)[e];
-        if (SPLIT) vl = reinterpret_cast<const uint4*>(ly.w_lo)[e];
-      }
+    // Weight pipeline, one slab (FG k-steps: every k-step of a hidden-row pair) at a time: slab t is loaded
+    // global -> registers during iteration t-2, written to LDS at the start of iteration t-1 (the loads
+    // had a whole iteration to land), made visible by the ONE barrier that ends iteration t-1, read
+    // during iteration t.  Two LDS buffers, one register set of up to 3 x 16 B per thread and half.
+    // (Round 1 staged and synchronised per k-step: 420 barriers per wave at the Criteo shape, 74 ns of
+    // barrier wait + lock-step between the two waves of a SIMD each — tools/microbench_cin; now 84.)
+    constexpr int kStageRounds = (FG * 4 * 64 + kCinWaves * 64 - 1) / (kCinWaves * 64);
+    const int slab_u4 = FG * MB * 64;                       // uint4 per slab and half
+    // (named registers, not arrays: arrays handed to a lambda went to scratch memory)
+    static_assert(kStageRounds <= 3, "stage registers");
+    uint4 vh0 = {}, vh1 = {}, vh2 = {}, vl0 = {}, vl1 = {}, vl2 = {};
+    auto stage_load = [&](int hp) {
+      const uint4* gh = reinterpret_cast<const uint4*>(ly.w_hi) + static_cast<int64_t>(hp) * slab_u4;
+      const uint4* gl = reinterpret_cast<const uint4*>(ly.w_lo) + static_cast<int64_t>(hp) * slab_u4;
+      constexpr int T = kCinWaves * 64;
+      if (tid < slab_u4) { vh0 = gh[tid]; if (SPLIT) vl0 = gl[tid]; }
+      if (kStageRounds > 1 && tid + T < slab_u4) { vh1 = gh[tid + T]; if (SPLIT) vl1 = gl[tid + T]; }
+      if (kStageRounds > 2 && tid + 2 * T < slab_u4) { vh2 = gh[tid + 2 * T]; if (SPLIT) vl2 = gl[tid + 2 * T]; }
     };
-    auto stage_store = [&](int buf, const uint4& vh, const uint4& vl) {
-      if (s_mb < MB) {
-        unsigned char* base = wbuf + buf * 2 * SLAB;
-        reinterpret_cast<uint4*>(base)[s_mb * 64 + s_lane] = vh;
-        if (SPLIT) reinterpret_cast<uint4*>(base + SLAB)[s_mb * 64 + s_lane] = vl;
-      }
+    auto stage_store = [&](int buf) {
+      uint4* bh_ = reinterpret_cast<uint4*>(wbuf + buf * 2 * SLAB);
+      uint4* bl_ = reinterpret_cast<uint4*>(wbuf + buf * 2 * SLAB + SLAB);
+      constexpr int T = kCinWaves * 64;
+      if (tid < slab_u4) { bh_[tid] = vh0; if (SPLIT) bl_[tid] = vl0; }
+      if (kStageRounds > 1 && tid + T < slab_u4) { bh_[tid + T] = vh1; if (SPLIT) bl_[tid + T] = vl1; }
+      if (kStageRounds > 2 && tid + 2 * T < slab_u4) { bh_[tid + 2 * T] = vh2; if (SPLIT) bl_[tid + 2 * T] = vl2; }
     };
-    // Weight pipeline: slab t is loaded global->registers during k-step t-2, written to LDS at
-    // the start of k-step t-1 (the load had a whole k-step to land), made visible by the
-    // barrier that ends k-step t-1, read during k-step t.  Two LDS buffers, one register set.
-    uint4 vh = {}, vl = {};
     __syncthreads();                       // previous layer's readers are done with both buffers / hid
-    stage_load(0, vh, vl);
-    stage_store(0, vh, vl);
-    if (ksteps > 1) stage_load(1, vh, vl);
+    stage_load(0);
+    stage_store(0);
+    if (ly.HP > 1) stage_load(1);
     __syncthreads();
     // One k-step = one 16-deep slice of the reduction: 4 (MB) x 3 (split) MFMAs per wave.  All A
     // fragments of the step are requested from LDS first, the B operand is generated while they are
     // in flight, and the MFMAs run hh / hl / lh across the four independent accumulators.  FULL
     // (MB == 4, the usual 128-channel layer) is free of branches, so nothing waits early: with a
     // uniform `mb < MB` test around every accumulator the compiler issued read - wait - MFMA eight
-    // times per step (LDS latency exposed each time).
+    // times per step (LDS latency exposed each time).  No barrier between the FG k-steps of a slab:
+    // the scheduler is free to overlap one step's B generation with another's MFMAs.
     auto kloop = [&](auto full_tag) {
       constexpr bool FULL = decltype(full_tag)::value;
-      int ks = 0;
       for (int hp = 0; hp < ly.HP; ++hp) {
         const float hv = hid[(2 * hp + hf) * kCinCols + n];
+        const int cur = hp & 1;
+        const unsigned char* base = wbuf + cur * 2 * SLAB;
+#ifdef DFM_CIN_STAMPS
+        const unsigned long long ts0 = wall_clock64();
+#endif
+        if (hp + 1 < ly.HP) stage_store(cur ^ 1);   // slab hp+1 (loaded one iteration ago)
+        if (hp + 2 < ly.HP) stage_load(hp + 2);
 #pragma unroll
-        for (int fg = 0; fg < FG; ++fg, ++ks) {
-          const int cur = ks & 1;
-          const unsigned char* base = wbuf + cur * 2 * SLAB;
+        for (int fg = 0; fg < FG; ++fg) {
           bf16x8 ah[4], al[4];
           if constexpr (FULL) {
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) {
-              ah[mb] = reinterpret_cast<const bf16x8*>(base)[mb * 64 + lane];
-              if (SPLIT) al[mb] = reinterpret_cast<const bf16x8*>(base + SLAB)[mb * 64 + lane];
+              ah[mb] = reinterpret_cast<const bf16x8*>(base)[(fg * 4 + mb) * 64 + lane];
+              if (SPLIT) al[mb] = reinterpret_cast<const bf16x8*>(base + SLAB)[(fg * 4 + mb) * 64 + lane];
             }
           }
-          if (ks + 1 < ksteps) stage_store(cur ^ 1, vh, vl);   // slab ks+1 (loaded one step ago)
-          if (ks + 2 < ksteps) stage_load(ks + 2, vh, vl);
           // B operand: Z values of this k-step for the lane's column
           bf16x8 bh, bl;
 #pragma unroll
@@ -202,23 +218,36 @@ __global__ __launch_bounds__(kCinWaves * 64, 2) void cin_fwd_mfma(CinMfmaArgs ar
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) {
               if (mb < MB) {
-                const bf16x8 a_h = reinterpret_cast<const bf16x8*>(base)[mb * 64 + lane];
+                const bf16x8 a_h = reinterpret_cast<const bf16x8*>(base)[(fg * MB + mb) * 64 + lane];
                 acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, bh, acc[mb], 0, 0, 0);
                 if (SPLIT) {
-                  const bf16x8 a_l = reinterpret_cast<const bf16x8*>(base + SLAB)[mb * 64 + lane];
+                  const bf16x8 a_l = reinterpret_cast<const bf16x8*>(base + SLAB)[(fg * MB + mb) * 64 + lane];
                   acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, bl, acc[mb], 0, 0, 0);
                   acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_l, bh, acc[mb], 0, 0, 0);
                 }
               }
             }
           }
-          __syncthreads();
         }
+#ifdef DFM_CIN_STAMPS
+        const unsigned long long ts1 = wall_clock64();      // all of the slab's work issued
+        __syncthreads();
+        const unsigned long long ts2 = wall_clock64();
+        st_work += ts1 - ts0; st_barrier += ts2 - ts1;
+#else
+        __syncthreads();
+#endif
       }
     };
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+#ifdef DFM_CIN_STAMPS
+    { const unsigned long long t = wall_clock64(); st_pre += t - st_mark; }
+#endif
     if (MB == 4) kloop(std::true_type{});
     else kloop(std::false_type{});
+#ifdef DFM_CIN_STAMPS
+    st_mark = wall_clock64();
+#endif
     // ---- epilogue: ReLU, sum-pool of the direct channels, hand the next channels over ------
     const bool last = li == args.L - 1;
     // the hidden image is rewritten below: every row of the next layer's (padded) image
@@ -245,16 +274,24 @@ __global__ __launch_bounds__(kCinWaves * 64, 2) void cin_fwd_mfma(CinMfmaArgs ar
           // sum-pool over the D columns of each sample (D consecutive lanes; xor partners share
           // the lane half, hence the row, so the branch is taken pairwise)
           if (rr < d_lim) {
-            float sum = live ? y : 0.f;
-#pragma unroll
-            for (int m = 1; m < D; m <<= 1) sum += __shfl_xor(sum, m, kWave);
+            float sum = group_sum<(D < 16 ? D : 16)>(live ? y : 0.f);
+            if (D == 32) sum += __shfl_xor(sum, 16, kWave);
             if (live && d == 0) obase[rr] = sum;
           }
         }
       }
     }
     (void)SPT;
+#ifdef DFM_CIN_STAMPS
+    { const unsigned long long t = wall_clock64(); st_epi += t - st_mark; st_mark = t; }
+#endif
   }
+#ifdef DFM_CIN_STAMPS
+  if (args.stamps && lane == 0) {
+    unsigned long long* p = args.stamps + (static_cast<size_t>(blockIdx.x) * kCinWaves + wave) * 8;
+    p[0] = st_begin; p[1] = wall_clock64(); p[2] = st_work; p[3] = st_barrier; p[4] = st_pre; p[5] = st_epi;
+  }
+#endif
 }
 
 // ---- host side ---------------------------------------------------------------------------
@@ -284,7 +321,7 @@ template <int D, int FG>
 static int launch_fwd(const CinMfmaArgs& args, bool split, hipStream_t st) {
   const int64_t ncols = args.B * D;
   const int64_t blocks = (ncols + kCinWaves * kCinCols - 1) / (kCinWaves * kCinCols);
-  const size_t lds = 2 * 2 * (4 * 64 * 16) + sizeof(float) * kCinWaves * args.hid_rows * kCinCols;
+  const size_t lds = 2 * 2 * (static_cast<size_t>(FG) * 4 * 64 * 16) + sizeof(float) * kCinWaves * args.hid_rows * kCinCols;
   DFM_REQUIRE(lds <= 160 * 1024, "CIN MFMA kernel needs %zu bytes of LDS", lds);
   if (split) {
     DFM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(cin_fwd_mfma<D, FG, true>),
