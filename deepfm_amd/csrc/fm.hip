@@ -89,6 +89,31 @@ __global__ __launch_bounds__(256) void fm_bwd_kernel(const float* __restrict__ e
   }
 }
 
+// d e = d flat + d (other consumer) + g_fm * (S - e): everything that flows back into field_embeddings of
+// AttentionDeepFM (attention_deepfm.py:48-66: FM on the raw embeddings, the attention stack, and the
+// flat copy that enters the DNN next to the attended one), one pass, 16 bytes per lane.
+__global__ __launch_bounds__(256) void embedding_grad_combine_kernel(
+    const float* __restrict__ g_flat, int64_t ld_flat, const float* __restrict__ g_extra,
+    const float* __restrict__ g_fm, const float* __restrict__ fm_sum, const float* __restrict__ e, int64_t rows,
+    int width, int dim, float* __restrict__ out) {
+  const int w4 = width / 4;
+  const int64_t t = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (t >= rows * w4) return;
+  const int64_t r = t / w4;
+  const int c = static_cast<int>(t % w4) * 4;
+  float4 v = ld4(g_flat + r * ld_flat + c);
+  if (g_extra) {
+    const float4 x = ld4(g_extra + r * width + c);
+    v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
+  }
+  if (g_fm) {
+    const float g = g_fm[r];
+    const float4 s4 = ld4(fm_sum + r * dim + c % dim), e4 = ld4(e + r * width + c);
+    v.x += g * (s4.x - e4.x); v.y += g * (s4.y - e4.y); v.z += g * (s4.z - e4.z); v.w += g * (s4.w - e4.w);
+  }
+  st4(out + r * width + c, v);
+}
+
 static int pow2_at_least(int x) {
   int p = 1;
   while (p < x) p <<= 1;
@@ -129,6 +154,23 @@ int dfm_fm_backward(const float* d_field_emb, const float* d_g_out, int64_t batc
     hipLaunchKernelGGL(fm_bwd_kernel<4>, grid, block, 0, as_stream(stream), d_field_emb, d_g_out, batch, num_fields, dim, lps, d_g_field);
   else
     hipLaunchKernelGGL(fm_bwd_kernel<1>, grid, block, 0, as_stream(stream), d_field_emb, d_g_out, batch, num_fields, dim, lps, d_g_field);
+  DFM_LAUNCH_CHECK();
+  return DFM_OK;
+}
+
+int dfm_embedding_grad_combine(const float* d_g_flat, int64_t ld_flat, const float* d_g_extra, const float* d_g_fm,
+                               const float* d_fm_sum, const float* d_field_emb, int64_t batch, int num_fields, int dim,
+                               float* d_g_field, dfm_stream_t stream) {
+  DFM_REQUIRE(d_g_flat && d_g_field, "null argument");
+  DFM_REQUIRE(num_fields > 0 && dim > 0 && dim % 4 == 0 && batch >= 0, "bad shape (dim must be a multiple of 4)");
+  DFM_REQUIRE(!d_g_fm || (d_fm_sum && d_field_emb), "the FM term needs fm_sum and field_embeddings");
+  const int width = num_fields * dim;
+  DFM_REQUIRE(ld_flat >= width && ld_flat % 4 == 0, "bad leading dimension");
+  if (batch == 0) return DFM_OK;
+  const int64_t threads = batch * (width / 4);
+  hipLaunchKernelGGL(embedding_grad_combine_kernel, dim3(static_cast<unsigned>((threads + 255) / 256)), dim3(256), 0,
+                     as_stream(stream), d_g_flat, ld_flat, d_g_extra, d_g_fm, d_fm_sum, d_field_emb, batch, width, dim,
+                     d_g_field);
   DFM_LAUNCH_CHECK();
   return DFM_OK;
 }

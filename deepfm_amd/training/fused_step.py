@@ -69,8 +69,9 @@ class _FusedTowerStep(RowSparseTrainStep):
         self.L = dnn._n_layers
         f32 = dict(dtype=torch.float32, device=dev)
         F, D = self.fe.shape[1], self.fe.shape[2]
-        self.x0 = self.fe.view(B, F * D)
+        self.x0 = self._tower_input()                      # (B, K) input of the first Linear
         self.g_fe = torch.empty(B, F, D, **f32)
+        self.g_x0 = self._tower_input_grad()               # where the first Linear's d input goes
         self.logits = torch.empty(B, **f32)
         self.g_logits = torch.empty(B, 1, **f32)
         self.lin, self.bn, self.drop_p = [], [], []
@@ -99,6 +100,16 @@ class _FusedTowerStep(RowSparseTrainStep):
                 raise RuntimeError("fused steps need RowSparseAdam's flat gradient views on every dense parameter")
 
     # ------------------------------------------------------------------ model-specific hooks
+    def _tower_input(self) -> torch.Tensor:
+        """Input of the first Linear: the flat embeddings (same bytes as field_embeddings)."""
+        return self.fe.view(self.B, -1)
+
+    def _tower_input_grad(self) -> torch.Tensor:
+        return self.g_fe
+
+    def _finish_embedding_grad(self) -> None:
+        """After the tower's backward: whatever is still missing in ``g_fe`` (default: nothing)."""
+
     def _interaction_forward(self) -> Optional[torch.Tensor]:
         """Runs the model's interaction layer; returns the per-sample scalar added to the logit
         next to first_order ((B,) tensor) or None."""
@@ -179,8 +190,9 @@ class _FusedTowerStep(RowSparseTrainStep):
                     None, 3, self.ws_lin[i].data_ptr(), st))
             else:
                 _lib.check(lib.dfm_linear_backward(
-                    self.dy[i].data_ptr(), B, n, xin.data_ptr(), k, lin.weight.data_ptr(), self.g_fe.data_ptr(),
+                    self.dy[i].data_ptr(), B, n, xin.data_ptr(), k, lin.weight.data_ptr(), self.g_x0.data_ptr(),
                     None, C.byref(fmb) if fmb is not None else None, 3, self.ws_lin[i].data_ptr(), st))
+        self._finish_embedding_grad()
         # the batch-split d weight products of all layers -> the flat gradient buffer, one launch
         refs = (_lib.SlabRef * self.L)()
         for i in range(self.L):
@@ -303,9 +315,94 @@ class FusedXDeepFMStep(_FusedTowerStep):
         return fmb
 
 
+class _Ctx:
+    """Stand-in for autograd's ctx: lets a torch.autograd.Function's forward / backward bodies be called
+    directly (no graph recording, no AccumulateGrad launches)."""
+
+    def save_for_backward(self, *tensors):
+        self.saved_tensors = tensors
+
+
+class FusedAttentionDeepFMStep(_FusedTowerStep):
+    """AttentionDeepFM (attention_deepfm.py:48-66): logits = (fo + fm) + output_linear(dnn(cat[attention(fe),
+    flat])).  The attention blocks run through the same kernels as the module (``_AttnGemmFn`` called
+    directly), their parameter gradients land in the flat buffer with one multi-tensor add, and the three
+    gradients of the embeddings (flat half of the DNN's d input, attention, FM) are summed in one pass
+    (``dfm_embedding_grad_combine``)."""
+
+    head_name = "output_linear"
+
+    @staticmethod
+    def eligible(model) -> bool:
+        from deepfm_amd.models.attention_deepfm import AttentionDeepFM
+        if not (isinstance(model, AttentionDeepFM) and _tower_ok(model)):
+            return False
+        att = model.attention
+        F = model.schema.num_fields
+        ok = _lib.load().dfm_attention_core_supported(F, att.attention_dim, att.num_heads)
+        return bool(ok) and att.embed_dim % 4 == 0 and att.attention_dim % 4 == 0 and att.embed_dim <= 64 \
+            and all(b.gemm_path for b in att.layers)
+
+    def __init__(self, model, optimizer: RowSparseAdam, batch_size: int, use_graph: bool = True) -> None:
+        super().__init__(model, optimizer, batch_size, use_graph)
+        f32 = dict(dtype=torch.float32, device=optimizer.device)
+        B, D = batch_size, self.fe.shape[2]
+        self.fm = torch.empty(B, **f32)
+        self.fm_sum = torch.empty(B, D, **f32)
+        self.blocks = list(model.attention.layers)
+        self._ctxs: List[_Ctx] = []
+        self._att_params = [p for b in self.blocks for p in b._param_list()]
+        for p in self._att_params:
+            if p.grad is None:
+                raise RuntimeError("fused steps need RowSparseAdam's flat gradient views on every dense parameter")
+
+    def _tower_input(self):
+        F, D = self.fe.shape[1], self.fe.shape[2]
+        self.xcat = torch.empty(self.B, 2 * F * D, dtype=torch.float32, device=self.fe.device)
+        self.g_xcat = torch.empty_like(self.xcat)
+        return self.xcat
+
+    def _tower_input_grad(self):
+        return self.g_xcat
+
+    def _gather_args(self) -> dict:
+        return dict(fm_out=self.fm, fm_sum=self.fm_sum)
+
+    def _interaction_forward(self):
+        from deepfm_amd.models.layers.attention import _AttnGemmFn
+        x = self.fe
+        self._ctxs = []
+        for block in self.blocks:
+            ctx = _Ctx()
+            x = _AttnGemmFn.forward(ctx, block, x, *block._param_list())
+            self._ctxs.append(ctx)
+        FD = self.fe.shape[1] * self.fe.shape[2]
+        # dnn_in = cat([attention(fe).flatten(1), flat], dim=1)   (attention_deepfm.py:57-61)
+        torch.cat([x.reshape(self.B, FD), self.fe.view(self.B, FD)], dim=1, out=self.xcat)
+        return self.fm
+
+    def _interaction_backward(self):
+        return None            # the first Linear stores its d input (B, 2 F D) as it is
+
+    def _finish_embedding_grad(self) -> None:
+        from deepfm_amd.models.layers.attention import _AttnGemmFn
+        B, F, D = self.fe.shape
+        FD = F * D
+        g = self.g_xcat[:, :FD].contiguous().view(B, F, D)          # d attention(fe)
+        grads: List[torch.Tensor] = []
+        for block, ctx in zip(reversed(self.blocks), reversed(self._ctxs)):
+            out = _AttnGemmFn.backward(ctx, g)
+            g = out[1]
+            grads = list(out[2:]) + grads
+        torch._foreach_add_([p.grad for p in self._att_params], [t.view_as(p) for t, p in zip(grads, self._att_params)])
+        _lib.check(_lib.load().dfm_embedding_grad_combine(
+            self.g_xcat.data_ptr() + FD * 4, 2 * FD, g.data_ptr(), self.g_logits.data_ptr(), self.fm_sum.data_ptr(),
+            self.fe.data_ptr(), B, F, D, self.g_fe.data_ptr(), _lib.stream_handle()))
+
+
 def fused_step_class(model):
     """The fused step that takes ``model``, or None (-> RowSparseTrainStep over autograd)."""
-    for cls in (FusedDeepFMStep, FusedXDeepFMStep):
+    for cls in (FusedDeepFMStep, FusedXDeepFMStep, FusedAttentionDeepFMStep):
         if cls.eligible(model):
             return cls
     return None

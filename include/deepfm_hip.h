@@ -248,6 +248,13 @@ int dfm_fm_forward(const float* d_field_emb, int64_t batch, int num_fields, int 
 /* d e[b,f,:] = g[b] * (S[b,:] - e[b,f,:]) */
 int dfm_fm_backward(const float* d_field_emb, const float* d_g_out, int64_t batch, int num_fields,
                     int dim, float* d_g_field, dfm_stream_t stream);
+/* d field_embeddings of a model with several consumers of the embeddings (attention_deepfm.py:48-66):
+ * out[b, :] = g_flat[b, :width] (row stride ld_flat floats: a slice of the DNN's d input)
+ *           + g_extra[b, :]                     (d from another layer, e.g. the attention stack; or NULL)
+ *           + g_fm[b] * (S[b, d] - e[b, f, d])  (FMInteraction backward, fm.py:18-23; or NULL). */
+int dfm_embedding_grad_combine(const float* d_g_flat, int64_t ld_flat, const float* d_g_extra, const float* d_g_fm,
+                               const float* d_fm_sum, const float* d_field_emb, int64_t batch, int num_fields, int dim,
+                               float* d_g_field, dfm_stream_t stream);
 
 /* Arithmetic of the matrix-core CIN path: 0 = bf16 x 3 split products (default; meets the 1e-4 bar
  * against cin.py:66-105), 1 = plain bf16 (throughput mode, its own looser tolerance), 2 = exact-fp32

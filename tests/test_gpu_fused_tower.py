@@ -426,3 +426,79 @@ def test_fused_xdeepfm_graph_replay_is_bitwise_equal_to_eager():
         results.append({k: npy(v).copy() for k, v in model.state_dict().items()})
     for k in results[0]:
         assert np.array_equal(results[0][k], results[1][k]), f"graph != eager: {k}"
+
+
+# ------------------------------------------------------------------ AttentionDeepFM on the fused tower
+def _small_attention_deepfm(seed=0, V=300, layers=1):
+    from deepfm_amd.config import ExperimentConfig
+    from deepfm_amd.models import create_model
+    from tests.helpers import schema_from_fields
+    from tools_shared import criteo_fields
+    fields = criteo_fields(V, 16)
+    cfg = ExperimentConfig()
+    cfg.dnn.hidden_units, cfg.dnn.dropout = [64, 32], 0.0
+    cfg.attention.num_heads, cfg.attention.attention_dim, cfg.attention.num_layers = 4, 32, layers
+    torch.manual_seed(seed)
+    model = create_model("attention_deepfm", schema_from_fields(fields), cfg).cuda().train()
+    model.embedding.set_grad_mode("rowsparse")
+    return fields, cfg, model
+
+
+@pytest.mark.parametrize("layers", [1, 2])
+def test_fused_attention_deepfm_step_matches_the_autograd_step(layers):
+    """FusedAttentionDeepFMStep against RowSparseTrainStep over autograd (whose forward and gradients are
+    pinned by the reference golden ``model_attention_deepfm``): Adam moments after one step, then losses."""
+    from deepfm_amd.training.fused_step import FusedAttentionDeepFMStep, fused_step_class
+    from deepfm_amd.training.rowsparse import RowSparseAdam
+    from deepfm_amd.training.step import RowSparseTrainStep
+    B = 600
+    rng = np.random.default_rng(51)
+    fields, _, _ = _small_attention_deepfm()
+    ids, dense, labels = _pool(fields, 4, B, rng)
+    runs = []
+    for fused in (False, True):
+        _, _, model = _small_attention_deepfm(seed=5, layers=layers)
+        opt = RowSparseAdam(model, lr=1e-3, l2=1e-5, max_grad_norm=1.0)
+        if fused:
+            assert fused_step_class(model) is FusedAttentionDeepFMStep
+        step = (FusedAttentionDeepFMStep if fused else RowSparseTrainStep)(model, opt, B, use_graph=False)
+        losses, snap = [], None
+        for i in range(4):
+            step.load_batch(torch.from_numpy(ids[i]).cuda(), torch.from_numpy(dense[i]).cuda(), torch.from_numpy(labels[i]).cuda())
+            step.run()
+            losses.append(float(step.loss))
+            if i == 0:
+                snap = dict(sq=float(opt.sq_norm), m=npy(opt.flat_m).copy(), tab=[npy(t).copy() for t in opt.exp_avg[:6]])
+        runs.append((losses, snap))
+    (l0, s0), (l1, s1) = runs
+    assert abs(s0["sq"] - s1["sq"]) < 1e-4 * s0["sq"]
+    assert_close(s1["m"], s0["m"], rtol=1e-4, atol_scale=2e-5, what="dense exp_avg after step 1")
+    for a, b in zip(s1["tab"], s0["tab"]):
+        assert_close(a, b, rtol=1e-4, atol_scale=2e-5, what="table exp_avg after step 1")
+    for a, b in zip(l1, l0):
+        assert abs(a - b) < 1e-4 * abs(b), (l1, l0)
+
+
+def test_fused_attention_deepfm_graph_replay_is_bitwise_equal_to_eager():
+    from deepfm_amd.training.fused_step import FusedAttentionDeepFMStep
+    from deepfm_amd.training.rowsparse import RowSparseAdam
+    B = 640
+    rng = np.random.default_rng(53)
+    fields, _, _ = _small_attention_deepfm()
+    ids, dense, labels = _pool(fields, 4, B, rng)
+    results = []
+    for use_graph in (False, True):
+        _, _, model = _small_attention_deepfm(seed=6)
+        opt = RowSparseAdam(model, lr=1e-3, l2=1e-5, max_grad_norm=1.0)
+        step = FusedAttentionDeepFMStep(model, opt, B, use_graph=use_graph)
+        start = copy.deepcopy(model.state_dict())
+        step.capture()
+        for k, v in model.state_dict().items():
+            assert torch.equal(v, start[k]), f"capture() changed {k}"
+        recs = step.pack_batches(torch.from_numpy(ids).cuda(), torch.from_numpy(dense).cuda(), torch.from_numpy(labels).cuda())
+        for i in range(4):
+            step.run_from(recs[i])
+        torch.cuda.synchronize()
+        results.append({k: npy(v).copy() for k, v in model.state_dict().items()})
+    for k in results[0]:
+        assert np.array_equal(results[0][k], results[1][k]), f"graph != eager: {k}"
