@@ -256,6 +256,17 @@ __device__ __forceinline__ int xcd_logical_index(int w, int total) {
   return (w % kXcds) * per + w / kXcds;
 }
 
+// The same for a group of workgroups that starts at dispatch index `first` (its members sit on XCD
+// (first + w) % 8): one launch that carries two kinds of work (d weight tiles, then d input tiles) must
+// spread EACH kind over all eight XCDs.  Mapping the whole grid at once put the first, long-running
+// kind on the first XCDs only: at out 256 x in 2496 the fused launch took 326 us against 65 + 69 us
+// for its two halves launched separately (tools/time_linear_bwd.py).
+__device__ __forceinline__ int xcd_logical_index_from(int w, int total, int first) {
+  const int per = total / kXcds;
+  if (w >= per * kXcds) return w;
+  return ((w + first) % kXcds) * per + w / kXcds;
+}
+
 // Host side: branch-free tile loads need all-or-nothing 16-byte pieces (see load_slice).
 static inline bool operand_fast(const float* p, int64_t ld, bool kc, int rows, int kdim) {
   return (reinterpret_cast<uintptr_t>(p) & 15) == 0 && ld % 4 == 0 && (kc ? kdim % 4 == 0 : rows % 4 == 0);

@@ -448,7 +448,9 @@ __global__ __launch_bounds__(kThreads) void linear_bwd_kernel(
   __shared__ Smem sm;
   const TilePos pos;
   f32x16 acc = {};
-  const int bid = xcd_logical_index(blockIdx.x, gridDim.x);
+  const int wg = blockIdx.x;
+  const int bid = wg < dw_blocks ? xcd_logical_index(wg, dw_blocks)
+                                 : dw_blocks + xcd_logical_index_from(wg - dw_blocks, static_cast<int>(gridDim.x) - dw_blocks, dw_blocks);
   if (bid < dw_blocks) {
     // ---- dW (N x K) = sum over the batch: A = dz (k-strided), B = x (k-strided) ----
     const int tile = bid % dw_tiles, sp = bid / dw_tiles;
