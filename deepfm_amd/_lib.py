@@ -146,6 +146,7 @@ SIGNATURES = {
                             _L, _I, _P]),
     "dfm_fm_forward": (_I, [_P, _L, _I, _I, _P, _P]),
     "dfm_fm_backward": (_I, [_P, _P, _L, _I, _I, _P, _P]),
+    "dfm_copy_2d": (_I, [_P, _L, _P, _L, _L, _I, _P]),
     "dfm_embedding_grad_combine": (_I, [_P, _L, _P, _P, _P, _P, _L, _I, _I, _P, _P]),
 }
 

@@ -114,6 +114,18 @@ __global__ __launch_bounds__(256) void embedding_grad_combine_kernel(
   st4(out + r * width + c, v);
 }
 
+// (rows x width) block copy between row-strided buffers, 16 bytes per lane: slices of the DNN's input /
+// d input (attention_deepfm.py:57-61 concatenates two (B, F*D) halves) without torch's generic strided copy.
+__global__ __launch_bounds__(256) void copy_2d_kernel(const float* __restrict__ src, int64_t ld_src,
+                                                      float* __restrict__ dst, int64_t ld_dst, int64_t rows, int width) {
+  const int w4 = width / 4;
+  const int64_t t = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (t >= rows * w4) return;
+  const int64_t r = t / w4;
+  const int c = static_cast<int>(t % w4) * 4;
+  st4(dst + r * ld_dst + c, ld4(src + r * ld_src + c));
+}
+
 static int pow2_at_least(int x) {
   int p = 1;
   while (p < x) p <<= 1;
@@ -171,6 +183,21 @@ int dfm_embedding_grad_combine(const float* d_g_flat, int64_t ld_flat, const flo
   hipLaunchKernelGGL(embedding_grad_combine_kernel, dim3(static_cast<unsigned>((threads + 255) / 256)), dim3(256), 0,
                      as_stream(stream), d_g_flat, ld_flat, d_g_extra, d_g_fm, d_fm_sum, d_field_emb, batch, width, dim,
                      d_g_field);
+  DFM_LAUNCH_CHECK();
+  return DFM_OK;
+}
+
+int dfm_copy_2d(const float* d_src, int64_t ld_src, float* d_dst, int64_t ld_dst, int64_t rows, int width,
+                dfm_stream_t stream) {
+  DFM_REQUIRE(d_src && d_dst, "null argument");
+  DFM_REQUIRE(rows >= 0 && width > 0 && width % 4 == 0 && ld_src >= width && ld_dst >= width && ld_src % 4 == 0 &&
+              ld_dst % 4 == 0, "bad shape (width and leading dimensions must be multiples of 4)");
+  DFM_REQUIRE((reinterpret_cast<uintptr_t>(d_src) & 15) == 0 && (reinterpret_cast<uintptr_t>(d_dst) & 15) == 0,
+              "16-byte aligned buffers only");
+  if (rows == 0) return DFM_OK;
+  const int64_t threads = rows * (width / 4);
+  hipLaunchKernelGGL(copy_2d_kernel, dim3(static_cast<unsigned>((threads + 255) / 256)), dim3(256), 0, as_stream(stream),
+                     d_src, ld_src, d_dst, ld_dst, rows, width);
   DFM_LAUNCH_CHECK();
   return DFM_OK;
 }

@@ -360,6 +360,7 @@ class FusedAttentionDeepFMStep(_FusedTowerStep):
         F, D = self.fe.shape[1], self.fe.shape[2]
         self.xcat = torch.empty(self.B, 2 * F * D, dtype=torch.float32, device=self.fe.device)
         self.g_xcat = torch.empty_like(self.xcat)
+        self.g_att = torch.empty(self.B, F * D, dtype=torch.float32, device=self.fe.device)
         return self.xcat
 
     def _tower_input_grad(self):
@@ -377,8 +378,10 @@ class FusedAttentionDeepFMStep(_FusedTowerStep):
             x = _AttnGemmFn.forward(ctx, block, x, *block._param_list())
             self._ctxs.append(ctx)
         FD = self.fe.shape[1] * self.fe.shape[2]
+        lib, st = _lib.load(), _lib.stream_handle()
         # dnn_in = cat([attention(fe).flatten(1), flat], dim=1)   (attention_deepfm.py:57-61)
-        torch.cat([x.reshape(self.B, FD), self.fe.view(self.B, FD)], dim=1, out=self.xcat)
+        _lib.check(lib.dfm_copy_2d(x.data_ptr(), FD, self.xcat.data_ptr(), 2 * FD, self.B, FD, st))
+        _lib.check(lib.dfm_copy_2d(self.fe.data_ptr(), FD, self.xcat.data_ptr() + FD * 4, 2 * FD, self.B, FD, st))
         return self.fm
 
     def _interaction_backward(self):
@@ -388,7 +391,8 @@ class FusedAttentionDeepFMStep(_FusedTowerStep):
         from deepfm_amd.models.layers.attention import _AttnGemmFn
         B, F, D = self.fe.shape
         FD = F * D
-        g = self.g_xcat[:, :FD].contiguous().view(B, F, D)          # d attention(fe)
+        g = self.g_att.view(B, F, D)                                # d attention(fe): first half of d dnn_in
+        _lib.check(_lib.load().dfm_copy_2d(self.g_xcat.data_ptr(), 2 * FD, g.data_ptr(), FD, B, FD, _lib.stream_handle()))
         grads: List[torch.Tensor] = []
         for block, ctx in zip(reversed(self.blocks), reversed(self._ctxs)):
             out = _AttnGemmFn.backward(ctx, g)

@@ -255,6 +255,10 @@ int dfm_fm_backward(const float* d_field_emb, const float* d_g_out, int64_t batc
 int dfm_embedding_grad_combine(const float* d_g_flat, int64_t ld_flat, const float* d_g_extra, const float* d_g_fm,
                                const float* d_fm_sum, const float* d_field_emb, int64_t batch, int num_fields, int dim,
                                float* d_g_field, dfm_stream_t stream);
+/* dst[r, :width] = src[r, :width] for r < rows, row strides ld_src / ld_dst floats (slices of the
+ * concatenated DNN input of attention_deepfm.py:57-61 and of its gradient). */
+int dfm_copy_2d(const float* d_src, int64_t ld_src, float* d_dst, int64_t ld_dst, int64_t rows, int width,
+                dfm_stream_t stream);
 
 /* Arithmetic of the matrix-core CIN path: 0 = bf16 x 3 split products (default; meets the 1e-4 bar
  * against cin.py:66-105), 1 = plain bf16 (throughput mode, its own looser tolerance), 2 = exact-fp32
