@@ -55,8 +55,11 @@ def parse():
     ap.add_argument("--no-extra-configs", action="store_true",
                     help="skip BASELINE.json configurations 3 and 4 (xDeepFM / AttentionDeepFM) after the headline")
     ap.add_argument("--extra-steps", type=int, default=60, help="timed steps of each extra configuration")
-    ap.add_argument("--timing-stride", type=int, default=8,
-                    help="the gather is timed (eagerly launched, events on the dispatch) on every n-th step of the timed region")
+    ap.add_argument("--timing-every", type=int, default=3,
+                    help="one launch in n of the timed region is a single step whose gather is launched eagerly with HIP "
+                         "events on the dispatch (the others are graph launches of --steps-per-graph steps)")
+    ap.add_argument("--steps-per-graph", type=int, default=4,
+                    help="consecutive training steps captured in one HIP graph (1 under data parallelism)")
     ap.add_argument("--gather-shape", type=int, default=0,
                     help="tuning aid: force a launch shape of the gather (dfm_gather_set_shape); 0 = automatic")
     ap.add_argument("--h2d", action="store_true",
@@ -176,17 +179,18 @@ def extra_config(name, args, dev, lib):
     cin_sizes = [128, 128, 128] if name == "xdeepfm" else None
     model, opt, step, fields, cfg, hp, fused = build_step(name, V, D, B, dev, args, cin_sizes)
     n_sparse, n_dense = 26, 13
-    warm, steps = 10, args.extra_steps
+    G = 1 if args.no_graph else args.steps_per_graph
+    warm, steps = -(-10 // G) * G, max(args.extra_steps // G, 1) * G                   # whole graph launches
     ids, dense, labels = make_pool(warm + steps, n_sparse, n_dense, B, V, 101, dev)     # every batch used once
     records = step.pack_batches(ids, dense, labels)
     step.load_packed(records[0])
-    step.capture()
-    for i in range(warm):
-        step.run_from(records[i])
+    step.capture(steps_per_graph=G)
+    for i in range(0, warm, G):
+        step.run_group([records[i + k] for k in range(G)])
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(warm, warm + steps):
-        step.run_from(records[i])
+    for i in range(warm, warm + steps, G):
+        step.run_group([records[i + k] for k in range(G)])
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     out = {
@@ -194,7 +198,8 @@ def extra_config(name, args, dev, lib):
                      f"vocab, {n_dense} dense, embed_dim {D}, batch {B}"
                      + (f", cin.layer_sizes={cin_sizes}" if cin_sizes else f", attention.num_heads={cfg.attention.num_heads}")),
         "ms_per_step": el / steps * 1e3, "samples_per_s": steps * B / el, "steps": steps, "warmup": warm,
-        "step": type(step).__name__, "hip_graph": not args.no_graph, "final_loss": float(step.loss.item()),
+        "step": type(step).__name__, "hip_graph": not args.no_graph, "steps_per_graph": G,
+        "final_loss": float(step.loss.item()),
     }
     # ---- the interaction layer alone, at the step's shapes, on this stream
     fe = step.fe.detach().clone().requires_grad_()
@@ -281,7 +286,7 @@ def main():
     ids, dense, labels = make_pool(total, n_sparse, n_dense, B, V, 1 + rank, dev)
     records = step.pack_batches(ids, dense, labels)      # one record per batch, resident in HBM
     step.load_packed(records[0])
-    step.capture(timed_variant=True)
+    step.capture(timed_variant=True, steps_per_graph=1 if (world > 1 or args.no_graph) else args.steps_per_graph)
 
     feed = None
     if args.h2d:
@@ -293,28 +298,52 @@ def main():
         loader = PackedBatchLoader(PackedColumns(model.schema, feats, labels.reshape(-1).cpu().numpy()), B)
         feed = iter(DeviceBatchRing(loader, dev, depth=4))
 
-    def run(i, timed):
-        # the gather reads batch i from its record and refreshes the step's static inputs on the way
-        step.run_from(next(feed) if feed is not None else records[i], eager_gather=timed and not args.no_graph)
+    G = step.steps_per_graph if not args.no_graph else 1
 
-    for i in range(args.warmup):
-        run(i, False)
+    def rec(i):
+        return next(feed) if feed is not None else records[i]
+
+    def plan(lo, hi, timing):
+        """How steps lo..hi-1 are launched: ('group', i) = steps i..i+G-1 in ONE graph launch; ('timed', i) /
+        ('single', i) = one step with the gather launched eagerly in front of the gather-less copy of the
+        graph (the only place HIP events can be attached to its dispatch).  With timing on, one timed
+        single step opens every cycle of `timing_every` launches; leftovers (hi - lo not a multiple of G)
+        run as single steps."""
+        out, i, launch = [], lo, 0
+        while i < hi:
+            if args.no_graph:
+                out.append(("timed" if timing else "single", i)); i += 1
+            elif timing and launch % args.timing_every == 0:
+                out.append(("timed", i)); i += 1
+            elif i + G <= hi:
+                out.append(("group", i)); i += G
+            else:
+                out.append(("single", i)); i += 1
+            launch += 1
+        return out
+
+    def execute(p):
+        for kind, i in p:
+            if kind == "group":
+                step.run_group([rec(i + k) for k in range(G)]) if G > 1 else step.run_from(rec(i))
+            else:
+                step.run_from(rec(i), eager_gather=not args.no_graph)
+
+    execute(plan(0, args.warmup, False))
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    # The gather runs inside the step's graph.  Every `stride`-th step of the timed region launches it eagerly
-    # instead, in front of a gather-less copy of the graph, with HIP start/stop events attached to the
-    # dispatch (hipExtLaunchKernel): the same kernel, arguments and position in the step, timed like
-    # rocprofv3's kernel trace times it.  (--no-graph: every step is eager and timed.)
+    # The gather is a node of the step's graph.  Once per `timing_every` launches of the timed region a step
+    # launches it eagerly instead, in front of a gather-less copy of the graph, with HIP start/stop events
+    # attached to the dispatch (hipExtLaunchKernel): the same kernel, arguments and position in the step,
+    # timed like rocprofv3's kernel trace times it.  (--no-graph: every step is eager and timed.)
     timing = not args.no_gather_timing
-    stride = 1 if args.no_graph else args.timing_stride
-    timed_steps = [i for i in range(args.warmup, total) if timing and (i - args.warmup) % stride == 0]
-    if timed_steps:
-        _lib.check(lib.dfm_gather_timing_begin(len(timed_steps)))
-    timed_set = set(timed_steps)
+    timed_plan = plan(args.warmup, total, timing)
+    n_timed = sum(1 for kind, _ in timed_plan if kind == "timed")
+    if n_timed:
+        _lib.check(lib.dfm_gather_timing_begin(n_timed))
     t0 = time.perf_counter()
-    for i in range(args.warmup, total):
-        run(i, i in timed_set)
+    execute(timed_plan)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -325,11 +354,11 @@ def main():
         elapsed = float(t.item())
     loss = float(step.loss.item())
 
-    us = (C.c_float * max(len(timed_steps), 1))()
-    n_timed = C.c_int(0)
-    if timed_steps:
-        _lib.check(lib.dfm_gather_timing_end(us, len(timed_steps), C.byref(n_timed)))
-    gather_us = [float(us[i]) for i in range(n_timed.value)]
+    us = (C.c_float * max(n_timed, 1))()
+    got = C.c_int(0)
+    if n_timed:
+        _lib.check(lib.dfm_gather_timing_end(us, n_timed, C.byref(got)))
+    gather_us = [float(us[i]) for i in range(got.value)]
     gather_avg_s = (sum(gather_us) / len(gather_us)) * 1e-6 if gather_us else float("nan")
     algo_bytes = gather_bytes_per_sample(n_sparse, n_dense, D) * B
     achieved = algo_bytes / gather_avg_s / 1e9 if gather_us else None
@@ -360,6 +389,7 @@ def main():
                 "global_batch": B * world,
                 "parallelism": f"dp{world}",
                 "hip_graph": not args.no_graph,
+                "steps_per_graph": G,
                 "input": "host memory -> pinned staging -> H2D ring (PCIe-inclusive)" if args.h2d else "resident in HBM",
                 "step": "fused tower kernels (no autograd)" if fused else "torch.autograd over the HIP ops",
                 **({"rehearsal": "gloo, all ranks on cuda:0 (not a measurement)"} if rehearsal else {}),
@@ -381,9 +411,9 @@ def main():
                 "avg_launch_us": gather_avg_s * 1e6 if gather_us else None,
                 "min_launch_us": min(gather_us) if gather_us else None,
                 "launches_timed": len(gather_us),
-                "timer": f"HIP start/stop events attached to the gather dispatch (hipExtLaunchKernel, on the launch stream) on "
-                         f"every {stride}-th step of the timed region; on those steps the gather is launched eagerly in front of "
-                         "a gather-less copy of the step's graph, on all others it is a node of the graph",
+                "timer": f"HIP start/stop events attached to the gather dispatch (hipExtLaunchKernel, on the launch stream): one launch "
+                         f"in {args.timing_every} of the timed region is a single step whose gather is launched eagerly in front of a "
+                         f"gather-less copy of the step's graph; the other launches are graphs of {G} step(s) with the gather as a node",
                 "rocprof": pmc,
             },
         }

@@ -42,11 +42,11 @@ from deepfm_amd.training.rowsparse import RowSparseAdam
 
 
 class _GraphSlot:
-    """One instantiated copy of graph A: exec + the gather's kernel node."""
+    """One instantiated copy of graph A: exec + the gather kernel node of every step it holds."""
 
     def __init__(self) -> None:
         self.graph: Optional[torch.cuda.CUDAGraph] = None
-        self.node = C.c_void_p()
+        self.nodes: List[C.c_void_p] = []
         self.done: Optional[torch.cuda.Event] = None      # recorded after the slot's latest launch
 
 
@@ -95,6 +95,7 @@ class RowSparseTrainStep:
         self.use_graph = use_graph
         self.side = torch.cuda.Stream(device=dev)   # row plan on a side stream (DFM_ROWPLAN_SIDE_STREAM=1 only)
         self.slots: List[_GraphSlot] = []
+        self.steps_per_graph = 1
         self._turn = 0
         self.graph_b: Optional[torch.cuda.CUDAGraph] = None
         self.body_graph: Optional[torch.cuda.CUDAGraph] = None     # graph A without the gather (timed variant)
@@ -195,9 +196,11 @@ class RowSparseTrainStep:
         ts += list(self.model.buffers())
         return ts
 
-    def capture(self, warmup_iters: int = 1, timed_variant: bool = False) -> None:
+    def capture(self, warmup_iters: int = 1, timed_variant: bool = False, steps_per_graph: int = 1) -> None:
         """Capture the step's graphs after ``warmup_iters`` eager steps (``timed_variant``: also a copy of
-        graph A without the gather, for ``run(eager_gather=True)``).  Side-effect free: the warm-up
+        graph A without the gather, for ``run(eager_gather=True)``; ``steps_per_graph`` > 1: that many
+        consecutive steps in one graph, launched with ``run_group`` — back-to-back graph launches are
+        ~14 us apart on the device, whatever they contain).  Side-effect free: the warm-up
         steps run on an all-padding batch (id 0 everywhere: no table row receives a gradient, so the
         row-wise Adam touches nothing) and every other piece of state a step writes — dense parameters,
         Adam moments, step count, dropout seed, BatchNorm running statistics, the static inputs — is
@@ -231,6 +234,9 @@ class RowSparseTrainStep:
             if single or fused_exchange:
                 self.opt.exchange()          # one rank: no device work, selects the local row lists
                 self._body_b()
+        if steps_per_graph < 1 or (steps_per_graph > 1 and not single and not fused_exchange):
+            raise ValueError("steps_per_graph > 1 needs the whole step inside one graph (one rank, or the in-graph exchange)")
+        self.steps_per_graph = steps_per_graph
         self.slots = []
         for _ in range(2):
             slot = _GraphSlot()
@@ -238,9 +244,12 @@ class RowSparseTrainStep:
             # hipGraphExecKernelNodeSetParams on the exec instantiated from it
             slot.graph = torch.cuda.CUDAGraph(keep_graph=True)
             with torch.cuda.graph(slot.graph, **mode):
-                self._gather(self.pad)
-                _lib.check(lib.dfm_graph_last_node(_lib.stream_handle(), C.byref(slot.node)))
-                body()
+                for _k in range(steps_per_graph):
+                    self._gather(self.pad)
+                    node = C.c_void_p()
+                    _lib.check(lib.dfm_graph_last_node(_lib.stream_handle(), C.byref(node)))
+                    slot.nodes.append(node)
+                    body()
             slot.graph.instantiate()
             self.slots.append(slot)
         if timed_variant:
@@ -281,18 +290,40 @@ class RowSparseTrainStep:
                 raise RuntimeError("run(eager_gather=True) needs capture(timed_variant=True)")
             self._gather()                 # eager: dfm_gather_timing_begin may attach events to this dispatch
             self.body_graph.replay()
-            done = None
+            self._after_graph_a(None)
+            return
+        if self.steps_per_graph != 1:
+            raise RuntimeError(f"the graphs hold {self.steps_per_graph} steps each: use run_group()")
+        self._launch([self._record])
+
+    def run_group(self, records) -> None:
+        """``steps_per_graph`` consecutive steps, one graph launch: ``records[k]`` is step k's batch record."""
+        if len(records) != self.steps_per_graph:
+            raise ValueError(f"run_group expects {self.steps_per_graph} records")
+        if not self.slots:
+            for r in records:
+                self.run_from(r)
+            return
+        for r in records:
+            if r.numel() != self.packed_bytes or r.dtype != torch.uint8 or not r.is_contiguous() or r.data_ptr() % 16:
+                raise ValueError("run_group expects contiguous, 16-byte aligned pack_batches() records")
+        self._launch(list(records))
+
+    def _launch(self, records) -> None:
+        slot = self.slots[self._turn]
+        self._turn ^= 1
+        if slot.done is not None:
+            slot.done.synchronize()        # its previous launch (two launches ago) has left the device
         else:
-            slot = self.slots[self._turn]
-            self._turn ^= 1
-            if slot.done is not None:
-                slot.done.synchronize()    # its previous launch (two steps ago) has left the device
-            else:
-                slot.done = torch.cuda.Event()
-            a, kw = self._gather_call(self._record)
-            self.emb.forward_staged_update(slot.graph.raw_cuda_graph_exec(), slot.node, *a, **kw)
-            slot.graph.replay()
-            done = slot.done
+            slot.done = torch.cuda.Event()
+        ex = slot.graph.raw_cuda_graph_exec()
+        for node, rec in zip(slot.nodes, records):
+            a, kw = self._gather_call(rec)
+            self.emb.forward_staged_update(ex, node, *a, **kw)
+        slot.graph.replay()
+        self._after_graph_a(slot.done)
+
+    def _after_graph_a(self, done) -> None:
         if self.graph_b is not None:
             # the replay produced the row gradients; the Python-side flag was only set while
             # the graph was being captured

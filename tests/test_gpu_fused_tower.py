@@ -316,13 +316,24 @@ def test_graph_node_updates_and_eager_gather_variant_are_bitwise_equal_to_eager(
     fields = criteo_fields(300, 16)
     ids, dense, labels = _pool(fields, n, B, rng)
     results = []
-    for mode in ("eager", "graph", "mixed"):
+    for mode in ("eager", "graph", "mixed", "groups"):
         _, _, model, hp, opt, Step = _fused_pair(B, seed=8)
         step = Step(model, opt, B, use_graph=mode != "eager")
         recs = step.pack_batches(torch.from_numpy(ids).cuda(), torch.from_numpy(dense).cuda(), torch.from_numpy(labels).cuda())
-        step.capture(timed_variant=True)
+        step.capture(timed_variant=True, steps_per_graph=3 if mode == "groups" else 1)
         losses = []
-        for i in range(n):
+        if mode == "groups":
+            # three steps per graph launch (run_group), a single eager-gather step in between
+            assert step.steps_per_graph == 3
+            with pytest.raises(RuntimeError):
+                step.run_from(recs[0])
+            step.run_group([recs[0], recs[1], recs[2]])
+            losses.append(step.loss.clone())
+            step.run_from(recs[3], eager_gather=True)
+            losses.append(step.loss.clone())
+            step.run_group([recs[4], recs[5], recs[6]])
+            losses.append(step.loss.clone())
+        for i in range(n if mode != "groups" else 0):
             if mode == "mixed" and i % 3 == 1:
                 step.run_from(recs[i], eager_gather=True)
             else:
@@ -331,8 +342,10 @@ def test_graph_node_updates_and_eager_gather_variant_are_bitwise_equal_to_eager(
         torch.cuda.synchronize()
         assert torch.equal(step.ids, torch.from_numpy(ids[n - 1]).cuda())      # static inputs: the last batch
         results.append(({k: npy(v).copy() for k, v in model.state_dict().items()}, [float(l) for l in losses]))
-    for other in results[1:]:
-        assert other[1] == results[0][1], "losses differ"
+    ref_losses = results[0][1]
+    for mode, other in zip(("graph", "mixed", "groups"), results[1:]):
+        want = ref_losses if mode != "groups" else [ref_losses[2], ref_losses[3], ref_losses[6]]
+        assert other[1] == want, f"{mode}: losses differ"
         for k in results[0][0]:
             assert np.array_equal(other[0][k], results[0][0][k]), k
 
