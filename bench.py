@@ -179,7 +179,7 @@ def extra_config(name, args, dev, lib):
     cin_sizes = [128, 128, 128] if name == "xdeepfm" else None
     model, opt, step, fields, cfg, hp, fused = build_step(name, V, D, B, dev, args, cin_sizes)
     n_sparse, n_dense = 26, 13
-    G = 1 if args.no_graph else args.steps_per_graph
+    G = 1 if (args.no_graph or opt.split) else args.steps_per_graph
     warm, steps = -(-10 // G) * G, max(args.extra_steps // G, 1) * G                   # whole graph launches
     ids, dense, labels = make_pool(warm + steps, n_sparse, n_dense, B, V, 101, dev)     # every batch used once
     records = step.pack_batches(ids, dense, labels)
@@ -286,7 +286,9 @@ def main():
     ids, dense, labels = make_pool(total, n_sparse, n_dense, B, V, 1 + rank, dev)
     records = step.pack_batches(ids, dense, labels)      # one record per batch, resident in HBM
     step.load_packed(records[0])
-    step.capture(timed_variant=True, steps_per_graph=1 if (world > 1 or args.no_graph) else args.steps_per_graph)
+    # several steps per graph need the whole step inside ONE graph: one rank without the split exchange path
+    spg = 1 if (opt.split or args.no_graph) else args.steps_per_graph
+    step.capture(timed_variant=True, steps_per_graph=spg)
 
     feed = None
     if args.h2d:

@@ -9,7 +9,7 @@
 //     64/(D/4) consecutive samples, a wave US sparse + UD dense fields of them per pass, so ids are
 //     read as one coalesced line and rows as 16-byte pieces, ALL loads of a pass in flight at once
 //     (the kernel is one dependent chain kernarg -> ids -> rows -> stores; round-2 stamps:
-//     profiles/r02_gather_microbench.txt).  field_embeddings is written with non-temporal stores.
+//     profiles/r02_gather_microbench.txt).
 //     first_order and the FM value are reduced across the block's waves through LDS in a fixed
 //     order (W == 1: no LDS, no barrier).
 //   * emb_fwd_general — any schema (mixed dims, projections, SEQUENCE bags): one thread
@@ -71,8 +71,9 @@ struct UniformArgs {
 };
 
 typedef float v4f __attribute__((ext_vector_type(4)));
-// field_embeddings is consumed by later kernels, never re-read here: streaming (nt) stores keep it from
-// displacing the XCD's L2 contents and shorten the end-of-kernel write-back (-0.8 us at B = 4096)
+// Streaming (nt) stores of field_embeddings: -0.8 us for the isolated kernel (tools/microbench_gather2), but
+// inside the training step they cost 0.4-1.2 us and 3.7 MB of extra write requests (the consumer is the next
+// kernel of the graph) — the product kernel stores plainly; shape 6 keeps the nt variant for the tools.
 __device__ __forceinline__ void st4_stream(float* p, const float4& v) {
   v4f t = {v.x, v.y, v.z, v.w};
   __builtin_nontemporal_store(t, reinterpret_cast<v4f*>(p));
@@ -163,7 +164,7 @@ __device__ __forceinline__ void emb_fwd_uniform_body(
       SQ.x = fmaf(m * e.x, e.x, SQ.x); SQ.y = fmaf(m * e.y, e.y, SQ.y);
       SQ.z = fmaf(m * e.z, e.z, SQ.z); SQ.w = fmaf(m * e.w, e.w, SQ.w);
       fo = fmaf(m, w1v[u], fo);
-      if (live && oks[u]) st4_stream(out + sl[u].field * D, e);
+      if (live && oks[u]) st4(out + sl[u].field * D, e);
     }
 #pragma unroll
     for (int u = 0; u < UD; ++u) {
@@ -175,7 +176,7 @@ __device__ __forceinline__ void emb_fwd_uniform_body(
       SQ.x = fmaf(m * e.x, e.x, SQ.x); SQ.y = fmaf(m * e.y, e.y, SQ.y);
       SQ.z = fmaf(m * e.z, e.z, SQ.z); SQ.w = fmaf(m * e.w, e.w, SQ.w);
       fo = fmaf(m, fmaf(x[u], dw1[u], db1[u]), fo);
-      if (live && okd[u]) st4_stream(out + dl[u].field * D, e);
+      if (live && okd[u]) st4(out + dl[u].field * D, e);
     }
   }
   if (bad && error_flag) atomicOr(error_flag, 1);
@@ -217,7 +218,7 @@ __device__ __forceinline__ void emb_fwd_uniform_body(
 // its use (staging is a template flag), and all of a wave's loads are in flight in three rounds:
 // ids + dense values -> rows + first-order scalars + dense weights -> math + streaming stores.
 // Measured against the 8-wave shape on the same tables: profiles/r02_gather_shapes.csv.
-template <int D, int NS, int ND, bool STAGE, int WAVE>
+template <int D, int NS, int ND, bool STAGE, int WAVE, bool NT>
 __device__ __forceinline__ void emb_fwd_pair_wave(
     const UniformArgs& args, int64_t B, int F, float* __restrict__ fe, int32_t* error_flag, float (&acc)[9]) {
   constexpr int LPR = D / 4;
@@ -272,7 +273,7 @@ __device__ __forceinline__ void emb_fwd_pair_wave(
     SQ.x = fmaf(e.x, e.x, SQ.x); SQ.y = fmaf(e.y, e.y, SQ.y);
     SQ.z = fmaf(e.z, e.z, SQ.z); SQ.w = fmaf(e.w, e.w, SQ.w);
     fo += w1v[u];
-    if (live) st4_stream(out + args.sp[2 * u + WAVE].field * D, e);
+    if (live) { if (NT) st4_stream(out + args.sp[2 * u + WAVE].field * D, e); else st4(out + args.sp[2 * u + WAVE].field * D, e); }
   }
 #pragma unroll
   for (int u = 0; u < HD; ++u) {
@@ -283,7 +284,7 @@ __device__ __forceinline__ void emb_fwd_pair_wave(
     SQ.x = fmaf(e.x, e.x, SQ.x); SQ.y = fmaf(e.y, e.y, SQ.y);
     SQ.z = fmaf(e.z, e.z, SQ.z); SQ.w = fmaf(e.w, e.w, SQ.w);
     fo += fmaf(x[u], dw1[u], db1[u]);
-    if (live) st4_stream(out + args.de[2 * u + WAVE].field * D, e);
+    if (live) { if (NT) st4_stream(out + args.de[2 * u + WAVE].field * D, e); else st4(out + args.de[2 * u + WAVE].field * D, e); }
   }
   if (bad && error_flag) atomicOr(error_flag, 1);
   if (q != 0) fo = 0.f;
@@ -291,7 +292,7 @@ __device__ __forceinline__ void emb_fwd_pair_wave(
   acc[4] = SQ.x; acc[5] = SQ.y; acc[6] = SQ.z; acc[7] = SQ.w; acc[8] = fo;
 }
 
-template <int D, int NS, int ND, bool STAGE>
+template <int D, int NS, int ND, bool STAGE, bool NT = false>
 __global__ __launch_bounds__(128) void emb_fwd_pair(
     UniformArgs args, int64_t B, int F, float* __restrict__ first_order, float* __restrict__ fe,
     float* __restrict__ fm_out, float* __restrict__ fm_sum, int32_t* error_flag,
@@ -302,13 +303,13 @@ __global__ __launch_bounds__(128) void emb_fwd_pair(
   const int lane = lane_id();
   float acc[9];
   if (wave_id_uniform() == 1) {
-    emb_fwd_pair_wave<D, NS, ND, STAGE, 1>(args, B, F, fe, error_flag, acc);
+    emb_fwd_pair_wave<D, NS, ND, STAGE, 1, NT>(args, B, F, fe, error_flag, acc);
 #pragma unroll
     for (int c = 0; c < 9; ++c) red[c][lane] = acc[c];
     __syncthreads();
     return;
   }
-  emb_fwd_pair_wave<D, NS, ND, STAGE, 0>(args, B, F, fe, error_flag, acc);
+  emb_fwd_pair_wave<D, NS, ND, STAGE, 0, NT>(args, B, F, fe, error_flag, acc);
   __syncthreads();
 #pragma unroll
   for (int c = 0; c < 9; ++c) acc[c] += red[c][lane];      // fixed order: wave 0 + wave 1
@@ -649,9 +650,10 @@ int g_gather_shape = 0;   // 0 = automatic; tools only (dfm_gather_set_shape)
 //   3: W = 4,  8 + 4
 //   4: W = 8,  4 + 2  (round 1's shape; more slots than a pass holds simply take more passes)
 //   5: emb_fwd_pair — two waves, compile-time field counts (26 SPARSE + 13 DENSE, D = 16 / 32)
+//   6: shape 5 with streaming stores
 // Automatic choice: 5 where it applies, else 4.  Shapes 1-3 exist for tools/time_gather.py.
 extern "C" int dfm_gather_set_shape(int shape) {
-  DFM_REQUIRE(shape >= 0 && shape <= 5, "gather shape %d outside [0, 5]", shape);
+  DFM_REQUIRE(shape >= 0 && shape <= 6, "gather shape %d outside [0, 6]", shape);
   g_gather_shape = shape;
   return DFM_OK;
 }
@@ -708,7 +710,8 @@ static int describe_uniform(const dfm_embedding_plan* plan, const PtrTable& in, 
   const bool pair_ok = (D == 16 || D == 32) && ns == 26 && nd == 13;
   if (shape == 0) shape = pair_ok ? 5 : 4;
   if (shape == 5 && !pair_ok) shape = 4;
-  g->pair = shape == 5;
+  if (shape == 6 && !pair_ok) shape = 4;
+  g->pair = shape == 5 || shape == 6;
 #define DFM_UNIFORM_KERNEL(WV, US_, UD_)                                               \
   do {                                                                                 \
     g->func = reinterpret_cast<const void*>(&emb_fwd_uniform<D, WV, US_, UD_>);        \
@@ -722,6 +725,13 @@ static int describe_uniform(const dfm_embedding_plan* plan, const PtrTable& in, 
       if constexpr (D == 16 || D == 32) {
         g->func = stage_out ? reinterpret_cast<const void*>(&emb_fwd_pair<D, 26, 13, true>)
                             : reinterpret_cast<const void*>(&emb_fwd_pair<D, 26, 13, false>);
+        g->block = dim3(128);
+      }
+      break;
+    case 6:     // shape 5 with streaming (nt) stores of field_embeddings
+      if constexpr (D == 16 || D == 32) {
+        g->func = stage_out ? reinterpret_cast<const void*>(&emb_fwd_pair<D, 26, 13, true, true>)
+                            : reinterpret_cast<const void*>(&emb_fwd_pair<D, 26, 13, false, true>);
         g->block = dim3(128);
       }
       break;

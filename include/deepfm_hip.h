@@ -140,7 +140,8 @@ int dfm_gather_timing_end(float* h_us, int capacity, int* h_count);
 /* Launch shape of the uniform gather (tuning aid, tools/time_gather.py): 0 = automatic (default),
  * 1 = one wave owns its samples across all fields (26 sparse + 13 dense slots in flight, no LDS),
  * 2 = 2 waves x (13 + 7), 3 = 4 waves x (8 + 4), 4 = 8 waves x (4 + 2), 5 = the two-wave kernel with
- * compile-time slot indices (the automatic choice where it applies).  Every shape computes the
+ * compile-time slot indices (the automatic choice where it applies), 6 = shape 5 with streaming stores.
+ * Every shape computes the
  * same values (bitwise for the gathered rows); only the work split inside a workgroup changes. */
 int dfm_gather_set_shape(int shape);
 
