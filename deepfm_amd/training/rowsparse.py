@@ -227,6 +227,26 @@ class RowSparseAdam:
                           "max_grad_norm": self.max_grad_norm}}
 
     def load_state_dict(self, sd: dict) -> None:
+        """This optimizer's own ``state_dict()``, or a ``torch.optim.Adam.state_dict()`` over
+        ``model.parameters()`` — what the reference's trainer writes as ``optimizer_state_dict``
+        (trainer.py:140-148; position-keyed ``state`` + ``param_groups``): moments are matched to
+        parameters by position in ``model.named_parameters()``; parameters torch never stepped get zeros."""
+        if "param_groups" in sd:
+            names = [n for n, _ in self.model.named_parameters()]
+            order = [i for g in sd["param_groups"] for i in g["params"]]
+            if len(order) != len(names):
+                raise KeyError(f"torch optimizer state covers {len(order)} parameters, the model has {len(names)}")
+            shapes = dict(self.model.named_parameters())
+            state, step = {}, 0
+            for i, name in zip(order, names):
+                st = sd["state"].get(i)
+                if st is None:
+                    z = torch.zeros_like(shapes[name], memory_format=torch.contiguous_format)
+                    state[name] = {"exp_avg": z, "exp_avg_sq": z.clone()}
+                else:
+                    state[name] = {"exp_avg": st["exp_avg"], "exp_avg_sq": st["exp_avg_sq"]}
+                    step = max(step, int(st["step"]))
+            sd = {"step": step, "state": state}
         tables, dense = self._named()
         want = {n for n, _ in tables} | {n for n, _ in dense}
         if set(sd["state"]) != want:

@@ -3,8 +3,11 @@
 
     {"epoch", "model_state_dict", "optimizer_state_dict", "best_metric"}
 
-with the reference's ``state_dict`` keys and shapes, so checkpoints move between the reference and
-this package in both directions.  Two differences, both on the safe side:
+with the reference's ``state_dict`` keys and shapes.  ``model_state_dict`` moves between the reference
+and this package in both directions.  ``optimizer_state_dict``: ``RowSparseAdam.load_state_dict`` reads
+both its own name-keyed format and the ``torch.optim.Adam.state_dict()`` the reference writes
+(trainer.py:144); what this package writes is its own format (torch's Adam cannot load it).  Two
+differences, both on the safe side:
 
 * tensors are made contiguous first: with packed row records (``FeatureEmbedding.pack_tables_``) a
   table is a strided view of a 4x larger buffer, and ``torch.save`` of a view writes the whole

@@ -61,3 +61,34 @@ def test_checkpoint_round_trip_and_resume(tmp_path):
             continue
         assert np.array_equal(finals[0][k], finals[1][k]), f"unpacked resume diverged: {k}"
         assert np.array_equal(finals[0][k], finals[2][k]), f"packed resume diverged: {k}"
+
+
+def test_reference_optimizer_state_dict_loads():
+    """A ``torch.optim.Adam.state_dict()`` over ``model.parameters()`` — what the reference's trainer stores
+    as ``optimizer_state_dict`` (trainer.py:140-148) — loads into RowSparseAdam: moments matched by
+    parameter position, step count taken over."""
+    from deepfm_amd.training.rowsparse import RowSparseAdam
+    _, _, model = _small_deepfm(seed=11)
+    model.embedding.set_grad_mode("dense")                   # every parameter under autograd, like the reference
+    ref_opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    rng = np.random.default_rng(4)
+    from tests.helpers import random_fields_batch
+    fields = criteo_fields(300, 16)
+    batch = {k: torch.from_numpy(v).cuda() for k, v in random_fields_batch(fields, 64, rng).items()}
+    for _ in range(2):
+        ref_opt.zero_grad()
+        model(batch).sum().backward()
+        ref_opt.step()
+    sd = ref_opt.state_dict()
+    assert "param_groups" in sd and isinstance(next(iter(sd["state"])), int)
+    want = {n: sd["state"][i] for i, (n, _) in enumerate(model.named_parameters())}
+    weights = {k: v.clone() for k, v in model.state_dict().items()}
+    _, _, fresh = _small_deepfm(seed=12)
+    fresh.load_state_dict(weights)
+    opt = RowSparseAdam(fresh, lr=1e-3)
+    opt.load_state_dict(sd)
+    assert int(opt.step_count) == 2
+    got = opt.state_dict()["state"]
+    for name, st in want.items():
+        assert torch.equal(got[name]["exp_avg"].cpu(), st["exp_avg"].cpu().reshape(got[name]["exp_avg"].shape)), name
+        assert torch.equal(got[name]["exp_avg_sq"].cpu(), st["exp_avg_sq"].cpu().reshape(got[name]["exp_avg_sq"].shape)), name
