@@ -55,9 +55,10 @@ def parse():
     ap.add_argument("--no-extra-configs", action="store_true",
                     help="skip BASELINE.json configurations 3 and 4 (xDeepFM / AttentionDeepFM) after the headline")
     ap.add_argument("--extra-steps", type=int, default=60, help="timed steps of each extra configuration")
-    ap.add_argument("--timing-every", type=int, default=3,
+    ap.add_argument("--timing-every", type=int, default=0,
                     help="one launch in n of the timed region is a single step whose gather is launched eagerly with HIP "
-                         "events on the dispatch (the others are graph launches of --steps-per-graph steps)")
+                         "events on the dispatch (the others are graph launches of --steps-per-graph steps); "
+                         "0 = automatic: 3, or 2 for runs of 40 steps or fewer (more samples)")
     ap.add_argument("--steps-per-graph", type=int, default=4,
                     help="consecutive training steps captured in one HIP graph (1 under data parallelism)")
     ap.add_argument("--gather-shape", type=int, default=0,
@@ -250,6 +251,8 @@ def extra_config(name, args, dev, lib):
 
 def main():
     args = parse()
+    if args.timing_every <= 0:
+        args.timing_every = 2 if args.steps <= 40 else 3
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))

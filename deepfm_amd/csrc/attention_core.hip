@@ -455,6 +455,13 @@ int check_core(int F, int A, int heads) {
 }
 }  // namespace
 
+namespace dfm {
+bool attn_mfma_supported(int F, int A, int heads);
+int attn_mfma_forward(const float* qkv, int64_t B, int F, int A, int heads, float* o, hipStream_t st);
+int attn_mfma_backward(const float* qkv, const float* d_o, int64_t B, int F, int A, int heads, float* d_qkv,
+                       hipStream_t st);
+}  // namespace dfm
+
 extern "C" int dfm_attention_core_supported(int num_fields, int attention_dim, int num_heads) {
   if (num_fields <= 0 || num_fields > kMaxF || num_heads <= 0 || attention_dim % num_heads) return 0;
   const int hd = attention_dim / num_heads;
@@ -466,6 +473,10 @@ extern "C" int dfm_attention_core_forward(const float* d_qkv, int64_t batch, int
   DFM_REQUIRE(d_qkv && d_o, "null argument");
   if (int rc = check_core(num_fields, attention_dim, num_heads)) return rc;
   if (batch == 0) return DFM_OK;
+  // head_dim 16, <= 48 fields (the Criteo shape): matrix-core kernels (attention_mfma.hip)
+  if (attn_mfma_supported(num_fields, attention_dim, num_heads) && (reinterpret_cast<uintptr_t>(d_qkv) & 15) == 0 &&
+      (reinterpret_cast<uintptr_t>(d_o) & 15) == 0)
+    return attn_mfma_forward(d_qkv, batch, num_fields, attention_dim, num_heads, d_o, as_stream(stream));
   const int hd = attention_dim / num_heads;
   const int64_t units = batch * num_heads;
   const dim3 grid(static_cast<unsigned>((units + kWavesPerBlock - 1) / kWavesPerBlock)), block(kWavesPerBlock * 64);
@@ -485,6 +496,9 @@ extern "C" int dfm_attention_core_backward(const float* d_qkv, const float* d_g_
   DFM_REQUIRE(d_qkv && d_g_o && d_g_qkv, "null argument");
   if (int rc = check_core(num_fields, attention_dim, num_heads)) return rc;
   if (batch == 0) return DFM_OK;
+  if (attn_mfma_supported(num_fields, attention_dim, num_heads) && (reinterpret_cast<uintptr_t>(d_qkv) & 15) == 0 &&
+      (reinterpret_cast<uintptr_t>(d_g_o) & 15) == 0 && (reinterpret_cast<uintptr_t>(d_g_qkv) & 15) == 0)
+    return attn_mfma_backward(d_qkv, d_g_o, batch, num_fields, attention_dim, num_heads, d_g_qkv, as_stream(stream));
   const int hd = attention_dim / num_heads;
   const int64_t units = batch * num_heads;
   const dim3 grid(static_cast<unsigned>((units + kWavesPerBlock - 1) / kWavesPerBlock)), block(kWavesPerBlock * 64);

@@ -1,0 +1,298 @@
+// Field self-attention core on the matrix cores: softmax(Q_h K_h^T / sqrt(hd)) V_h and its backward for
+// head_dim 16 and up to 48 fields (the Criteo shape: F = 39, 4 heads of 16; reference
+// deepfm/models/layers/attention.py:100-112), one wave per (sample, head), exact fp32
+// (v_mfma_f32_16x16x4_f32: a k-ordered fp32 fma chain).
+//
+// Why: the VALU kernels of attention_core.hip keep 39 of 64 lanes busy with scalar-operand FMAs
+// (19 of the 64 FLOP/clk a SIMD has) behind scalar-load latency: 81 us forward, 217 us backward for
+// 1.6 + 4 GFLOP.  The 39 x 16 . 16 x 39 and 39 x 39 . 39 x 16 products fit 16 x 16 x 4 MFMA tiles
+// (F padded to 3 tiles of 16).
+//
+// Layouts (lane l: c = l & 15, g = l >> 4):
+//   MFMA 16x16x4:  A[i = c][k' = g],  B[k' = g][j = c],  D reg r = D[i = 4g + r][j = c].
+//   * "row fragment" of a (tokens x 16) matrix X, tile t: the float4 X[16t + c][4g .. 4g+3]; element kc
+//     feeds MFMA kc, so the contraction index of MFMA kc at position g is k = 4g + kc — the same
+//     permutation on both operands, which a sum over k does not see.  One 16-byte load per tile.
+//   * a D tile of Z (rows R, cols C) is, register r at a time, the B operand of a product that
+//     contracts over Z's ROW index: X[m][C] = sum_R A[m][R] Z[R][C] with A[i = c][k' = g] = A[m = c][R = 4g + r].
+//     So scores are computed TRANSPOSED, ST[key][query] = K Q^T: softmax'ed in place they are the B
+//     operand of O^T[d][query] = sum_key V^T[d][key] PT[key][query] — no lane movement, no LDS.
+//   * the backward needs P and dS with queries as the contraction index too (dV = P^T dO, dK = dS^T Q):
+//     those two are transposed through a wave-private LDS image (row stride 52 floats: conflict-free).
+//   Reductions over keys run over a tile's registers and tiles (in-lane) and over the four 16-lane rows:
+//   v_permlane16_swap + v_permlane32_swap (VALU), not ds_bpermute.
+#include "common.h"
+
+using namespace dfm;
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kHd = 16;
+constexpr int kUnitsPerBlock = 4;         // waves per workgroup, one (sample, head) each
+constexpr int kTS = 52;                   // row stride (floats) of the transpose image: 4 * 52 % 32 == 16
+
+__device__ __forceinline__ unsigned fbits(float x) { return __builtin_bit_cast(unsigned, x); }
+__device__ __forceinline__ float bitsf(unsigned x) { return __builtin_bit_cast(float, x); }
+
+// combine over the four 16-lane rows of the wave (lanes c, c+16, c+32, c+48), result in every lane
+__device__ __forceinline__ float rows4_sum(float x) {
+  auto a = __builtin_amdgcn_permlane16_swap(fbits(x), fbits(x), false, false);     // rows {0,1} and {2,3}
+  const float y = bitsf(a[0]) + bitsf(a[1]);
+  auto b = __builtin_amdgcn_permlane32_swap(fbits(y), fbits(y), false, false);     // halves
+  return bitsf(b[0]) + bitsf(b[1]);
+}
+__device__ __forceinline__ float rows4_max(float x) {
+  auto a = __builtin_amdgcn_permlane16_swap(fbits(x), fbits(x), false, false);
+  const float y = fmaxf(bitsf(a[0]), bitsf(a[1]));
+  auto b = __builtin_amdgcn_permlane32_swap(fbits(y), fbits(y), false, false);
+  return fmaxf(bitsf(b[0]), bitsf(b[1]));
+}
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 acc) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+}
+// acc += sum over the 16 contraction values held as two row fragments
+__device__ __forceinline__ f32x4 mfma_frag(const float4& a, const float4& b, f32x4 acc) {
+  acc = mfma4(a.x, b.x, acc);
+  acc = mfma4(a.y, b.y, acc);
+  acc = mfma4(a.z, b.z, acc);
+  acc = mfma4(a.w, b.w, acc);
+  return acc;
+}
+
+// row fragment of rows [16t, 16t+16) of the matrix at `p` (row stride ld); rows >= F read as `fill` * row F-1
+__device__ __forceinline__ float4 row_frag(const float* p, int64_t ld, int t, int c, int g, int F, float scale) {
+  const int row = 16 * t + c;
+  const int rc = row < F ? row : F - 1;
+  const float m = row < F ? scale : 0.f;
+  const float4 v = ld4(p + static_cast<int64_t>(rc) * ld + 4 * g);
+  return make_float4(v.x * m, v.y * m, v.z * m, v.w * m);
+}
+// A operand "token on the contraction index": X[16t + 4g + r][c]; rows >= F clamped (times `zero_pad` ? 0 : 1)
+__device__ __forceinline__ float col_elem(const float* p, int64_t ld, int t, int r, int c, int g, int F, bool zero_pad) {
+  const int row = 16 * t + 4 * g + r;
+  const int rc = row < F ? row : F - 1;
+  const float v = p[static_cast<int64_t>(rc) * ld + c];
+  return (zero_pad && row >= F) ? 0.f : v;
+}
+
+// scores (transposed) -> probabilities, in place: pt[tk][tq] reg r = P[query 16tq + c][key 16tk + 4g + r]
+template <int NT>
+__device__ __forceinline__ void scores_softmax(const float4 (&kf)[NT], const float4 (&qf)[NT], int F, int g,
+                                               f32x4 (&pt)[NT][NT]) {
+#pragma unroll
+  for (int tk = 0; tk < NT; ++tk)
+#pragma unroll
+    for (int tq = 0; tq < NT; ++tq) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      pt[tk][tq] = mfma_frag(kf[tk], qf[tq], acc);
+    }
+#pragma unroll
+  for (int tq = 0; tq < NT; ++tq) {
+    float mx = -INFINITY;
+#pragma unroll
+    for (int tk = 0; tk < NT; ++tk)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (16 * tk + 4 * g + r >= F) pt[tk][tq][r] = -INFINITY;        // keys past the end
+        mx = fmaxf(mx, pt[tk][tq][r]);
+      }
+    mx = rows4_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int tk = 0; tk < NT; ++tk)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = expf(pt[tk][tq][r] - mx);
+        pt[tk][tq][r] = e;
+        sum += e;
+      }
+    const float inv = 1.f / rows4_sum(sum);
+#pragma unroll
+    for (int tk = 0; tk < NT; ++tk)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pt[tk][tq][r] *= inv;
+  }
+}
+
+// Transposes through the wave-private image: lane (c, g) of tile (tk, tq) holds keys 16tk+4g..+3 of query
+// 16tq + c -> one 16-byte store at [query][key]; read back one query row per register.
+template <int NT>
+__device__ __forceinline__ void put_image(float* img, const f32x4 (&m)[NT][NT], int c, int g) {
+#pragma unroll
+  for (int tk = 0; tk < NT; ++tk)
+#pragma unroll
+    for (int tq = 0; tq < NT; ++tq)
+      st4(img + (16 * tq + c) * kTS + 16 * tk + 4 * g, make_float4(m[tk][tq][0], m[tk][tq][1], m[tk][tq][2], m[tk][tq][3]));
+}
+// X^T[d][key] = sum_query Y[query][d] M[query][key] for M in the image (Y rows past the end count as 0);
+// X[key][:] goes to out[key * ldo + col0 + d].
+template <int NT>
+__device__ __forceinline__ void contract_queries(const float* img, const float* __restrict__ y, int64_t ldy,
+                                                 float* __restrict__ out, int64_t ldo, int col0, int F, int c, int g) {
+  float ya[NT][4];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ya[t][r] = col_elem(y, ldy, t, r, c, g, F, true);
+#pragma unroll
+  for (int tk = 0; tk < NT; ++tk) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int tq = 0; tq < NT; ++tq)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc = mfma4(ya[tq][r], img[(16 * tq + 4 * g + r) * kTS + 16 * tk + c], acc);
+    const int key = 16 * tk + c;
+    if (key < F) st4(out + static_cast<int64_t>(key) * ldo + col0 + 4 * g, make_float4(acc[0], acc[1], acc[2], acc[3]));
+  }
+}
+
+template <int NT>
+__global__ __launch_bounds__(kUnitsPerBlock * 64) void attn_mfma_fwd(const float* __restrict__ qkv, int64_t B, int F,
+                                                                      int A, int heads, float* __restrict__ o) {
+  const int lane = lane_id(), wave = wave_id_uniform();
+  const int64_t unit = static_cast<int64_t>(blockIdx.x) * kUnitsPerBlock + wave;
+  if (unit >= B * heads) return;                       // wave-uniform; the kernel has no workgroup barrier
+  const int64_t b = unit / heads;
+  const int h = static_cast<int>(unit % heads);
+  const int c = lane & 15, g = lane >> 4;
+  const int64_t rs = 3 * static_cast<int64_t>(A);
+  const float* base = qkv + b * F * rs + h * kHd;
+  const float inv_scale = 0.25f;                       // 1 / sqrt(16)   (attention.py:100-103)
+  float4 qf[NT], kf[NT];
+  float va[NT][4];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    qf[t] = row_frag(base, rs, t, c, g, F, inv_scale);
+    kf[t] = row_frag(base + A, rs, t, c, g, F, 1.f);
+  }
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) va[t][r] = col_elem(base + 2 * A, rs, t, r, c, g, F, false);   // P is 0 there
+  f32x4 pt[NT][NT];
+  scores_softmax<NT>(kf, qf, F, g, pt);
+  // O^T[d = 4g + r][query = 16tq + c] = sum_key V[key][d] P[query][key]
+#pragma unroll
+  for (int tq = 0; tq < NT; ++tq) {
+    f32x4 ot = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int tk = 0; tk < NT; ++tk)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ot = mfma4(va[tk][r], pt[tk][tq][r], ot);
+    const int query = 16 * tq + c;
+    if (query < F) st4(o + (b * F + query) * A + h * kHd + 4 * g, make_float4(ot[0], ot[1], ot[2], ot[3]));
+  }
+}
+
+// d_qkv (B*F, 3A) from d_o (B*F, A); recomputes the probabilities.
+template <int NT>
+__global__ __launch_bounds__(kUnitsPerBlock * 64) void attn_mfma_bwd(const float* __restrict__ qkv,
+                                                                      const float* __restrict__ d_o, int64_t B, int F,
+                                                                      int A, int heads, float* __restrict__ d_qkv) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int lane = lane_id(), wave = wave_id_uniform();
+  const int64_t unit = static_cast<int64_t>(blockIdx.x) * kUnitsPerBlock + wave;
+  if (unit >= B * heads) return;                       // wave-uniform; LDS images are wave-private, no barrier
+  const int64_t b = unit / heads;
+  const int h = static_cast<int>(unit % heads);
+  const int c = lane & 15, g = lane >> 4;
+  const int64_t rs = 3 * static_cast<int64_t>(A);
+  const float* base = qkv + b * F * rs + h * kHd;
+  const float* gbase = d_o + b * F * A + h * kHd;
+  float* dbase = d_qkv + b * F * rs + h * kHd;
+  float* img = lds + static_cast<size_t>(wave) * (16 * NT) * kTS;      // [query][key] image, wave-private
+  const float inv_scale = 0.25f;
+  f32x4 pt[NT][NT], ds[NT][NT];
+  {
+    float4 qf[NT], kf[NT], vf[NT], gf[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      qf[t] = row_frag(base, rs, t, c, g, F, inv_scale);
+      kf[t] = row_frag(base + A, rs, t, c, g, F, 1.f);
+      vf[t] = row_frag(base + 2 * A, rs, t, c, g, F, 1.f);
+      gf[t] = row_frag(gbase, A, t, c, g, F, 1.f);                     // rows >= F are zero: no gradient from padding
+    }
+    scores_softmax<NT>(kf, qf, F, g, pt);
+    // dP^T[key][query] = sum_d V[key][d] dO[query][d]
+#pragma unroll
+    for (int tk = 0; tk < NT; ++tk)
+#pragma unroll
+      for (int tq = 0; tq < NT; ++tq) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        ds[tk][tq] = mfma_frag(vf[tk], gf[tq], acc);
+      }
+  }
+  // dS^T = P^T o (dP^T - sum_key dP o P) / sqrt(hd)
+#pragma unroll
+  for (int tq = 0; tq < NT; ++tq) {
+    float dot = 0.f;
+#pragma unroll
+    for (int tk = 0; tk < NT; ++tk)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dot = fmaf(ds[tk][tq][r], pt[tk][tq][r], dot);
+    dot = rows4_sum(dot);
+#pragma unroll
+    for (int tk = 0; tk < NT; ++tk)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ds[tk][tq][r] = pt[tk][tq][r] * (ds[tk][tq][r] - dot) * inv_scale;
+  }
+  // ---- dQ^T[d][query] = sum_key K[key][d] dS[query][key]   (contraction over keys: dS^T as it stands) ----
+  {
+    float ka[NT][4];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ka[t][r] = col_elem(base + A, rs, t, r, c, g, F, false);    // dS^T is 0 there
+#pragma unroll
+    for (int tq = 0; tq < NT; ++tq) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int tk = 0; tk < NT; ++tk)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc = mfma4(ka[tk][r], ds[tk][tq][r], acc);
+      const int query = 16 * tq + c;
+      if (query < F) st4(dbase + static_cast<int64_t>(query) * rs + 4 * g, make_float4(acc[0], acc[1], acc[2], acc[3]));
+    }
+  }
+  // ---- the two products that contract over QUERIES go through the transposed image ----
+  put_image<NT>(img, pt, c, g);
+  contract_queries<NT>(img, gbase, A, dbase, rs, 2 * A, F, c, g);   // dV^T = dO^T P   (dO past the end counts as 0)
+  put_image<NT>(img, ds, c, g);                                     // same wave, LDS in order: the reads above are done
+  contract_queries<NT>(img, base, rs, dbase, rs, A, F, c, g);       // dK^T = Q^T dS   (unscaled Q; dS carries 1/sqrt(hd))
+}
+
+}  // namespace
+
+namespace dfm {
+
+bool attn_mfma_supported(int F, int A, int heads) {
+  return heads > 0 && A % heads == 0 && A / heads == kHd && F >= 1 && F <= 48 && A % 4 == 0;
+}
+
+int attn_mfma_forward(const float* qkv, int64_t B, int F, int A, int heads, float* o, hipStream_t st) {
+  const int64_t units = B * heads;
+  const dim3 grid(static_cast<unsigned>((units + kUnitsPerBlock - 1) / kUnitsPerBlock)), block(kUnitsPerBlock * 64);
+  const int nt = (F + 15) / 16;
+  if (nt == 1) hipLaunchKernelGGL(attn_mfma_fwd<1>, grid, block, 0, st, qkv, B, F, A, heads, o);
+  else if (nt == 2) hipLaunchKernelGGL(attn_mfma_fwd<2>, grid, block, 0, st, qkv, B, F, A, heads, o);
+  else hipLaunchKernelGGL(attn_mfma_fwd<3>, grid, block, 0, st, qkv, B, F, A, heads, o);
+  DFM_LAUNCH_CHECK();
+  return DFM_OK;
+}
+
+int attn_mfma_backward(const float* qkv, const float* d_o, int64_t B, int F, int A, int heads, float* d_qkv,
+                       hipStream_t st) {
+  const int64_t units = B * heads;
+  const dim3 grid(static_cast<unsigned>((units + kUnitsPerBlock - 1) / kUnitsPerBlock)), block(kUnitsPerBlock * 64);
+  const int nt = (F + 15) / 16;
+  const size_t lds = sizeof(float) * kUnitsPerBlock * (16 * nt) * kTS;
+  if (nt == 1) hipLaunchKernelGGL(attn_mfma_bwd<1>, grid, block, lds, st, qkv, d_o, B, F, A, heads, d_qkv);
+  else if (nt == 2) hipLaunchKernelGGL(attn_mfma_bwd<2>, grid, block, lds, st, qkv, d_o, B, F, A, heads, d_qkv);
+  else hipLaunchKernelGGL(attn_mfma_bwd<3>, grid, block, lds, st, qkv, d_o, B, F, A, heads, d_qkv);
+  DFM_LAUNCH_CHECK();
+  return DFM_OK;
+}
+
+}  // namespace dfm
