@@ -460,7 +460,44 @@ bool attn_mfma_supported(int F, int A, int heads);
 int attn_mfma_forward(const float* qkv, int64_t B, int F, int A, int heads, float* o, hipStream_t st);
 int attn_mfma_backward(const float* qkv, const float* d_o, int64_t B, int F, int A, int heads, float* d_qkv,
                        hipStream_t st);
+bool attn_qkv_mfma_supported(int F, int D, int A, int heads);
+int attn_qkv_mfma_forward(const float* x, const float* w, const float* bias, int64_t B, int F, int D, int A, int heads,
+                          float* o, hipStream_t st);
+int attn_qkv_mfma_backward(const float* x, const float* w, const float* bias, const float* d_o, int64_t B, int F, int D,
+                           int A, int heads, float* d_qkv, hipStream_t st);
 }  // namespace dfm
+
+// Attention core with the Q | K | V projection inside (attention_mfma.hip): x (B*F, D), stacked weight
+// (3A, D) = [W_q; W_k; W_v], stacked bias (3A).
+extern "C" int dfm_attention_qkv_core_supported(int num_fields, int embed_dim, int attention_dim, int num_heads) {
+  return attn_qkv_mfma_supported(num_fields, embed_dim, attention_dim, num_heads) ? 1 : 0;
+}
+
+static bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+extern "C" int dfm_attention_qkv_core_forward(const float* d_x, const float* d_w_qkv, const float* d_b_qkv, int64_t batch,
+                                              int num_fields, int embed_dim, int attention_dim, int num_heads,
+                                              float* d_o, dfm_stream_t stream) {
+  DFM_REQUIRE(d_x && d_w_qkv && d_b_qkv && d_o, "null argument");
+  DFM_REQUIRE(attn_qkv_mfma_supported(num_fields, embed_dim, attention_dim, num_heads),
+              "unsupported shape (dfm_attention_qkv_core_supported)");
+  DFM_REQUIRE(al16(d_x) && al16(d_w_qkv) && al16(d_b_qkv) && al16(d_o), "16-byte aligned buffers only");
+  if (batch == 0) return DFM_OK;
+  return attn_qkv_mfma_forward(d_x, d_w_qkv, d_b_qkv, batch, num_fields, embed_dim, attention_dim, num_heads, d_o,
+                               as_stream(stream));
+}
+
+extern "C" int dfm_attention_qkv_core_backward(const float* d_x, const float* d_w_qkv, const float* d_b_qkv,
+                                               const float* d_g_o, int64_t batch, int num_fields, int embed_dim,
+                                               int attention_dim, int num_heads, float* d_g_qkv, dfm_stream_t stream) {
+  DFM_REQUIRE(d_x && d_w_qkv && d_b_qkv && d_g_o && d_g_qkv, "null argument");
+  DFM_REQUIRE(attn_qkv_mfma_supported(num_fields, embed_dim, attention_dim, num_heads),
+              "unsupported shape (dfm_attention_qkv_core_supported)");
+  DFM_REQUIRE(al16(d_x) && al16(d_w_qkv) && al16(d_b_qkv) && al16(d_g_o) && al16(d_g_qkv), "16-byte aligned buffers only");
+  if (batch == 0) return DFM_OK;
+  return attn_qkv_mfma_backward(d_x, d_w_qkv, d_b_qkv, d_g_o, batch, num_fields, embed_dim, attention_dim, num_heads,
+                                d_g_qkv, as_stream(stream));
+}
 
 extern "C" int dfm_attention_core_supported(int num_fields, int attention_dim, int num_heads) {
   if (num_fields <= 0 || num_fields > kMaxF || num_heads <= 0 || attention_dim % num_heads) return 0;

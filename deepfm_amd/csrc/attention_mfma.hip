@@ -129,13 +129,8 @@ __device__ __forceinline__ void put_image(float* img, const f32x4 (&m)[NT][NT], 
 // X^T[d][key] = sum_query Y[query][d] M[query][key] for M in the image (Y rows past the end count as 0);
 // X[key][:] goes to out[key * ldo + col0 + d].
 template <int NT>
-__device__ __forceinline__ void contract_queries(const float* img, const float* __restrict__ y, int64_t ldy,
+__device__ __forceinline__ void contract_queries(const float* img, const float (&ya)[NT][4],
                                                  float* __restrict__ out, int64_t ldo, int col0, int F, int c, int g) {
-  float ya[NT][4];
-#pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) ya[t][r] = col_elem(y, ldy, t, r, c, g, F, true);
 #pragma unroll
   for (int tk = 0; tk < NT; ++tk) {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -257,10 +252,182 @@ __global__ __launch_bounds__(kUnitsPerBlock * 64) void attn_mfma_bwd(const float
     }
   }
   // ---- the two products that contract over QUERIES go through the transposed image ----
+  float ya[NT][4];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ya[t][r] = col_elem(gbase, A, t, r, c, g, F, true);
   put_image<NT>(img, pt, c, g);
-  contract_queries<NT>(img, gbase, A, dbase, rs, 2 * A, F, c, g);   // dV^T = dO^T P   (dO past the end counts as 0)
+  contract_queries<NT>(img, ya, dbase, rs, 2 * A, F, c, g);         // dV^T = dO^T P   (dO past the end counts as 0)
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ya[t][r] = col_elem(base, rs, t, r, c, g, F, true);
   put_image<NT>(img, ds, c, g);                                     // same wave, LDS in order: the reads above are done
-  contract_queries<NT>(img, base, rs, dbase, rs, A, F, c, g);       // dK^T = Q^T dS   (unscaled Q; dS carries 1/sqrt(hd))
+  contract_queries<NT>(img, ya, dbase, rs, A, F, c, g);             // dK^T = Q^T dS   (unscaled Q; dS carries 1/sqrt(hd))
+}
+
+
+// ==================================================================================================
+// The same two kernels with the Q | K | V projection INSIDE (attention.py:95-97: Linear(D, A) each):
+// x (B*F, D) and the stacked weight (3A, D) + bias (3A) come in, the (B*F, 3A) projection is never
+// written or read (123 MB each way at the Criteo shape; the core kernels above are HBM-bound on it).
+// Per (sample, head) the head's 16 output features of Q, K, V are 16 x D . D x 16-token products:
+//   transposed  (A = W_h, B = x^T): D[d = 4g + r][token = c]  = the ROW FRAGMENT of the projection,
+//   direct      (A = x,  B = W_h^T): D[token = 4g + r][d = c] = its "token on the contraction index" form,
+// both from the same operand registers (x row fragments, W row fragments), bias as the accumulator's
+// start value.  KD = D / 16 sixteen-wide chunks of the input features.
+template <int NT, int KD>
+struct Proj {
+  float4 xf[NT][KD];          // x[token 16t + c][16kd + 4g ..]   (tokens past the end: 0)
+  int c, g;
+  __device__ __forceinline__ void load_x(const float* __restrict__ x, int64_t row0, int F, int D, int c_, int g_) {
+    c = c_; g = g_;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int kd = 0; kd < KD; ++kd) xf[t][kd] = row_frag(x + row0 * D + 16 * kd, D, t, c, g, F, 1.f);
+  }
+  // rows [r0, r0 + 16) of the stacked weight: W[r0 + c][16kd + 4g ..]
+  __device__ __forceinline__ void load_w(const float* __restrict__ w, int r0, int D, float4 (&wf)[KD]) const {
+#pragma unroll
+    for (int kd = 0; kd < KD; ++kd) wf[kd] = ld4(w + static_cast<int64_t>(r0 + c) * D + 16 * kd + 4 * g);
+  }
+  // row fragments of (x W^T + b)[:, r0 : r0 + 16], times `scale`
+  __device__ __forceinline__ void transposed(const float4 (&wf)[KD], const float* __restrict__ bias, int r0, float scale,
+                                             float4 (&out)[NT]) const {
+    const float4 b4 = ld4(bias + r0 + 4 * g);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      f32x4 acc = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+      for (int kd = 0; kd < KD; ++kd) acc = mfma_frag(wf[kd], xf[t][kd], acc);
+      out[t] = make_float4(acc[0] * scale, acc[1] * scale, acc[2] * scale, acc[3] * scale);
+    }
+  }
+  // out[t][r] = (x W^T + b)[token 16t + 4g + r][r0 + c]; tokens past the end: the bias alone, or 0 (zero_pad)
+  __device__ __forceinline__ void direct(const float4 (&wf)[KD], const float* __restrict__ bias, int r0, int F,
+                                         bool zero_pad, float (&out)[NT][4]) const {
+    const float bc = bias[r0 + c];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      f32x4 acc = {bc, bc, bc, bc};
+#pragma unroll
+      for (int kd = 0; kd < KD; ++kd) acc = mfma_frag(xf[t][kd], wf[kd], acc);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) out[t][r] = (zero_pad && 16 * t + 4 * g + r >= F) ? 0.f : acc[r];
+    }
+  }
+};
+
+template <int NT, int KD>
+__global__ __launch_bounds__(kUnitsPerBlock * 64) void attn_qkv_mfma_fwd(
+    const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, int64_t B, int F, int D,
+    int A, int heads, float* __restrict__ o) {
+  const int lane = lane_id(), wave = wave_id_uniform();
+  const int64_t unit = static_cast<int64_t>(blockIdx.x) * kUnitsPerBlock + wave;
+  if (unit >= B * heads) return;
+  const int64_t b = unit / heads;
+  const int h = static_cast<int>(unit % heads);
+  const int c = lane & 15, g = lane >> 4;
+  Proj<NT, KD> pj;
+  pj.load_x(x, b * F, F, D, c, g);
+  float4 wq[KD], wk[KD], wv[KD];
+  pj.load_w(w, h * kHd, D, wq);
+  pj.load_w(w, A + h * kHd, D, wk);
+  pj.load_w(w, 2 * A + h * kHd, D, wv);
+  float4 qf[NT], kf[NT];
+  float va[NT][4];
+  pj.transposed(wq, bias, h * kHd, 0.25f, qf);                  // 1 / sqrt(16)
+  pj.transposed(wk, bias, A + h * kHd, 1.f, kf);
+  pj.direct(wv, bias, 2 * A + h * kHd, F, false, va);           // P is 0 past the end
+  f32x4 pt[NT][NT];
+  scores_softmax<NT>(kf, qf, F, g, pt);
+#pragma unroll
+  for (int tq = 0; tq < NT; ++tq) {
+    f32x4 ot = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int tk = 0; tk < NT; ++tk)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ot = mfma4(va[tk][r], pt[tk][tq][r], ot);
+    const int query = 16 * tq + c;
+    if (query < F) st4(o + (b * F + query) * A + h * kHd + 4 * g, make_float4(ot[0], ot[1], ot[2], ot[3]));
+  }
+}
+
+// d_qkv (B*F, 3A) = gradient of the projection's output, from d_o; Q, K, V recomputed from x.
+template <int NT, int KD>
+__global__ __launch_bounds__(kUnitsPerBlock * 64) void attn_qkv_mfma_bwd(
+    const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+    const float* __restrict__ d_o, int64_t B, int F, int D, int A, int heads, float* __restrict__ d_qkv) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int lane = lane_id(), wave = wave_id_uniform();
+  const int64_t unit = static_cast<int64_t>(blockIdx.x) * kUnitsPerBlock + wave;
+  if (unit >= B * heads) return;
+  const int64_t b = unit / heads;
+  const int h = static_cast<int>(unit % heads);
+  const int c = lane & 15, g = lane >> 4;
+  const int64_t rs = 3 * static_cast<int64_t>(A);
+  const float* gbase = d_o + b * F * A + h * kHd;
+  float* dbase = d_qkv + b * F * rs + h * kHd;
+  float* img = lds + static_cast<size_t>(wave) * (16 * NT) * kTS;
+  Proj<NT, KD> pj;
+  pj.load_x(x, b * F, F, D, c, g);
+  float4 wq[KD], wk[KD];
+  pj.load_w(w, h * kHd, D, wq);
+  pj.load_w(w, A + h * kHd, D, wk);
+  f32x4 pt[NT][NT], ds[NT][NT];
+  {
+    float4 qf[NT], kf[NT], vf[NT], gf[NT], wv[KD];
+    pj.load_w(w, 2 * A + h * kHd, D, wv);
+    pj.transposed(wq, bias, h * kHd, 0.25f, qf);
+    pj.transposed(wk, bias, A + h * kHd, 1.f, kf);
+    pj.transposed(wv, bias, 2 * A + h * kHd, 1.f, vf);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) gf[t] = row_frag(gbase, A, t, c, g, F, 1.f);
+    scores_softmax<NT>(kf, qf, F, g, pt);
+#pragma unroll
+    for (int tk = 0; tk < NT; ++tk)
+#pragma unroll
+      for (int tq = 0; tq < NT; ++tq) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        ds[tk][tq] = mfma_frag(vf[tk], gf[tq], acc);
+      }
+  }
+#pragma unroll
+  for (int tq = 0; tq < NT; ++tq) {
+    float dot = 0.f;
+#pragma unroll
+    for (int tk = 0; tk < NT; ++tk)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dot = fmaf(ds[tk][tq][r], pt[tk][tq][r], dot);
+    dot = rows4_sum(dot);
+#pragma unroll
+    for (int tk = 0; tk < NT; ++tk)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ds[tk][tq][r] = pt[tk][tq][r] * (ds[tk][tq][r] - dot) * 0.25f;
+  }
+  float ya[NT][4];
+  pj.direct(wk, bias, A + h * kHd, F, false, ya);               // K, token on the contraction index (dS^T is 0 past the end)
+#pragma unroll
+  for (int tq = 0; tq < NT; ++tq) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int tk = 0; tk < NT; ++tk)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc = mfma4(ya[tk][r], ds[tk][tq][r], acc);
+    const int query = 16 * tq + c;
+    if (query < F) st4(dbase + static_cast<int64_t>(query) * rs + 4 * g, make_float4(acc[0], acc[1], acc[2], acc[3]));
+  }
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ya[t][r] = col_elem(gbase, A, t, r, c, g, F, true);
+  put_image<NT>(img, pt, c, g);
+  contract_queries<NT>(img, ya, dbase, rs, 2 * A, F, c, g);     // dV^T = dO^T P
+  pj.direct(wq, bias, h * kHd, F, true, ya);                    // unscaled Q, 0 past the end
+  put_image<NT>(img, ds, c, g);
+  contract_queries<NT>(img, ya, dbase, rs, A, F, c, g);         // dK^T = Q^T dS
 }
 
 }  // namespace
@@ -293,6 +460,55 @@ int attn_mfma_backward(const float* qkv, const float* d_o, int64_t B, int F, int
   else hipLaunchKernelGGL(attn_mfma_bwd<3>, grid, block, lds, st, qkv, d_o, B, F, A, heads, d_qkv);
   DFM_LAUNCH_CHECK();
   return DFM_OK;
+}
+
+bool attn_qkv_mfma_supported(int F, int D, int A, int heads) {
+  return attn_mfma_supported(F, A, heads) && (D == 16 || D == 32 || D == 48 || D == 64);
+}
+
+template <int KD>
+static int launch_qkv_fwd(const float* x, const float* w, const float* bias, int64_t B, int F, int D, int A, int heads,
+                          float* o, hipStream_t st) {
+  const int64_t units = B * heads;
+  const dim3 grid(static_cast<unsigned>((units + kUnitsPerBlock - 1) / kUnitsPerBlock)), block(kUnitsPerBlock * 64);
+  const int nt = (F + 15) / 16;
+  if (nt == 1) hipLaunchKernelGGL((attn_qkv_mfma_fwd<1, KD>), grid, block, 0, st, x, w, bias, B, F, D, A, heads, o);
+  else if (nt == 2) hipLaunchKernelGGL((attn_qkv_mfma_fwd<2, KD>), grid, block, 0, st, x, w, bias, B, F, D, A, heads, o);
+  else hipLaunchKernelGGL((attn_qkv_mfma_fwd<3, KD>), grid, block, 0, st, x, w, bias, B, F, D, A, heads, o);
+  DFM_LAUNCH_CHECK();
+  return DFM_OK;
+}
+template <int KD>
+static int launch_qkv_bwd(const float* x, const float* w, const float* bias, const float* d_o, int64_t B, int F, int D,
+                          int A, int heads, float* d_qkv, hipStream_t st) {
+  const int64_t units = B * heads;
+  const dim3 grid(static_cast<unsigned>((units + kUnitsPerBlock - 1) / kUnitsPerBlock)), block(kUnitsPerBlock * 64);
+  const int nt = (F + 15) / 16;
+  const size_t lds = sizeof(float) * kUnitsPerBlock * (16 * nt) * kTS;
+  if (nt == 1) hipLaunchKernelGGL((attn_qkv_mfma_bwd<1, KD>), grid, block, lds, st, x, w, bias, d_o, B, F, D, A, heads, d_qkv);
+  else if (nt == 2) hipLaunchKernelGGL((attn_qkv_mfma_bwd<2, KD>), grid, block, lds, st, x, w, bias, d_o, B, F, D, A, heads, d_qkv);
+  else hipLaunchKernelGGL((attn_qkv_mfma_bwd<3, KD>), grid, block, lds, st, x, w, bias, d_o, B, F, D, A, heads, d_qkv);
+  DFM_LAUNCH_CHECK();
+  return DFM_OK;
+}
+
+int attn_qkv_mfma_forward(const float* x, const float* w, const float* bias, int64_t B, int F, int D, int A, int heads,
+                          float* o, hipStream_t st) {
+  switch (D / 16) {
+    case 1: return launch_qkv_fwd<1>(x, w, bias, B, F, D, A, heads, o, st);
+    case 2: return launch_qkv_fwd<2>(x, w, bias, B, F, D, A, heads, o, st);
+    case 3: return launch_qkv_fwd<3>(x, w, bias, B, F, D, A, heads, o, st);
+    default: return launch_qkv_fwd<4>(x, w, bias, B, F, D, A, heads, o, st);
+  }
+}
+int attn_qkv_mfma_backward(const float* x, const float* w, const float* bias, const float* d_o, int64_t B, int F, int D,
+                           int A, int heads, float* d_qkv, hipStream_t st) {
+  switch (D / 16) {
+    case 1: return launch_qkv_bwd<1>(x, w, bias, d_o, B, F, D, A, heads, d_qkv, st);
+    case 2: return launch_qkv_bwd<2>(x, w, bias, d_o, B, F, D, A, heads, d_qkv, st);
+    case 3: return launch_qkv_bwd<3>(x, w, bias, d_o, B, F, D, A, heads, d_qkv, st);
+    default: return launch_qkv_bwd<4>(x, w, bias, d_o, B, F, D, A, heads, d_qkv, st);
+  }
 }
 
 }  // namespace dfm

@@ -111,10 +111,18 @@ class _AttnGemmFn(torch.autograd.Function):
         w_qkv = torch.cat([wq, wk, wv], dim=0)                      # (3A, D)
         b_qkv = torch.cat([bq, bk, bv], dim=0)
         X = x.view(M, D)
-        qkv = torch.empty(M, 3 * A, dtype=torch.float32, device=x.device)
-        _gemm(X, D, True, w_qkv, D, True, qkv, M, 3 * A, D, bias=b_qkv)
         o = torch.empty(M, A, dtype=torch.float32, device=x.device)
-        _lib.check(lib.dfm_attention_core_forward(qkv.data_ptr(), B, F, A, H, o.data_ptr(), _lib.stream_handle()))
+        # projection inside the core kernel where its shape allows: the (M, 3A) Q|K|V is never materialised
+        inside = bool(lib.dfm_attention_qkv_core_supported(F, D, A, H)) and X.data_ptr() % 16 == 0
+        if inside:
+            qkv = None
+            _lib.check(lib.dfm_attention_qkv_core_forward(X.data_ptr(), w_qkv.data_ptr(), b_qkv.data_ptr(), B, F, D, A,
+                                                          H, o.data_ptr(), _lib.stream_handle()))
+        else:
+            qkv = torch.empty(M, 3 * A, dtype=torch.float32, device=x.device)
+            _gemm(X, D, True, w_qkv, D, True, qkv, M, 3 * A, D, bias=b_qkv)
+            _lib.check(lib.dfm_attention_core_forward(qkv.data_ptr(), B, F, A, H, o.data_ptr(),
+                                                      _lib.stream_handle()))
         y = torch.empty(M, D, dtype=torch.float32, device=x.device)
         _gemm(o, A, True, wo, A, True, y, M, D, A, bias=bo)
         stats = None
@@ -129,7 +137,7 @@ class _AttnGemmFn(torch.autograd.Function):
             gamma = beta = None
             out = y
         ctx.block, ctx.dims = block, (B, F, D, A, H)
-        ctx.save_for_backward(X, qkv, o, y, stats, w_qkv, wo, gamma)
+        ctx.save_for_backward(X, qkv, o, y, stats, w_qkv, wo, gamma, b_qkv)
         return out.view(B, F, D)
 
     @staticmethod
@@ -139,7 +147,7 @@ class _AttnGemmFn(torch.autograd.Function):
         block = ctx.block
         B, F, D, A, H = ctx.dims
         M = B * F
-        X, qkv, o, y, stats, w_qkv, wo, gamma = ctx.saved_tensors
+        X, qkv, o, y, stats, w_qkv, wo, gamma, b_qkv = ctx.saved_tensors
         dev = X.device
         g = g_out.contiguous().view(M, D)
         from deepfm_amd.models.layers.linear import ones_column
@@ -162,8 +170,13 @@ class _AttnGemmFn(torch.autograd.Function):
         d_o = torch.empty(M, A, dtype=torch.float32, device=dev)
         _gemm(g_y, D, True, wo, A, False, d_o, M, A, D)                          # dO = g_y Wo
         d_qkv = torch.empty(M, 3 * A, dtype=torch.float32, device=dev)
-        _lib.check(lib.dfm_attention_core_backward(qkv.data_ptr(), d_o.data_ptr(), B, F, A, H, d_qkv.data_ptr(),
-                                                   _lib.stream_handle()))
+        if qkv is None:                                                          # Q, K, V recomputed from X in-kernel
+            _lib.check(lib.dfm_attention_qkv_core_backward(X.data_ptr(), w_qkv.data_ptr(), b_qkv.data_ptr(),
+                                                           d_o.data_ptr(), B, F, D, A, H, d_qkv.data_ptr(),
+                                                           _lib.stream_handle()))
+        else:
+            _lib.check(lib.dfm_attention_core_backward(qkv.data_ptr(), d_o.data_ptr(), B, F, A, H, d_qkv.data_ptr(),
+                                                       _lib.stream_handle()))
         d_wqkv = torch.empty(3 * A, D, dtype=torch.float32, device=dev)
         d_bqkv = torch.empty(3 * A, 1, dtype=torch.float32, device=dev)
         if not _weight_grad(d_qkv, X, M, 3 * A, D, d_wqkv, d_bqkv):

@@ -331,6 +331,19 @@ int dfm_attention_core_forward(const float* d_qkv, int64_t batch, int num_fields
                                int num_heads, float* d_o, dfm_stream_t stream);
 int dfm_attention_core_backward(const float* d_qkv, const float* d_g_o, int64_t batch, int num_fields,
                                 int attention_dim, int num_heads, float* d_g_qkv, dfm_stream_t stream);
+/* The same core with the Q | K | V projection (attention.py:95-97, three Linear(D, A)) inside the kernel:
+ * d_x (batch * num_fields, embed_dim), d_w_qkv (3 * attention_dim, embed_dim) = [W_q; W_k; W_v] stacked,
+ * d_b_qkv (3 * attention_dim).  The (batch * num_fields, 3 * attention_dim) projection is never written;
+ * the backward recomputes it from d_x and returns its gradient d_g_qkv, which feeds the weight / input
+ * gradient GEMMs.  _supported(): head_dim 16, <= 48 fields, embed_dim in {16, 32, 48, 64}; all buffers
+ * 16-byte aligned. */
+int dfm_attention_qkv_core_supported(int num_fields, int embed_dim, int attention_dim, int num_heads);
+int dfm_attention_qkv_core_forward(const float* d_x, const float* d_w_qkv, const float* d_b_qkv, int64_t batch,
+                                   int num_fields, int embed_dim, int attention_dim, int num_heads, float* d_o,
+                                   dfm_stream_t stream);
+int dfm_attention_qkv_core_backward(const float* d_x, const float* d_w_qkv, const float* d_b_qkv,
+                                    const float* d_g_o, int64_t batch, int num_fields, int embed_dim,
+                                    int attention_dim, int num_heads, float* d_g_qkv, dfm_stream_t stream);
 size_t dfm_layernorm_workspace_bytes(int64_t rows, int dim);
 int dfm_layernorm_forward(const float* d_y, const float* d_res, int64_t rows, int dim, const float* d_gamma,
                           const float* d_beta, float eps, float* d_out, float* d_stats, dfm_stream_t stream);
