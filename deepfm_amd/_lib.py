@@ -16,6 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DFM_LIB_PATH") or os.path.join(_HERE, "lib", "libdeepfm_hip.so")
 
 MAX_FIELDS = 64
+MAX_RANKS = 64
 ROWPLAN_CHUNK = 4096
 SPARSE, DENSE, SEQUENCE = 0, 1, 2
 COMBINER = {"mean": 0, "sum": 1, "max": 2}
@@ -144,12 +145,20 @@ SIGNATURES = {
     "dfm_step_prepare_num_partials": (_L, [_I, _I, _I, _L]),
     "dfm_step_match_bytes": (_SZ, [_I, _I]),
     "dfm_step_prepare": (_I, [C.POINTER(Table), _I, _I, _I, _P, _P, _P, _P, _P, _F, _F, _P, _P, _L, _L,
-                              C.POINTER(SlabRef), _I, _P, _I, _P, _P, _P]),
+                              C.POINTER(SlabRef), _I, _P, _I, _L, _P, _P, _P]),
     "dfm_step_apply": (_I, [C.POINTER(Table), _I, _I, _I, _P, _P, _P, _P, _P, _P, _F, _F, _F, _F, _P, _P, _P, _P, _P,
                             _L, _I, _P]),
     "dfm_fm_forward": (_I, [_P, _L, _I, _I, _P, _P]),
     "dfm_fm_backward": (_I, [_P, _P, _L, _I, _I, _P, _P]),
     "dfm_copy_2d": (_I, [_P, _L, _P, _L, _L, _I, _P]),
+    "dfm_stage_record": (_I, [_P, _P, _L, _P]),
+    "dfm_stage_record_update": (_I, [_P, _P, _P, _P, _L]),
+    "dfm_shard_gather": (_I, [C.POINTER(Table), C.POINTER(C.c_int32), _I, _I, _I, _L, _P, _P, _P, _P, _P]),
+    "dfm_shard_pack_segment": (_L, [_L, _I, _I, _L]),
+    "dfm_shard_pack": (_I, [C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I, C.POINTER(C.c_int32), _I, _I, _I, _L,
+                            _P, _P, _P, _L, _P, _P]),
+    "dfm_shard_rowgrad": (_I, [_I, _I, _I, _L, _P, _L, _P, _P, _P, _P, _P, _P]),
+    "dfm_sum_floats": (_I, [_P, _L, _P, _P]),
     "dfm_embedding_grad_combine": (_I, [_P, _L, _P, _P, _P, _P, _L, _I, _I, _P, _P]),
 }
 

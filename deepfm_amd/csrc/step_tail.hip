@@ -38,7 +38,8 @@ constexpr int kStepPrepPerThread = 4;
 // summation order is fixed, at the cost of no extra launch.
 __device__ __forceinline__ void dense_prepare_slabs_body(int blk, float* __restrict__ g, const float* __restrict__ p,
                                                          int64_t n, int64_t n_l2, float l2, const SlabTable& st,
-                                                         const float* __restrict__ gathered, int world, float scale,
+                                                         const float* __restrict__ gathered, int world,
+                                                         int64_t gathered_stride, float scale,
                                                          float* __restrict__ partial) {
   const int64_t i = (static_cast<int64_t>(blk) * kTailThreads + threadIdx.x) * kStepPrepPerThread;
   float sq = 0.f;
@@ -49,7 +50,7 @@ __device__ __forceinline__ void dense_prepare_slabs_body(int blk, float* __restr
     if (gathered) {
       gi = make_float4(0.f, 0.f, 0.f, 0.f);
       for (int r = 0; r < world; ++r) {
-        const float4 t = ld4(gathered + static_cast<int64_t>(r) * n + i);
+        const float4 t = ld4(gathered + static_cast<int64_t>(r) * gathered_stride + i);
         gi.x += t.x; gi.y += t.y; gi.z += t.z; gi.w += t.w;
       }
       gi.x *= scale; gi.y *= scale; gi.z *= scale; gi.w *= scale;
@@ -88,7 +89,7 @@ __device__ __forceinline__ void dense_prepare_slabs_body(int blk, float* __restr
       float ge = g[e];
       if (gathered) {
         ge = 0.f;
-        for (int r = 0; r < world; ++r) ge += gathered[static_cast<int64_t>(r) * n + e];
+        for (int r = 0; r < world; ++r) ge += gathered[static_cast<int64_t>(r) * gathered_stride + e];
         ge *= scale;
         g[e] = ge;
       }
@@ -124,14 +125,14 @@ __global__ __launch_bounds__(kTailThreads) void step_prepare_kernel(
     const int32_t* __restrict__ num_uniq, float* __restrict__ row_g2, float* __restrict__ row_g1,
     int32_t* __restrict__ owner_flag, float grad_scale, float l2, float* __restrict__ g, const float* __restrict__ p,
     int64_t n, int64_t n_l2, SlabTable slabs, const float* __restrict__ dense_gathered, int world,
-    float* __restrict__ partial, const uint8_t* __restrict__ match) {
+    int64_t gathered_stride, float* __restrict__ partial, const uint8_t* __restrict__ match) {
   const int blk = blockIdx.x;
   if (blk < merge_blocks)
     rowadam_merge_body(blk, tabs, S, D, L, uniq_rows, num_uniq, row_g2, row_g1, owner_flag, grad_scale, l2, partial,
                        match);
   else
-    dense_prepare_slabs_body(blk - merge_blocks, g, p, n, n_l2, l2, slabs, dense_gathered, world, grad_scale,
-                             partial + merge_blocks);
+    dense_prepare_slabs_body(blk - merge_blocks, g, p, n, n_l2, l2, slabs, dense_gathered, world, gathered_stride,
+                             grad_scale, partial + merge_blocks);
 }
 
 __global__ __launch_bounds__(kTailThreads) void step_apply_kernel(
@@ -231,8 +232,8 @@ extern "C" int dfm_step_prepare(const dfm_table* tables, int num_sparse, int dim
                                 const int32_t* d_uniq_rows, const int32_t* d_num_uniq, float* d_row_g2,
                                 float* d_row_g1, int32_t* d_owner_flag, float grad_scale, float l2, float* d_g,
                                 const float* d_p, int64_t n, int64_t n_l2, const dfm_slab_ref* slabs, int num_slabs,
-                                const float* d_dense_gathered, int world, float* d_partials, void* d_match,
-                                dfm_stream_t stream) {
+                                const float* d_dense_gathered, int world, int64_t gathered_stride, float* d_partials,
+                                void* d_match, dfm_stream_t stream) {
   DFM_REQUIRE(tables && d_uniq_rows && d_num_uniq && d_row_g2 && d_row_g1 && d_owner_flag && d_partials && d_g && d_p,
               "null argument");
   DFM_REQUIRE(num_sparse > 0 && num_sparse <= DFM_MAX_FIELDS && num_lists > 0, "bad sizes");
@@ -243,6 +244,9 @@ extern "C" int dfm_step_prepare(const dfm_table* tables, int num_sparse, int dim
   DFM_REQUIRE(num_slabs >= 0 && num_slabs <= kMaxSlabs && (num_slabs == 0 || slabs), "0..%d slab references", kMaxSlabs);
   DFM_REQUIRE(!d_dense_gathered || (world >= 1 && (reinterpret_cast<uintptr_t>(d_dense_gathered) & 15) == 0 && n % 4 == 0),
               "gathered dense gradients: world >= 1, 16-byte aligned, n a multiple of 4");
+  if (d_dense_gathered && gathered_stride == 0) gathered_stride = n;
+  DFM_REQUIRE(!d_dense_gathered || (gathered_stride >= n && gathered_stride % 4 == 0),
+              "gathered dense gradients: the stride between ranks must be >= n and a multiple of 4 floats");
   TableArgs ta;
   if (int rc = fill_tables(tables, num_sparse, dim, &ta, false)) return rc;
   SlabTable st = {};
@@ -272,7 +276,7 @@ extern "C" int dfm_step_prepare(const dfm_table* tables, int num_sparse, int dim
   hipLaunchKernelGGL(step_prepare_kernel, dim3(static_cast<unsigned>(mb + pb)), dim3(kTailThreads), 0,
                      as_stream(stream), static_cast<int>(mb), ta, num_sparse, dim, num_lists, d_uniq_rows, d_num_uniq,
                      d_row_g2, d_row_g1, d_owner_flag, grad_scale, l2, d_g, d_p, n, n_l2, st, d_dense_gathered, world,
-                     d_partials, match);
+                     gathered_stride, d_partials, match);
   DFM_LAUNCH_CHECK();
   return DFM_OK;
 }

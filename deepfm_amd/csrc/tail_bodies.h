@@ -83,11 +83,19 @@ __device__ __forceinline__ void dense_fields_uniform_body(int blk, const int32_t
   }
 }
 
+// Where sample b's gradients live: g_field + (b * F + f) * D and g_first + b in one array each, or —
+// field-sharded tables (shard.hip): one received segment per source rank — every `samples` samples a
+// new segment starts `stride` floats further on, in both arrays.
+struct SampleSegments {
+  int64_t samples;   // 0: one array
+  int64_t stride;
+};
+
 // One row gradient per distinct id: sum of its contributions in sample order.
 __device__ __forceinline__ void rowgrad_body(int blk, FieldMap fmap, int S, int F, int D, int lists, const float* __restrict__ g_first,
     const float* __restrict__ g_field, const int32_t* __restrict__ sorted_pos,
     const int32_t* __restrict__ seg_start, const int32_t* __restrict__ num_uniq,
-    float* __restrict__ row_g2, float* __restrict__ row_g1) {
+    float* __restrict__ row_g2, float* __restrict__ row_g1, SampleSegments segs = SampleSegments{0, 0}) {
   const int lpr = D / 4;
   const int64_t t = static_cast<int64_t>(blk) * kTailThreads + threadIdx.x;
   const int q = static_cast<int>(t % lpr);
@@ -104,10 +112,15 @@ __device__ __forceinline__ void rowgrad_body(int blk, FieldMap fmap, int S, int 
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   float acc1 = 0.f;
   for (int p = p0; p < p1; ++p) {
-    const int64_t b = pos[p];
-    const float4 g = ld4(g_field + (b * F + f) * D + q * 4);
+    int64_t b = pos[p], off = 0;
+    if (segs.samples > 0) {
+      const int64_t sg = b / segs.samples;
+      off = sg * segs.stride;
+      b -= sg * segs.samples;
+    }
+    const float4 g = ld4(g_field + off + (b * F + f) * D + q * 4);
     acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
-    if (q == 0) acc1 += g_first[b];
+    if (q == 0) acc1 += g_first[off + b];
   }
   st4(row_g2 + (list * CH + u) * D + q * 4, acc);
   if (q == 0) row_g1[list * CH + u] = acc1;

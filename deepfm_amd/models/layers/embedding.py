@@ -93,6 +93,7 @@ class FeatureEmbedding(nn.Module):
         self._plan_static = False
         self._sparse_pos = [i for i, s in enumerate(schema.fields.values())
                             if s.feature_type is FeatureType.SPARSE]
+        self._row_source: Optional[Dict[str, Tuple[torch.Tensor, torch.Tensor]]] = None
 
     # ------------------------------------------------------------------ init / bookkeeping
     def _init_weights(self) -> None:
@@ -119,6 +120,19 @@ class FeatureEmbedding(nn.Module):
         if pinned:
             self._ensure_plan(device)
         self._plan_static = pinned
+
+    def bind_row_source(self, views: Optional[Dict[str, Tuple[torch.Tensor, torch.Tensor]]]) -> None:
+        """Field-sharded data parallelism (training/sharded.py): the rows of the SPARSE fields do not come
+        from this module's tables but from ``views[name] = (e (n, d), w (n, 1))`` — strided views of the
+        buffer the rows all-to-all delivers, one row per sample — and the id fed for such a field is the
+        sample's own index.  ``None`` restores the module's tables."""
+        if views is not None:
+            missing = [n for n, sp in self.schema.fields.items()
+                       if sp.feature_type is FeatureType.SPARSE and n not in views]
+            if missing:
+                raise KeyError(f"bind_row_source: no view for SPARSE field(s) {missing[:3]}")
+        self._row_source = views
+        self._drop_plan()
 
     def _drop_plan(self) -> None:
         self._plan_static = False
@@ -199,6 +213,8 @@ class FeatureEmbedding(nn.Module):
         if self._plan_static and self._plan is not None:
             return self._plan
         params = list(self.parameters())
+        if self._row_source is not None:
+            params = params + [t for pair in self._row_source.values() for t in pair]
         key = (device, tuple((p.data_ptr(), p.stride(0)) for p in params))
         if self._plan is not None and key == self._plan_key:
             return self._plan
@@ -209,7 +225,11 @@ class FeatureEmbedding(nn.Module):
             raise ValueError(f"{n} fields > DFM_MAX_FIELDS={_lib.MAX_FIELDS}")
         arr = (_lib.Field * n)()
         for i, (name, spec, second, first, proj) in enumerate(self._field_params()):
-            for p in (second.weight, first.weight):
+            w2, w1, rows = second.weight, first.weight, spec.vocabulary_size
+            if self._row_source is not None and spec.feature_type is FeatureType.SPARSE:
+                w2, w1 = self._row_source[name]
+                rows = w2.shape[0]
+            for p in (w2, w1):
                 _lib.require_device(p, f"parameter of field {name!r}")
                 # rows may be strided (packed row records), elements of a row are contiguous
                 if p.dtype != torch.float32 or p.dim() != 2 or (p.shape[1] > 1 and p.stride(1) != 1):
@@ -217,12 +237,12 @@ class FeatureEmbedding(nn.Module):
             fd = arr[i]
             fd.kind = _KIND[spec.feature_type]
             fd.dim = spec.embedding_dim
-            fd.vocab = spec.vocabulary_size if spec.feature_type is not FeatureType.DENSE else 0
+            fd.vocab = rows if spec.feature_type is not FeatureType.DENSE else 0
             fd.max_len = spec.max_length
             fd.combiner = _lib.COMBINER[spec.combiner] if spec.feature_type is FeatureType.SEQUENCE else 0
-            fd.w2, fd.w1 = second.weight.data_ptr(), first.weight.data_ptr()
+            fd.w2, fd.w1 = w2.data_ptr(), w1.data_ptr()
             if spec.feature_type is not FeatureType.DENSE:
-                fd.stride2, fd.stride1 = second.weight.stride(0), first.weight.stride(0)
+                fd.stride2, fd.stride1 = w2.stride(0), w1.stride(0)
             if spec.feature_type is FeatureType.DENSE:
                 fd.b2, fd.b1 = second.bias.data_ptr(), first.bias.data_ptr()
             fd.proj = proj.weight.data_ptr() if proj is not None else None
@@ -334,18 +354,19 @@ class FeatureEmbedding(nn.Module):
         return fo, fe, flat, fm_out
 
     def backward_rowsparse(self, inputs: List[torch.Tensor], g_fo: torch.Tensor, g_fe: torch.Tensor,
-                           dense_grads: Dict[int, torch.Tensor]) -> None:
+                           dense_grads: Dict[int, torch.Tensor], sparse: bool = True) -> None:
         """Row-sparse backward: DENSE-field Linear gradients are ADDED into ``dense_grads``
         ({id(param): buffer}); one gradient row per distinct id goes to ``self.rowsparse``
-        (whose row plan must have been built from the same ``inputs``)."""
+        (whose row plan must have been built from the same ``inputs``).  ``sparse=False``: the
+        DENSE fields only (field-sharded tables: the SPARSE fields' gradients travel to their owners)."""
         B, F, D = g_fe.shape
         if B == 0:
             return
         lib = _lib.load()
         plan = self._ensure_plan(g_fe.device)
-        S = len(self._sparse_pos)
+        S = len(self._sparse_pos) if sparse else 0
         rs = self.rowsparse
-        fmap = (C.c_int32 * max(S, 1))(*self._sparse_pos)
+        fmap = (C.c_int32 * max(S, 1))(*self._sparse_pos[:S])
         if dense_grads and self._plan_uniform and g_fe.data_ptr() % 16 == 0 and self._all_dense_grads(dense_grads):
             # DENSE-field gradients and row gradients in ONE launch (csrc/step_tail.hip)
             if self._dense_list is None or self._dense_list.device != g_fe.device:

@@ -73,3 +73,40 @@ def allgather_step(local: Sequence[torch.Tensor], out: Sequence[torch.Tensor],
     else:
         for dst, src in zip(out, local):
             dist.all_gather_into_tensor(dst, src, group=group)
+
+
+def _log_once(key, message: str, *args) -> None:
+    if key not in _GROUPED:
+        _GROUPED[key] = True
+        import logging
+        logging.getLogger("deepfm_amd.exchange").info(message, *args)
+
+
+def all_to_all(out: torch.Tensor, inp: torch.Tensor, out_splits: Sequence[int], in_splits: Sequence[int],
+               group: Optional[dist.ProcessGroup] = None) -> None:
+    """``inp`` = one contiguous segment per peer (``in_splits[q]`` elements for rank q), ``out`` = one
+    per source rank (``out_splits[p]`` from rank p): the three exchanges of the field-sharded step
+    (training/sharded.py).  RCCL: one grouped send/recv launch (``all_to_all_single``), capturable in a
+    HIP graph.  One rank without a process group: a device copy.  gloo has no all-to-all on device
+    buffers: the CPU/one-GPU rehearsals stage through host memory (logged; never the RCCL path)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        if list(out_splits) != list(in_splits) or len(in_splits) != 1:
+            raise RuntimeError("all_to_all without a process group: one rank only")
+        out.copy_(inp)
+        return
+    if dist.get_backend(group) != "nccl" and inp.is_cuda:
+        _log_once(("a2a-host", group), "all-to-all over %s: staged through host memory (rehearsal only)",
+                  dist.get_backend(group))
+        host_out = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(host_out, inp.cpu(), list(out_splits), list(in_splits), group=group)
+        out.copy_(host_out)
+        return
+    dist.all_to_all_single(out, inp, list(out_splits), list(in_splits), group=group)
+
+
+def all_gather_scalars(out: torch.Tensor, mine: torch.Tensor, group: Optional[dist.ProcessGroup] = None) -> None:
+    """``out[r] = mine`` of rank r (``mine``: one element).  One rank without a process group: a copy."""
+    if not (dist.is_available() and dist.is_initialized()):
+        out.copy_(mine)
+        return
+    dist.all_gather_into_tensor(out, mine, group=group)

@@ -39,11 +39,16 @@ from deepfm_amd.models.layers.embedding import FeatureEmbedding
 class RowSparseAdam:
     def __init__(self, model: torch.nn.Module, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
                  l2: float = 0.0, max_grad_norm: Optional[float] = None,
-                 process_group: Optional[dist.ProcessGroup] = None) -> None:
+                 process_group: Optional[dist.ProcessGroup] = None,
+                 row_embedding: Optional[FeatureEmbedding] = None) -> None:
+        """``row_embedding``: the module whose SPARSE tables take the row-wise updates and whose row
+        lists (``.rowsparse``) feed them — ``model.embedding`` unless the tables are field-sharded
+        (training/sharded.py passes this rank's shard, whose tables are the model's own Parameters)."""
         emb = model.embedding
         if not isinstance(emb, FeatureEmbedding) or emb.grad_mode != "rowsparse":
             raise ValueError("model.embedding must be a FeatureEmbedding in 'rowsparse' grad mode")
         self.model, self.emb = model, emb
+        self.row_emb = row_embedding if row_embedding is not None else emb
         self.lr, self.betas, self.eps, self.l2 = lr, betas, eps, l2
         self.max_grad_norm = max_grad_norm
         self.group = process_group
@@ -55,7 +60,7 @@ class RowSparseAdam:
         self.split = self.world > 1 or (os.environ.get("DFM_FORCE_DP_PATH") == "1" and dist.is_available()
                                         and dist.is_initialized())
 
-        tables = emb.table_parameters()
+        tables = self.row_emb.table_parameters()
         if not tables:
             raise ValueError("no SPARSE tables to optimise")
         dev = tables[0].device
@@ -66,9 +71,9 @@ class RowSparseAdam:
         # Adam moments: inside the packed row records when the embedding was packed
         # (FeatureEmbedding.pack_tables_), else separate contiguous tensors
         self.exp_avg, self.exp_avg_sq = [], []
-        sparse_names = [n for n, spec in model.schema.fields.items() if spec.feature_type is FeatureType.SPARSE]
+        sparse_names = [n for n, spec in self.row_emb.schema.fields.items() if spec.feature_type is FeatureType.SPARSE]
         for name, w2, w1 in zip(sparse_names, tables[0::2], tables[1::2]):
-            rec = emb.packed.get(name) if getattr(emb, "packed", None) else None
+            rec = self.row_emb.packed.get(name) if getattr(self.row_emb, "packed", None) else None
             if rec is not None and rec["buffer"].data_ptr() == w2.data_ptr():
                 self.exp_avg += [rec["m2"], rec["m1"]]
                 self.exp_avg_sq += [rec["v2"], rec["v1"]]
@@ -84,7 +89,7 @@ class RowSparseAdam:
 
         # dense parameters: ONE flat parameter buffer and ONE flat gradient buffer; every
         # parameter / .grad becomes a view (embedding parameters first: they take the L2 term)
-        table_ids = {id(p) for p in tables}
+        table_ids = {id(p) for p in tables} | {id(p) for p in emb.table_parameters()}
         emb_dense = [p for p in emb.non_table_parameters() if p.requires_grad]
         emb_ids = {id(p) for p in emb_dense}
         others = [p for p in model.parameters()
@@ -112,6 +117,7 @@ class RowSparseAdam:
         self._partials = None
         self._match = None
         self._cur = None
+        self._extra_partials = 0                         # floats kept free behind the norm partials (sharded tables)
         self.seed_tick: Optional[torch.Tensor] = None    # int64 device counter advanced once per apply()
         # (dfm_slab_ref[], count): d-weight slabs of dfm_linear_backward that apply() folds into the flat
         # gradient (single rank only: under data parallelism they must be in before the all-reduce)
@@ -124,8 +130,8 @@ class RowSparseAdam:
         ``force=True`` to discard gradients accumulated by a backward pass that was not applied."""
         if force:
             self.flat_grad.zero_()
-        if self.emb.rowsparse is not None:
-            self.emb.rowsparse.has_grad = False
+        if self.row_emb.rowsparse is not None:
+            self.row_emb.rowsparse.has_grad = False
 
     def _table_struct(self):
         arr = (_lib.Table * self.num_sparse)()
@@ -147,7 +153,7 @@ class RowSparseAdam:
     def exchange(self) -> None:
         """Data-parallel gradient exchange (no-op for one rank): all-reduce of the flat dense
         gradient, all-gather of the row lists.  Plain RCCL collectives on the current stream."""
-        rs = self.emb.rowsparse
+        rs = self.row_emb.rowsparse
         if rs is None or not rs.has_grad:
             raise RuntimeError("RowSparseAdam: no row gradients (run a backward pass first)")
         local = (rs.uniq_rows, rs.num_uniq, rs.row_g2, rs.row_g1)
@@ -175,11 +181,10 @@ class RowSparseAdam:
         n_partials = lib.dfm_step_prepare_num_partials(self.num_sparse, self.dim, lists, n_dense)
         if self._owner is None or self._owner.shape != uniq.shape:
             self._owner = torch.empty_like(uniq)
-            self._partials = torch.zeros(n_partials, dtype=torch.float32, device=self.device)
+            self._partials = torch.zeros(n_partials + self._extra_partials, dtype=torch.float32, device=self.device)
             mbytes = lib.dfm_step_match_bytes(self.num_sparse, lists)
             self._match = torch.empty(mbytes, dtype=torch.uint8, device=self.device) if mbytes else None
-        dense_gathered = self._gathered[0] if (self.split and self._gathered is not None and self._cur is not None
-                                               and self._cur[0] is self._gathered[1]) else None
+        dense_gathered, gathered_stride = self._dense_source()
         tabs = self._table_struct()
         refs, n_refs = self.slab_refs if (self.slab_refs is not None and not self.split) else (None, 0)
         # three launches: [row-list merge | dense L2 (+ d-weight slabs) + norm partials] -> clip coefficient
@@ -187,9 +192,10 @@ class RowSparseAdam:
         _lib.check(lib.dfm_step_prepare(tabs, self.num_sparse, self.dim, lists, uniq.data_ptr(), num.data_ptr(),
                                         g2.data_ptr(), g1.data_ptr(), self._owner.data_ptr(), grad_scale, self.l2,
                                         self.flat_grad.data_ptr(), self.flat_param.data_ptr(), n_dense, self.n_l2,
-                                        refs, n_refs, _lib.ptr(dense_gathered), max(self.world, 1),
+                                        refs, n_refs, _lib.ptr(dense_gathered), max(self.world, 1), gathered_stride,
                                         self._partials.data_ptr(), _lib.ptr(self._match), stream))
-        _lib.check(lib.dfm_grad_norm_finalize(self._partials.data_ptr(), n_partials,
+        norm_ptr, n_norm = self._norm_partials(n_partials, lists)
+        _lib.check(lib.dfm_grad_norm_finalize(norm_ptr, n_norm,
                                               self.max_grad_norm or 0.0, self.sq_norm.data_ptr(),
                                               self.clip_coef.data_ptr(), self.step_count.data_ptr(),
                                               _lib.ptr(self.seed_tick), stream))
@@ -198,7 +204,19 @@ class RowSparseAdam:
                                       self.lr, self.betas[0], self.betas[1], self.eps, self.step_count.data_ptr(),
                                       self.flat_param.data_ptr(), self.flat_m.data_ptr(), self.flat_v.data_ptr(),
                                       self.flat_grad.data_ptr(), n_dense, 1, stream))
-        self.emb.rowsparse.has_grad = False
+        self.row_emb.rowsparse.has_grad = False
+
+    def _dense_source(self):
+        """(every rank's dense gradient buffer, floats between ranks) for the prepare launch's rank-ordered
+        mean, or (None, 0): the local flat gradient is the whole gradient."""
+        if (self.split and self._gathered is not None and self._cur is not None
+                and self._cur[0] is self._gathered[1]):
+            return self._gathered[0], 0
+        return None, 0
+
+    def _norm_partials(self, n_partials: int, lists: int):
+        """(address, count) of the floats whose sum is the squared global gradient norm."""
+        return self._partials.data_ptr(), n_partials
 
     def step(self) -> None:
         self.exchange()

@@ -51,6 +51,8 @@ class _GraphSlot:
 
 
 class RowSparseTrainStep:
+    exchange_in_body = False      # True: the step's collectives are part of _gather / _body_a / _body_b themselves
+
     def __init__(self, model, optimizer: RowSparseAdam, batch_size: int, use_graph: bool = True) -> None:
         self.model, self.opt, self.B = model, optimizer, batch_size
         self.emb = model.embedding
@@ -156,6 +158,27 @@ class RowSparseTrainStep:
         a, kw = self._gather_call(self._record if record is None else record)
         self.emb.forward_staged(*a, **kw)
 
+    def _capture_gather(self, record: torch.Tensor) -> C.c_void_p:
+        """``_gather`` while the stream is being captured; returns the graph node that reads the batch
+        record (the one ``_update_gather`` re-points before every launch)."""
+        self._gather(record)
+        node = C.c_void_p()
+        _lib.check(_lib.load().dfm_graph_last_node(_lib.stream_handle(), C.byref(node)))
+        return node
+
+    def _update_gather(self, graph_exec: int, node: C.c_void_p, record: torch.Tensor) -> None:
+        a, kw = self._gather_call(record)
+        self.emb.forward_staged_update(graph_exec, node, *a, **kw)
+
+    def _build_rowplan(self) -> None:
+        """Row plan of the step's ids (sort / unique / segments per SPARSE field)."""
+        self.emb.build_rowplan(self.inputs, self.B)
+
+    def _embedding_backward(self, g_fo: torch.Tensor, g_fe: torch.Tensor) -> None:
+        """d first_order (B, 1), d field_embeddings (B, F, D) -> DENSE-field Linear gradients and one
+        gradient row per distinct id."""
+        self.emb.backward_rowsparse(self.inputs, g_fo, g_fe, self.dense_grads)
+
     def _body_a(self) -> None:
         self.opt.zero_grad()
         cur = torch.cuda.current_stream()
@@ -163,9 +186,9 @@ class RowSparseTrainStep:
         if side:
             self.side.wait_stream(cur)
             with torch.cuda.stream(self.side):
-                self.emb.build_rowplan(self.inputs, self.B)
+                self._build_rowplan()
         else:
-            self.emb.build_rowplan(self.inputs, self.B)
+            self._build_rowplan()
         fo = self.fo.detach().requires_grad_()
         fe = self.fe.detach().requires_grad_()
         logits = self.model._forward_components(fo, fe, fe.view(self.B, -1))
@@ -175,7 +198,7 @@ class RowSparseTrainStep:
         self.loss.copy_(loss.detach())
         if side:
             cur.wait_stream(self.side)
-        self.emb.backward_rowsparse(self.inputs, fo.grad, fe.grad, self.dense_grads)
+        self._embedding_backward(fo.grad, fe.grad)
 
     def _body_b(self) -> None:
         self.opt.apply()
@@ -224,8 +247,11 @@ class RowSparseTrainStep:
         # opt-in (DFM_DP_GRAPH_COLLECTIVE=1): capture the exchange inside the graph — one graph launch
         # per step under data parallelism.  Verified with a single-rank RCCL communicator only
         # (DFM_FORCE_DP_PATH=1); not validated on a multi-GPU box, hence not the default.
-        fused_exchange = ((not single) and os.environ.get("DFM_DP_GRAPH_COLLECTIVE") == "1"
-                          and torch.distributed.is_initialized() and torch.distributed.get_backend() == "nccl")
+        # A step whose collectives sit inside its body (exchange_in_body: the field-sharded step) has no
+        # split form: it is captured whole.
+        fused_exchange = self.exchange_in_body or (
+            (not single) and os.environ.get("DFM_DP_GRAPH_COLLECTIVE") == "1"
+            and torch.distributed.is_initialized() and torch.distributed.get_backend() == "nccl")
         # thread_local capture mode: another thread (the RCCL watchdog polling its events under
         # data parallelism) must not invalidate the capture
         mode = dict(capture_error_mode="thread_local")
@@ -245,10 +271,7 @@ class RowSparseTrainStep:
             slot.graph = torch.cuda.CUDAGraph(keep_graph=True)
             with torch.cuda.graph(slot.graph, **mode):
                 for _k in range(steps_per_graph):
-                    self._gather(self.pad)
-                    node = C.c_void_p()
-                    _lib.check(lib.dfm_graph_last_node(_lib.stream_handle(), C.byref(node)))
-                    slot.nodes.append(node)
+                    slot.nodes.append(self._capture_gather(self.pad))
                     body()
             slot.graph.instantiate()
             self.slots.append(slot)
@@ -266,6 +289,17 @@ class RowSparseTrainStep:
         with torch.no_grad():
             for t, v in zip(state, saved):
                 t.copy_(v)
+        torch.cuda.synchronize()
+
+    def release_graphs(self) -> None:
+        """Drop every captured graph (the step runs eagerly afterwards).  Call before
+        ``torch.distributed.destroy_process_group()`` when collectives were captured: the graphs hold the
+        communicator's kernels, and tearing the communicator down under them does not return."""
+        torch.cuda.synchronize()
+        self.slots, self.body_graph, self.graph_b = [], None, None
+        self.steps_per_graph, self._turn = 1, 0
+        import gc
+        gc.collect()
         torch.cuda.synchronize()
 
     def run_from(self, record: torch.Tensor, eager_gather: bool = False) -> None:
@@ -318,8 +352,7 @@ class RowSparseTrainStep:
             slot.done = torch.cuda.Event()
         ex = slot.graph.raw_cuda_graph_exec()
         for node, rec in zip(slot.nodes, records):
-            a, kw = self._gather_call(rec)
-            self.emb.forward_staged_update(ex, node, *a, **kw)
+            self._update_gather(ex, node, rec)
         slot.graph.replay()
         self._after_graph_a(slot.done)
 

@@ -29,6 +29,7 @@ extern "C" {
 
 #define DFM_ABI_VERSION 1
 #define DFM_MAX_FIELDS 64      /* per-call pointer tables travel as kernel arguments */
+#define DFM_MAX_RANKS 64       /* data-parallel ranks of one job (csrc/shard.hip) */
 #define DFM_ROWPLAN_CHUNK 4096 /* ids per sorted list (one LDS-resident sort) */
 
 enum dfm_status { DFM_OK = 0, DFM_ERR_INVALID = 1, DFM_ERR_HIP = 2, DFM_ERR_UNSUPPORTED = 3 };
@@ -508,16 +509,17 @@ int dfm_step_embedding_backward(const int32_t* d_dense_list, int num_dense, cons
  * memberships of every row in the other lists are resolved first by one extra launch through LDS
  * (the merge then does byte reads instead of num_lists - 1 global binary searches per row).
  * d_dense_gathered (optional, data parallel): (world, n) — every rank's dense gradient buffer from
- * the step's all-gather; d_g is then REPLACED by grad_scale * their sum in rank order (an
- * all-reduce with a fixed summation order and no launch of its own). */
+ * the step's exchange, rank r's at d_dense_gathered + r * gathered_stride floats (0 = n: contiguous);
+ * d_g is then REPLACED by grad_scale * their sum in rank order (an all-reduce with a fixed summation
+ * order and no launch of its own). */
 int64_t dfm_step_prepare_num_partials(int num_sparse, int dim, int num_lists, int64_t n);
 size_t dfm_step_match_bytes(int num_sparse, int num_lists);
 int dfm_step_prepare(const dfm_table* tables, int num_sparse, int dim, int num_lists,
                      const int32_t* d_uniq_rows, const int32_t* d_num_uniq, float* d_row_g2,
                      float* d_row_g1, int32_t* d_owner_flag, float grad_scale, float l2, float* d_g,
                      const float* d_p, int64_t n, int64_t n_l2, const dfm_slab_ref* slabs, int num_slabs,
-                     const float* d_dense_gathered, int world, float* d_partials, void* d_match,
-                     dfm_stream_t stream);
+                     const float* d_dense_gathered, int world, int64_t gathered_stride, float* d_partials,
+                     void* d_match, dfm_stream_t stream);
 /* dfm_rowadam_apply + dfm_dense_adam in one launch. */
 int dfm_step_apply(const dfm_table* tables, int num_sparse, int dim, int num_lists,
                    const int32_t* d_uniq_rows, const int32_t* d_num_uniq, const float* d_row_g2,
@@ -550,6 +552,45 @@ size_t dfm_weight_grad_workspace_bytes(int64_t rows, int n1, int n2);
 int dfm_weight_grad_f32(const float* d_g, int64_t ldg, const float* d_x, int64_t ldx, int64_t rows, int n1,
                         int n2, float* d_dw, int64_t lddw, float* d_db, int accumulate, void* d_workspace,
                         dfm_stream_t stream);
+
+/* ---------------------------------------------------------------------------------
+ * Field-sharded embedding tables under data parallelism (csrc/shard.hip).  The reference trains on one
+ * device (deepfm/training/trainer.py:47-56), so nothing of it is replaced here: these are the device
+ * halves of this build's N-GPU step — rank r owns the tables of a contiguous block of
+ * SPARSE fields, serves their rows to every rank's batch and receives the gradients back; three
+ * all-to-alls per step (ids, rows, gradients) carry plain contiguous buffers:
+ *   ids   segment for owner q : the batch's ids of q's fields               (nf_q, batch) int64
+ *   rows  segment for rank p  : [e (batch, nf_r, dim) | first-order w (batch, nf_r)]
+ *   grads segment for owner q : [d e (batch, nf_q, dim) | d first (batch) | dense gradients (n_dense)]
+ * ------------------------------------------------------------------------------- */
+/* Copy of a batch record into the step's static inputs as a kernel of its own (the first node of a
+ * captured step); _update re-points that node of an instantiated graph at another record (host-side
+ * only; see dfm_embedding_forward_staged_update for the rules). */
+int dfm_stage_record(const void* d_src, void* d_dst, int64_t nbytes, dfm_stream_t stream);
+int dfm_stage_record_update(void* graph_exec, void* node, const void* d_src, void* d_dst, int64_t nbytes);
+/* Owner side, forward: d_ids (world, num_owned, batch) as received -> d_send (world segments of
+ * batch * num_owned * (dim + 1) floats, layout above) and d_gids (num_owned, world * batch): the same
+ * ids field-major, the input of dfm_rowplan_build over the global batch.  tables[j] / vocab[j]: the
+ * owned tables in field order (Adam state pointers unused).  Out-of-range ids: row 0 + *d_error_flag |= 1. */
+int dfm_shard_gather(const dfm_table* tables, const int32_t* vocab, int num_owned, int dim, int world,
+                     int64_t batch, const int64_t* d_ids, float* d_send, int64_t* d_gids,
+                     int32_t* d_error_flag, dfm_stream_t stream);
+/* Batch side, backward: length in floats of one gradient segment, and the kernel that fills all of
+ * them: first_field[q] / field_count[q] = rank q's block of SPARSE fields (indices into
+ * field_of_sparse, which maps a SPARSE field to its schema position in d_g_field (batch, num_fields, dim)). */
+int64_t dfm_shard_pack_segment(int64_t batch, int num_owned, int dim, int64_t n_dense);
+int dfm_shard_pack(const int32_t* first_field, const int32_t* field_count, int world,
+                   const int32_t* field_of_sparse, int num_sparse, int num_fields, int dim, int64_t batch,
+                   const float* d_g_field, const float* d_g_first, const float* d_dense, int64_t n_dense,
+                   float* d_send, dfm_stream_t stream);
+/* Owner side, backward: dfm_rowgrad_build over the received gradient segments (d_recv: world segments
+ * of `segment` floats each, source-rank major; sample p * batch + b of the row plan is sample b of
+ * segment p). */
+int dfm_shard_rowgrad(int num_owned, int dim, int world, int64_t batch, const float* d_recv, int64_t segment,
+                      const int32_t* d_sorted_pos, const int32_t* d_seg_start, const int32_t* d_num_uniq,
+                      float* d_row_g2, float* d_row_g1, dfm_stream_t stream);
+/* *d_out = x[0] + ... + x[n-1] in a fixed order (one workgroup): a rank's share of |g|^2. */
+int dfm_sum_floats(const float* d_x, int64_t n, float* d_out, dfm_stream_t stream);
 
 #ifdef __cplusplus
 }

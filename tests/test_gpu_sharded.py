@@ -1,0 +1,164 @@
+"""GPU: data parallelism with field-sharded embedding tables (training/sharded.py, csrc/shard.hip).
+
+No reference counterpart (trainer.py:47-56 is single-device); what is pinned here:
+  * one rank, no process group: the sharded step — ids / rows / gradients through the all-to-all
+    buffers, local gather over received rows, row plan and row gradients from the received segments —
+    trains like the plain fused step (whose tail is pinned to reference goldens by
+    tests/test_gpu_train_golden.py); graph replay with a re-pointed staging node == eager, bit for bit;
+  * two ranks on cuda:0 over gloo: dense replicas stay bit-identical, and tables + dense parameters
+    match the replicated-table data-parallel step (same global batch, same per-rank BatchNorm) to
+    rounding (row gradients are summed in a different order);
+  * one rank over RCCL: the three all-to-alls and the norm all-gather captured inside the step's graph
+    == the same step run eagerly, bit for bit.
+"""
+import json
+import math
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _model(kind, V, D, seed=0):
+    from deepfm_amd.config import ExperimentConfig
+    from deepfm_amd.models import create_model
+    from tests.helpers import schema_from_fields
+    from tools_shared import criteo_fields
+    cfg = ExperimentConfig()
+    if kind == "xdeepfm":
+        cfg.cin.layer_sizes = [32, 16]
+    torch.manual_seed(seed)
+    with torch.device("cuda"):
+        model = create_model(kind, schema_from_fields(criteo_fields(V, D)), cfg)
+    model.train()
+    model.embedding.pack_tables_()
+    model.embedding.set_grad_mode("rowsparse")
+    return model
+
+
+def _batches(n, B, V, seed):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    ids = torch.randint(0, V, (n, 26, B), generator=g, device="cuda", dtype=torch.int64)
+    dense = torch.rand((n, 13, B), generator=g, device="cuda")
+    labels = (torch.rand((n, B), generator=g, device="cuda") < 0.3).float()
+    return ids, dense, labels
+
+
+def _state(model, opt):
+    tables = torch.cat([p.detach().reshape(-1) for p in model.embedding.table_parameters()])
+    moments = torch.cat([m.detach().reshape(-1) for m in opt.exp_avg] + [v.detach().reshape(-1) for v in opt.exp_avg_sq])
+    return dict(flat=opt.flat_param.clone(), tables=tables.clone(), moments=moments.clone(), m=opt.flat_m.clone())
+
+
+def _run(kind, sharded, use_graph, steps=4, B=512, V=300, D=16, spg=1):
+    from deepfm_amd.training.fused_step import fused_step_class
+    from deepfm_amd.training.rowsparse import RowSparseAdam
+    from deepfm_amd.training.sharded import make_sharded_step
+    model = _model(kind, V, D)
+    kw = dict(lr=1e-2, l2=1e-5, max_grad_norm=1.0)
+    if sharded:
+        step, opt, shard = make_sharded_step(model, B, use_graph=use_graph, **kw)
+    else:
+        opt = RowSparseAdam(model, **kw)
+        step = fused_step_class(model)(model, opt, B, use_graph=use_graph)
+    step.seed.fill_(1234)                                   # same dropout masks in every variant
+    ids, dense, labels = _batches(steps, B, V, 7)
+    recs = step.pack_batches(ids, dense, labels)
+    losses = []
+    if use_graph:
+        step.capture(steps_per_graph=spg)
+        for i in range(0, steps, spg):
+            if spg == 1:
+                step.run_from(recs[i])
+            else:
+                step.run_group([recs[i + k] for k in range(spg)])
+            losses.append(float(step.loss))
+    else:
+        for i in range(steps):
+            step.run_from(recs[i])
+            losses.append(float(step.loss))
+    torch.cuda.synchronize()
+    return _state(model, opt), losses
+
+
+def _close(a, b, what, rtol=2e-4):
+    a, b = a.double().cpu().numpy(), b.double().cpu().numpy()
+    scale = max(np.abs(b).max(), 1e-30)
+    err = np.abs(a - b)
+    bad = err > rtol * np.abs(b) + 2e-6 * scale
+    assert bad.mean() <= 1e-3, f"{what}: {bad.sum()} / {bad.size} out of tolerance (max err {err.max():.3e}, scale {scale:.3e})"
+
+
+@pytest.mark.parametrize("kind", ["deepfm", "xdeepfm", "attention_deepfm"])
+def test_one_rank_sharded_step_trains_like_the_fused_step(kind):
+    want, wl = _run(kind, sharded=False, use_graph=False)
+    got, gl = _run(kind, sharded=True, use_graph=False)
+    assert np.allclose(wl, gl, rtol=1e-5, atol=1e-7), (wl, gl)
+    for k in want:
+        _close(got[k], want[k], f"{kind} {k}")
+    assert float((got["tables"] != 0).float().mean()) > 0.5
+
+
+@pytest.mark.parametrize("spg", [1, 2])
+def test_sharded_graph_replay_equals_eager_bitwise(spg):
+    eager, el = _run("deepfm", sharded=True, use_graph=False)
+    graph, gl = _run("deepfm", sharded=True, use_graph=True, spg=spg)
+    assert el[spg - 1::spg] == gl
+    for k in eager:
+        assert torch.equal(eager[k], graph[k]), k
+
+
+def test_field_shards_partition():
+    from deepfm_amd.training.sharded import FieldShards
+    sh = FieldShards(26, 8)
+    assert sh.count == [4, 4, 3, 3, 3, 3, 3, 3] and sh.first == [0, 4, 8, 11, 14, 17, 20, 23]
+    assert [sh.owner(s) for s in (0, 3, 4, 25)] == [(0, 0), (0, 3), (1, 0), (7, 2)]
+    with pytest.raises(ValueError):
+        FieldShards(3, 4)
+
+
+def _launch(nproc, args, env_extra, dump=None):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "tests", "dp_rehearsal_worker.py")] + args
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **env_extra)
+    if dump:
+        env["DFM_REHEARSAL_DUMP"] = dump
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("RESULT ")]
+    assert line, p.stdout[-2000:]
+    return json.loads(line[0][len("RESULT "):])
+
+
+def test_two_ranks_sharded_vs_replicated(tmp_path):
+    rep = _launch(2, ["eager", "4", "fused"], {}, str(tmp_path / "rep"))
+    sh = _launch(2, ["eager", "4", "sharded"], {}, str(tmp_path / "sh"))
+    assert sh[0]["flat"] == sh[1]["flat"], "dense replicas diverged"
+    assert sh[0]["tables"] == sh[1]["tables"]               # after restore_tables: the owners' rows everywhere
+    assert all(math.isfinite(r["loss"]) for r in sh) and sh[0]["moved"] > 0.5
+    for r in range(2):
+        a, b = np.load(f"{tmp_path}/sh.rank{r}.npz"), np.load(f"{tmp_path}/rep.rank{r}.npz")
+        assert abs(float(a["loss"]) - float(b["loss"])) < 1e-5
+        for k in ("flat", "tables"):
+            _close(torch.from_numpy(a[k]), torch.from_numpy(b[k]), f"rank {r} {k}")
+
+
+def test_one_rank_rccl_collectives_inside_the_graph():
+    eager = _launch(1, ["eager", "4", "sharded", "nccl"], {})[0]
+    graph = _launch(1, ["graph", "4", "sharded", "nccl"], {})[0]
+    assert eager["flat"] == graph["flat"] and eager["tables"] == graph["tables"] and eager["loss"] == graph["loss"]
+    assert graph["moved"] > 0.5
