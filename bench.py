@@ -50,6 +50,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather-timing", action="store_true",
                     help="do not attach HIP events to the gather dispatches (roofline fields become null)")
+    ap.add_argument("--dp-mode", choices=("sharded", "replicated"), default="sharded",
+                    help="N > 1 ranks: embedding tables sharded by field over the ranks (rows and gradients of the batch "
+                         "travel by all-to-all, every row update is local) or replicated on every rank (row lists "
+                         "all-gathered, every replica applies every rank's row updates)")
     ap.add_argument("--unpacked", action="store_true", help="keep the tables as separate contiguous tensors")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-extra-configs", action="store_true",
@@ -147,9 +151,14 @@ def build_step(name, V, D, B, dev, args, cin_sizes=None):
         model.embedding.pack_tables_()        # 256-B row records: [w2 | w1 m1 v1 | m2 | v2]
     model.embedding.set_grad_mode("rowsparse")
     hp = dict(lr=cfg.training.lr, l2=cfg.feature.embedding_l2_reg, max_grad_norm=cfg.training.gradient_clip_norm)
-    opt = RowSparseAdam(model, lr=hp["lr"], l2=hp["l2"], max_grad_norm=hp["max_grad_norm"])
     cls = None if args.autograd else fused_step_class(model)
     fused = cls is not None
+    if dist.is_initialized() and args.dp_mode == "sharded" and fused and not args.unpacked:
+        # N ranks (or DFM_FORCE_DP_PATH=1: one rank over RCCL): tables sharded by field, three all-to-alls per step
+        from deepfm_amd.training.sharded import make_sharded_step
+        step, opt, _ = make_sharded_step(model, B, use_graph=not args.no_graph, **hp)
+        return model, opt, step, fields, cfg, hp, fused
+    opt = RowSparseAdam(model, lr=hp["lr"], l2=hp["l2"], max_grad_norm=hp["max_grad_norm"])
     step = (cls or RowSparseTrainStep)(model, opt, B, use_graph=not args.no_graph)
     return model, opt, step, fields, cfg, hp, fused
 
@@ -180,7 +189,7 @@ def extra_config(name, args, dev, lib):
     cin_sizes = [128, 128, 128] if name == "xdeepfm" else None
     model, opt, step, fields, cfg, hp, fused = build_step(name, V, D, B, dev, args, cin_sizes)
     n_sparse, n_dense = 26, 13
-    G = 1 if (args.no_graph or opt.split) else args.steps_per_graph
+    G = 1 if (args.no_graph or (opt.split and not step.exchange_in_body)) else args.steps_per_graph
     warm, steps = -(-10 // G) * G, max(args.extra_steps // G, 1) * G                   # whole graph launches
     ids, dense, labels = make_pool(warm + steps, n_sparse, n_dense, B, V, 101, dev)     # every batch used once
     records = step.pack_batches(ids, dense, labels)
@@ -290,7 +299,7 @@ def main():
     records = step.pack_batches(ids, dense, labels)      # one record per batch, resident in HBM
     step.load_packed(records[0])
     # several steps per graph need the whole step inside ONE graph: one rank without the split exchange path
-    spg = 1 if (opt.split or args.no_graph) else args.steps_per_graph
+    spg = 1 if ((opt.split and not step.exchange_in_body) or args.no_graph) else args.steps_per_graph
     step.capture(timed_variant=True, steps_per_graph=spg)
 
     feed = None
@@ -303,7 +312,7 @@ def main():
         loader = PackedBatchLoader(PackedColumns(model.schema, feats, labels.reshape(-1).cpu().numpy()), B)
         feed = iter(DeviceBatchRing(loader, dev, depth=4))
 
-    G = step.steps_per_graph if not args.no_graph else 1
+    G = step.steps_per_graph if (not args.no_graph and step.use_graph) else 1
 
     def rec(i):
         return next(feed) if feed is not None else records[i]
@@ -392,7 +401,8 @@ def main():
                             f"embed_dim {D}, batch {B}/GPU; step = fwd + BCE + L2 + bwd + clip + "
                             "row-wise Adam on touched rows (lazy L2) + dense Adam",
                 "global_batch": B * world,
-                "parallelism": f"dp{world}",
+                "parallelism": f"dp{world}" + ("" if not dist.is_initialized() else
+                                                f" ({'field-sharded tables, 3 all-to-alls + 1 scalar all-gather per step' if step.exchange_in_body else 'replicated tables, one grouped all-gather per step'})"),
                 "hip_graph": not args.no_graph,
                 "steps_per_graph": G,
                 "input": "host memory -> pinned staging -> H2D ring (PCIe-inclusive)" if args.h2d else "resident in HBM",
@@ -433,6 +443,8 @@ def main():
             out["extra_configs"] = [extra_config(n, args, dev, lib) for n in ("xdeepfm", "attention_deepfm")]
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
+        if "step" in locals():
+            step.release_graphs()        # graphs holding captured RCCL kernels must go before the communicator
         dist.destroy_process_group()
 
 

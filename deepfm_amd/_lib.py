@@ -156,7 +156,7 @@ SIGNATURES = {
     "dfm_shard_gather": (_I, [C.POINTER(Table), C.POINTER(C.c_int32), _I, _I, _I, _L, _P, _P, _P, _P, _P]),
     "dfm_shard_pack_segment": (_L, [_L, _I, _I, _L]),
     "dfm_shard_pack": (_I, [C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I, C.POINTER(C.c_int32), _I, _I, _I, _L,
-                            _P, _P, _P, _L, _P, _P]),
+                            _P, _P, _P, _L, C.POINTER(SlabRef), _I, _P, _P]),
     "dfm_shard_rowgrad": (_I, [_I, _I, _I, _L, _P, _L, _P, _P, _P, _P, _P, _P]),
     "dfm_sum_floats": (_I, [_P, _L, _P, _P]),
     "dfm_embedding_grad_combine": (_I, [_P, _L, _P, _P, _P, _P, _L, _I, _I, _P, _P]),

@@ -73,12 +73,15 @@ struct PackPlan {
 };
 
 // d field_embeddings (B, F, D), d first_order (B), the flat dense gradient (n) -> the send layout of the
-// gradient all-to-all: segment q = [d e of q's fields (B, nf_q, D) | d first (B) | dense (n)].
+// gradient all-to-all: segment q = [d e of q's fields (B, nf_q, D) | d first (B) | dense (n)].  The
+// batch-split d-weight slabs of the tower (dfm_linear_backward) are added on the way, in slab order
+// (what dfm_linear_backward_finish would have done in a launch of its own); the flat buffer itself is
+// left as it is — the optimizer's prepare launch replaces it by the mean over ranks.
 __global__ __launch_bounds__(kThreads) void shard_pack_kernel(PackPlan plan, int64_t B, int F, int D,
                                                               const float* __restrict__ g_field,
                                                               const float* __restrict__ g_first,
                                                               const float* __restrict__ dense, int64_t n,
-                                                              float* __restrict__ send) {
+                                                              SlabTable slabs, float* __restrict__ send) {
   const int64_t e = (static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x) * 4;
   if (e >= plan.seg_start[plan.world]) return;
   int q = 0;
@@ -96,7 +99,9 @@ __global__ __launch_bounds__(kThreads) void shard_pack_kernel(PackPlan plan, int
   } else if (o < rows + B) {
     v = ld4(g_first + (o - rows));
   } else {
-    v = ld4(dense + (o - rows - B));
+    const float* src = dense + (o - rows - B);
+    v = ld4(src);
+    add_slabs(v, src, slabs);
   }
   st4(send + e, v);
 }
@@ -200,7 +205,7 @@ extern "C" int64_t dfm_shard_pack_segment(int64_t batch, int num_owned, int dim,
 extern "C" int dfm_shard_pack(const int32_t* first_field, const int32_t* field_count, int world,
                               const int32_t* field_of_sparse, int num_sparse, int num_fields, int dim, int64_t batch,
                               const float* d_g_field, const float* d_g_first, const float* d_dense, int64_t n_dense,
-                              float* d_send, dfm_stream_t stream) {
+                              const dfm_slab_ref* slabs, int num_slabs, float* d_send, dfm_stream_t stream) {
   DFM_REQUIRE(first_field && field_count && field_of_sparse && d_g_field && d_g_first && d_dense && d_send, "null argument");
   DFM_REQUIRE(world > 0 && world <= DFM_MAX_RANKS && num_sparse > 0 && num_sparse <= DFM_MAX_FIELDS &&
                   num_fields <= DFM_MAX_FIELDS, "bad field / rank count");
@@ -222,9 +227,11 @@ extern "C" int dfm_shard_pack(const int32_t* first_field, const int32_t* field_c
     pp.count[q] = field_count[q];
     pp.seg_start[q + 1] = pp.seg_start[q] + dfm_shard_pack_segment(batch, field_count[q], dim, n_dense);
   }
+  SlabTable st;
+  if (int rc = fill_slab_table(slabs, num_slabs, d_dense, n_dense, &st)) return rc;
   const int64_t threads = pp.seg_start[world] / 4;
   hipLaunchKernelGGL(shard_pack_kernel, dim3(static_cast<unsigned>((threads + kThreads - 1) / kThreads)), dim3(kThreads), 0,
-                     as_stream(stream), pp, batch, num_fields, dim, d_g_field, d_g_first, d_dense, n_dense, d_send);
+                     as_stream(stream), pp, batch, num_fields, dim, d_g_field, d_g_first, d_dense, n_dense, st, d_send);
   DFM_LAUNCH_CHECK();
   return DFM_OK;
 }

@@ -15,18 +15,7 @@
 using namespace dfm;
 using namespace dfm::tail;
 
-extern "C" int dfm_linear_backward_splits(int64_t batch, int out_features, int in_features);
-
 namespace {
-constexpr int kMaxSlabs = 16;
-struct SlabTable {
-  const float* slabs[kMaxSlabs];
-  float* g[kMaxSlabs];
-  int64_t elems[kMaxSlabs];
-  int splits[kMaxSlabs];
-  int count;
-};
-
 // dense_prepare_body with the batch-split d-weight products folded in, ONE float4 per thread (the
 // slab sums want many threads with few dependent loads each): parameters start on 64-byte
 // boundaries and weights have a multiple of 4 elements, so a float4 belongs to at most one
@@ -56,27 +45,7 @@ __device__ __forceinline__ void dense_prepare_slabs_body(int blk, float* __restr
       gi.x *= scale; gi.y *= scale; gi.z *= scale; gi.w *= scale;
       dirty = true;
     }
-    for (int r = 0; r < st.count; ++r) {
-      const int64_t off = (g + i) - st.g[r];
-      if (off >= 0 && off < st.elems[r]) {
-        const float* sl = st.slabs[r] + off;
-        const int64_t stride = st.elems[r];
-        const int splits = st.splits[r];
-        int q = 0;
-        for (; q + 8 <= splits; q += 8) {
-          float4 t[8];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) t[u] = ld4(sl + (q + u) * stride);
-#pragma unroll
-          for (int u = 0; u < 8; ++u) { gi.x += t[u].x; gi.y += t[u].y; gi.z += t[u].z; gi.w += t[u].w; }
-        }
-        for (; q < splits; ++q) {
-          const float4 t = ld4(sl + q * stride);
-          gi.x += t.x; gi.y += t.y; gi.z += t.z; gi.w += t.w;
-        }
-        dirty = true;
-      }
-    }
+    if (add_slabs(gi, g + i, st)) dirty = true;
     if (i < n_l2) {                          // n_l2 is a multiple of 16 (padded parameters)
       const float4 pi = ld4(p + i);
       gi.x = fmaf(k, pi.x, gi.x); gi.y = fmaf(k, pi.y, gi.y); gi.z = fmaf(k, pi.z, gi.z); gi.w = fmaf(k, pi.w, gi.w);
@@ -241,7 +210,6 @@ extern "C" int dfm_step_prepare(const dfm_table* tables, int num_sparse, int dim
   DFM_REQUIRE(n > 0 && n_l2 >= 0 && n_l2 <= n && n_l2 % 16 == 0, "bad dense sizes (n_l2 must be a multiple of 16)");
   DFM_REQUIRE((reinterpret_cast<uintptr_t>(d_g) & 63) == 0 && (reinterpret_cast<uintptr_t>(d_p) & 15) == 0,
               "dense buffers must be 64-byte aligned");
-  DFM_REQUIRE(num_slabs >= 0 && num_slabs <= kMaxSlabs && (num_slabs == 0 || slabs), "0..%d slab references", kMaxSlabs);
   DFM_REQUIRE(!d_dense_gathered || (world >= 1 && (reinterpret_cast<uintptr_t>(d_dense_gathered) & 15) == 0 && n % 4 == 0),
               "gathered dense gradients: world >= 1, 16-byte aligned, n a multiple of 4");
   if (d_dense_gathered && gathered_stride == 0) gathered_stride = n;
@@ -250,19 +218,7 @@ extern "C" int dfm_step_prepare(const dfm_table* tables, int num_sparse, int dim
   TableArgs ta;
   if (int rc = fill_tables(tables, num_sparse, dim, &ta, false)) return rc;
   SlabTable st = {};
-  for (int i = 0; i < num_slabs; ++i) {
-    const dfm_slab_ref& h = slabs[i];
-    DFM_REQUIRE(h.workspace && h.g_w && h.batch > 0 && h.out_features > 0 && h.in_features > 0, "incomplete dfm_slab_ref");
-    const int64_t elems = static_cast<int64_t>(h.out_features) * h.in_features;
-    DFM_REQUIRE(elems % 4 == 0 && (reinterpret_cast<uintptr_t>(h.workspace) & 15) == 0 && h.g_w >= d_g &&
-                    h.g_w + elems <= d_g + n && ((h.g_w - d_g) % 16) == 0,
-                "slab-backed weights must be 64-byte aligned views of the dense gradient buffer");
-    st.slabs[i] = static_cast<const float*>(h.workspace);
-    st.g[i] = h.g_w;
-    st.elems[i] = elems;
-    st.splits[i] = dfm_linear_backward_splits(h.batch, h.out_features, h.in_features);
-  }
-  st.count = num_slabs;
+  if (int rc = fill_slab_table(slabs, num_slabs, d_g, n, &st)) return rc;
   const int64_t mb = row_blocks(num_sparse, dim, num_lists), pb = prep_blocks(n);
   // with three or more lists (data-parallel ranks x chunks) the list memberships are resolved once,
   // through LDS, instead of by L-1 global binary searches per entry inside the merge

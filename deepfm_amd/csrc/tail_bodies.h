@@ -20,6 +20,45 @@ struct TableArgs {
   dfm_table t[DFM_MAX_FIELDS];
 };
 
+// Batch-split d-weight products of dfm_linear_backward (tower.hip): `splits` slabs of `elems` floats
+// each, to be added in slab order into the weight's view `g` of the flat dense gradient.
+constexpr int kMaxSlabs = 16;
+struct SlabTable {
+  const float* slabs[kMaxSlabs];
+  float* g[kMaxSlabs];
+  int64_t elems[kMaxSlabs];
+  int splits[kMaxSlabs];
+  int count;
+};
+
+// gi += the slabs of the float4 at `gptr` (an address inside the flat gradient buffer; parameters start
+// on 64-byte boundaries, so a float4 belongs to at most one slab-backed weight); true if any were added.
+__device__ __forceinline__ bool add_slabs(float4& gi, const float* gptr, const SlabTable& st) {
+  bool any = false;
+  for (int r = 0; r < st.count; ++r) {
+    const int64_t off = gptr - st.g[r];
+    if (off >= 0 && off < st.elems[r]) {
+      const float* sl = st.slabs[r] + off;
+      const int64_t stride = st.elems[r];
+      const int splits = st.splits[r];
+      int q = 0;
+      for (; q + 8 <= splits; q += 8) {
+        float4 t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = ld4(sl + (q + u) * stride);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { gi.x += t[u].x; gi.y += t[u].y; gi.z += t[u].z; gi.w += t[u].w; }
+      }
+      for (; q < splits; ++q) {
+        const float4 t = ld4(sl + q * stride);
+        gi.x += t.x; gi.y += t.y; gi.z += t.z; gi.w += t.w;
+      }
+      any = true;
+    }
+  }
+  return any;
+}
+
 // fixed-order sum of `sq` over the workgroup's 4 waves -> partial[blk]
 __device__ __forceinline__ void block_partial(float sq, float* __restrict__ partial, int blk) {
   __shared__ float wsum[4];
@@ -308,5 +347,31 @@ __device__ __forceinline__ void dense_adam_body(int blk, float* __restrict__ p, 
   if (g_zero) g_zero[i] = 0.f;       // the gradient buffer is ready for the next step's accumulation
 }
 
+}  // namespace tail
+}  // namespace dfm
+
+extern "C" int dfm_linear_backward_splits(int64_t batch, int out_features, int in_features);
+
+namespace dfm {
+namespace tail {
+// host: dfm_slab_ref[] -> SlabTable (every g_w must be a 64-byte aligned view of d_g[0 .. n))
+inline int fill_slab_table(const dfm_slab_ref* slabs, int num_slabs, const float* d_g, int64_t n, SlabTable* st) {
+  DFM_REQUIRE(num_slabs >= 0 && num_slabs <= kMaxSlabs && (num_slabs == 0 || slabs), "0..%d slab references", kMaxSlabs);
+  memset(st, 0, sizeof(*st));
+  for (int i = 0; i < num_slabs; ++i) {
+    const dfm_slab_ref& h = slabs[i];
+    DFM_REQUIRE(h.workspace && h.g_w && h.batch > 0 && h.out_features > 0 && h.in_features > 0, "incomplete dfm_slab_ref");
+    const int64_t elems = static_cast<int64_t>(h.out_features) * h.in_features;
+    DFM_REQUIRE(elems % 4 == 0 && (reinterpret_cast<uintptr_t>(h.workspace) & 15) == 0 && h.g_w >= d_g &&
+                    h.g_w + elems <= d_g + n && ((h.g_w - d_g) % 16) == 0,
+                "slab-backed weights must be 64-byte aligned views of the dense gradient buffer");
+    st->slabs[i] = static_cast<const float*>(h.workspace);
+    st->g[i] = h.g_w;
+    st->elems[i] = elems;
+    st->splits[i] = dfm_linear_backward_splits(h.batch, h.out_features, h.in_features);
+  }
+  st->count = num_slabs;
+  return DFM_OK;
+}
 }  // namespace tail
 }  // namespace dfm

@@ -104,8 +104,9 @@ def all_to_all(out: torch.Tensor, inp: torch.Tensor, out_splits: Sequence[int], 
     dist.all_to_all_single(out, inp, list(out_splits), list(in_splits), group=group)
 
 
-def all_gather_scalars(out: torch.Tensor, mine: torch.Tensor, group: Optional[dist.ProcessGroup] = None) -> None:
-    """``out[r] = mine`` of rank r (``mine``: one element).  One rank without a process group: a copy."""
+def all_gather_flat(out: torch.Tensor, mine: torch.Tensor, group: Optional[dist.ProcessGroup] = None) -> None:
+    """``out[r * n : (r + 1) * n] = mine`` of rank r (``mine``: n contiguous elements).  One rank without a
+    process group: a copy."""
     if not (dist.is_available() and dist.is_initialized()):
         out.copy_(mine)
         return

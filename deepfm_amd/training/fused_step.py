@@ -58,9 +58,11 @@ class _FusedTowerStep(RowSparseTrainStep):
     (``_interaction_backward`` -> the epilogue of the first Linear's d input)."""
 
     head_name = "output_linear"
+    slabs_travel = False         # True: _embedding_backward consumes self._slab_refs (training/sharded.py)
 
     def __init__(self, model, optimizer: RowSparseAdam, batch_size: int, use_graph: bool = True) -> None:
         super().__init__(model, optimizer, batch_size, use_graph)
+        self._slab_refs = None
         if not self.eligible(model):
             raise ValueError(f"{type(self).__name__}: model/configuration not eligible (use RowSparseTrainStep)")
         lib = _lib.load()
@@ -199,7 +201,9 @@ class _FusedTowerStep(RowSparseTrainStep):
             r, lin = refs[i], self.lin[i]
             r.workspace, r.g_w = self.ws_lin[i].data_ptr(), lin.weight.grad.data_ptr()
             r.batch, r.out_features, r.in_features = B, lin.out_features, lin.in_features
-        if not self.opt.split:
+        if self.slabs_travel:
+            self._slab_refs = (refs, self.L)         # summed by the gradient pack kernel (field-sharded tables)
+        elif not self.opt.split:
             self.opt.slab_refs = (refs, self.L)      # summed by the optimizer's prepare launch
         else:
             _lib.check(lib.dfm_linear_backward_finish(refs, self.L, st))    # must precede the all-reduce

@@ -117,7 +117,6 @@ class RowSparseAdam:
         self._partials = None
         self._match = None
         self._cur = None
-        self._extra_partials = 0                         # floats kept free behind the norm partials (sharded tables)
         self.seed_tick: Optional[torch.Tensor] = None    # int64 device counter advanced once per apply()
         # (dfm_slab_ref[], count): d-weight slabs of dfm_linear_backward that apply() folds into the flat
         # gradient (single rank only: under data parallelism they must be in before the all-reduce)
@@ -181,7 +180,8 @@ class RowSparseAdam:
         n_partials = lib.dfm_step_prepare_num_partials(self.num_sparse, self.dim, lists, n_dense)
         if self._owner is None or self._owner.shape != uniq.shape:
             self._owner = torch.empty_like(uniq)
-            self._partials = torch.zeros(n_partials + self._extra_partials, dtype=torch.float32, device=self.device)
+            self._partials = torch.zeros(n_partials + self._extra_partial_count(lists), dtype=torch.float32,
+                                         device=self.device)
             mbytes = lib.dfm_step_match_bytes(self.num_sparse, lists)
             self._match = torch.empty(mbytes, dtype=torch.uint8, device=self.device) if mbytes else None
         dense_gathered, gathered_stride = self._dense_source()
@@ -213,6 +213,10 @@ class RowSparseAdam:
                 and self._cur[0] is self._gathered[1]):
             return self._gathered[0], 0
         return None, 0
+
+    def _extra_partial_count(self, lists: int) -> int:
+        """Floats kept free behind the norm partials (subclasses that exchange partial norms)."""
+        return 0
 
     def _norm_partials(self, n_partials: int, lists: int):
         """(address, count) of the floats whose sum is the squared global gradient norm."""

@@ -147,9 +147,7 @@ class ShardedRowAdam(RowSparseAdam):
         self.shard = shard
         self.world = shard.world
         self.split = True                     # d-weight slabs must be in the flat gradient before it travels
-        self._extra_partials = self.world
         self.dense_source: Optional[Tuple[torch.Tensor, int]] = None
-        self._sq_local = torch.zeros(1, dtype=torch.float32, device=self.device)
 
     @torch.no_grad()
     def exchange(self) -> None:
@@ -163,16 +161,22 @@ class ShardedRowAdam(RowSparseAdam):
             raise RuntimeError("ShardedRowAdam: the step has not attached its gradient receive buffer")
         return self.dense_source
 
+    def _row_partials(self, lists: int) -> int:
+        return _lib.load().dfm_rowadam_num_partials(self.num_sparse, self.dim, lists)
+
+    def _extra_partial_count(self, lists: int) -> int:
+        return self.world * self._row_partials(lists)
+
     def _norm_partials(self, n_partials: int, lists: int):
-        lib = _lib.load()
-        rows = lib.dfm_rowadam_num_partials(self.num_sparse, self.dim, lists)
         if self.max_grad_norm is None:
             # no clip: nothing downstream reads the norm; the step / seed tick still happens in finalize
             return self._partials.data_ptr(), n_partials
-        # [row partials (this rank's rows) | dense partials (identical on every rank) | one float per rank]
-        _lib.check(lib.dfm_sum_floats(self._partials.data_ptr(), rows, self._sq_local.data_ptr(), _lib.stream_handle()))
-        exchange.all_gather_scalars(self._partials[n_partials:n_partials + self.world], self._sq_local, self.group)
-        return self._partials.data_ptr() + 4 * rows, n_partials - rows + self.world
+        # [row partials of this rank's rows | dense partials (identical on every rank) | every rank's row
+        #  partials, all-gathered]: summed from the second block on, in the same order on every rank
+        rows = self._row_partials(lists)
+        exchange.all_gather_flat(self._partials[n_partials:n_partials + self.world * rows], self._partials[:rows],
+                                 self.group)
+        return self._partials.data_ptr() + 4 * rows, n_partials - rows + self.world * rows
 
 
 class ShardedStepMixin:
@@ -180,6 +184,7 @@ class ShardedStepMixin:
     touch points — gather, row plan, embedding backward — with their sharded forms."""
 
     exchange_in_body = True
+    slabs_travel = True          # the tower's d-weight slabs are summed by the gradient pack kernel
 
     def __init__(self, model, optimizer: ShardedRowAdam, batch_size: int, use_graph: bool = True) -> None:
         if not isinstance(optimizer, ShardedRowAdam):
@@ -286,8 +291,9 @@ class ShardedStepMixin:
         # DENSE-field Linear gradients -> the flat dense gradient (complete after this launch)
         self.emb.backward_rowsparse(self.local_inputs, g_fo, g_fe, self.dense_grads, sparse=False)
         flat = self.opt.flat_grad
+        refs, n_refs = self._slab_refs if self._slab_refs is not None else (None, 0)
         _lib.check(lib.dfm_shard_pack(self._first, self._count, sh.world, self._fmap, len(self.emb._sparse_pos), F, D, B,
-                                      g_fe.data_ptr(), g_fo.data_ptr(), flat.data_ptr(), flat.numel(),
+                                      g_fe.data_ptr(), g_fo.data_ptr(), flat.data_ptr(), flat.numel(), refs, n_refs,
                                       self.grad_send.data_ptr(), st))
         exchange.all_to_all(self.grad_recv, self.grad_send, self.grad_out_splits, self.grad_in_splits, sh.group)
         rs = sh.emb.rowsparse

@@ -577,12 +577,14 @@ int dfm_shard_gather(const dfm_table* tables, const int32_t* vocab, int num_owne
                      int32_t* d_error_flag, dfm_stream_t stream);
 /* Batch side, backward: length in floats of one gradient segment, and the kernel that fills all of
  * them: first_field[q] / field_count[q] = rank q's block of SPARSE fields (indices into
- * field_of_sparse, which maps a SPARSE field to its schema position in d_g_field (batch, num_fields, dim)). */
+ * field_of_sparse, which maps a SPARSE field to its schema position in d_g_field (batch, num_fields, dim)).
+ * `slabs` (optional, as in dfm_step_prepare): dfm_linear_backward workspaces whose batch-split products are
+ * added to their weights' part of the dense segment on the way (d_dense itself is not modified). */
 int64_t dfm_shard_pack_segment(int64_t batch, int num_owned, int dim, int64_t n_dense);
 int dfm_shard_pack(const int32_t* first_field, const int32_t* field_count, int world,
                    const int32_t* field_of_sparse, int num_sparse, int num_fields, int dim, int64_t batch,
                    const float* d_g_field, const float* d_g_first, const float* d_dense, int64_t n_dense,
-                   float* d_send, dfm_stream_t stream);
+                   const dfm_slab_ref* slabs, int num_slabs, float* d_send, dfm_stream_t stream);
 /* Owner side, backward: dfm_rowgrad_build over the received gradient segments (d_recv: world segments
  * of `segment` floats each, source-rank major; sample p * batch + b of the row plan is sample b of
  * segment p). */
