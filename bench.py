@@ -273,6 +273,13 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    json_out = sys.stdout
+    if world > 1 or os.environ.get("DFM_FORCE_DP_PATH") == "1":
+        # RCCL prints its version banner on stdout when a communicator comes up; the contract is ONE JSON
+        # line there, so everything else written to fd 1 goes to stderr and the result to a saved copy
+        json_out = os.fdopen(os.dup(1), "w")
+        sys.stdout.flush()
+        os.dup2(2, 1)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearsal:
@@ -441,7 +448,7 @@ def main():
             del step, opt, model, records
             torch.cuda.empty_cache()
             out["extra_configs"] = [extra_config(n, args, dev, lib) for n in ("xdeepfm", "attention_deepfm")]
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=json_out, flush=True)
     if dist.is_initialized():
         if "step" in locals():
             step.release_graphs()        # graphs holding captured RCCL kernels must go before the communicator

@@ -82,28 +82,37 @@ __global__ __launch_bounds__(kThreads) void shard_pack_kernel(PackPlan plan, int
                                                               const float* __restrict__ g_first,
                                                               const float* __restrict__ dense, int64_t n,
                                                               SlabTable slabs, float* __restrict__ send) {
-  const int64_t e = (static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x) * 4;
-  if (e >= plan.seg_start[plan.world]) return;
-  int q = 0;
-  while (e >= plan.seg_start[q + 1]) ++q;
-  const int64_t o = e - plan.seg_start[q];
-  const int nf = plan.count[q];
-  const int64_t rows = B * nf * D;
-  float4 v;
-  if (o < rows) {
+  // one float4 per thread, three ranges of threads: [d e of every SPARSE field | d first, once per peer |
+  // the dense gradient, computed once and stored into every peer's segment]
+  int64_t t = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+  const int S = plan.first[plan.world - 1] + plan.count[plan.world - 1];
+  const int64_t emb4 = B * S * D / 4, first4 = B / 4, dense4 = n / 4;
+  if (t < emb4) {
+    const int64_t e = t * 4;                           // segments' row parts back to back: q's starts at B * first[q] * D
+    int q = 0;
+    while (q + 1 < plan.world && e >= B * plan.first[q + 1] * D) ++q;
+    const int64_t o = e - B * plan.first[q] * D;
+    const int nf = plan.count[q];
     const int64_t r = o / D;                           // b * nf + j
     const int64_t b = r / nf;
     const int j = static_cast<int>(r - b * nf);
     const int f = plan.field_of_sparse[plan.first[q] + j];
-    v = ld4(g_field + (b * F + f) * D + (o - r * D));
-  } else if (o < rows + B) {
-    v = ld4(g_first + (o - rows));
-  } else {
-    const float* src = dense + (o - rows - B);
-    v = ld4(src);
-    add_slabs(v, src, slabs);
+    st4(send + plan.seg_start[q] + o, ld4(g_field + (b * F + f) * D + (o - r * D)));
+    return;
   }
-  st4(send + e, v);
+  t -= emb4;
+  if (t < first4 * plan.world) {
+    const int q = static_cast<int>(t / first4);
+    const int64_t o = (t - q * first4) * 4;
+    st4(send + plan.seg_start[q] + B * plan.count[q] * D + o, ld4(g_first + o));
+    return;
+  }
+  t -= first4 * plan.world;
+  if (t >= dense4) return;
+  const float* src = dense + t * 4;
+  float4 v = ld4(src);
+  add_slabs(v, src, slabs);
+  for (int q = 0; q < plan.world; ++q) st4(send + plan.seg_start[q] + B * plan.count[q] * D + B + t * 4, v);
 }
 
 __global__ __launch_bounds__(kThreads) void shard_rowgrad_kernel(FieldMap fm, int S, int D, int lists,
@@ -229,7 +238,11 @@ extern "C" int dfm_shard_pack(const int32_t* first_field, const int32_t* field_c
   }
   SlabTable st;
   if (int rc = fill_slab_table(slabs, num_slabs, d_dense, n_dense, &st)) return rc;
-  const int64_t threads = pp.seg_start[world] / 4;
+  DFM_REQUIRE(pp.first[0] == 0, "rank 0 owns the first SPARSE fields");
+  for (int q = 1; q < world; ++q)
+    DFM_REQUIRE(pp.first[q] == pp.first[q - 1] + pp.count[q - 1], "the ranks' field blocks must be contiguous and in rank order");
+  DFM_REQUIRE(pp.first[world - 1] + pp.count[world - 1] == num_sparse, "the ranks' field blocks must cover every SPARSE field");
+  const int64_t threads = batch * num_sparse * dim / 4 + batch / 4 * world + n_dense / 4;
   hipLaunchKernelGGL(shard_pack_kernel, dim3(static_cast<unsigned>((threads + kThreads - 1) / kThreads)), dim3(kThreads), 0,
                      as_stream(stream), pp, batch, num_fields, dim, d_g_field, d_g_first, d_dense, n_dense, st, d_send);
   DFM_LAUNCH_CHECK();

@@ -83,10 +83,11 @@ __global__ __launch_bounds__(kTailThreads) void step_embedding_backward_kernel(
                  row_g1);
 }
 
-__global__ __launch_bounds__(kTailThreads) void step_match_kernel(int S, int L, const int32_t* __restrict__ uniq_rows,
+constexpr int kMatchThreads = 1024;
+__global__ __launch_bounds__(kMatchThreads) void step_match_kernel(int S, int L, const int32_t* __restrict__ uniq_rows,
                                                                   const int32_t* __restrict__ num_uniq,
                                                                   uint8_t* __restrict__ match) {
-  rowadam_match_body(blockIdx.x, S, L, uniq_rows, num_uniq, match);
+  rowadam_match_body<kMatchThreads>(blockIdx.x, S, L, uniq_rows, num_uniq, match);
 }
 
 __global__ __launch_bounds__(kTailThreads) void step_prepare_kernel(
@@ -226,7 +227,7 @@ extern "C" int dfm_step_prepare(const dfm_table* tables, int num_sparse, int dim
   if (match) {
     DFM_REQUIRE(num_lists <= 255, "at most 255 lists");
     hipLaunchKernelGGL(step_match_kernel, dim3(static_cast<unsigned>(num_sparse * num_lists * num_lists)),
-                       dim3(kTailThreads), 0, as_stream(stream), num_sparse, num_lists, d_uniq_rows, d_num_uniq, match);
+                       dim3(kMatchThreads), 0, as_stream(stream), num_sparse, num_lists, d_uniq_rows, d_num_uniq, match);
     DFM_LAUNCH_CHECK();
   }
   hipLaunchKernelGGL(step_prepare_kernel, dim3(static_cast<unsigned>(mb + pb)), dim3(kTailThreads), 0,

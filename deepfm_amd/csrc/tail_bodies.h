@@ -179,6 +179,9 @@ __device__ __forceinline__ int find_row(const int32_t* __restrict__ rows, int n,
 // workgroup (s, ln, lq) holds list ln's sorted rows in LDS (16 KB) and answers list lq's <= 4096
 // queries with LDS binary searches; match[(lq*S+s)*CH + u][ln] = 1 iff found.  Replaces the
 // O(L^2) global-memory binary searches of the merge when many lists (data-parallel ranks) meet.
+// THREADS per workgroup: the queries are independent chains of ~12 dependent LDS reads, so the kernel wants
+// as many of them in flight as a workgroup can hold (1024: 4 queries per thread instead of 16).
+template <int THREADS>
 __device__ __forceinline__ void rowadam_match_body(int blk, int S, int L, const int32_t* __restrict__ uniq_rows,
                                                    const int32_t* __restrict__ num_uniq,
                                                    uint8_t* __restrict__ match) {
@@ -189,9 +192,9 @@ __device__ __forceinline__ void rowadam_match_body(int blk, int S, int L, const 
   if (ln == lq) return;
   const int64_t lt = static_cast<int64_t>(ln) * S + s, lqs = static_cast<int64_t>(lq) * S + s;
   const int nt = num_uniq[lt], nq = num_uniq[lqs];
-  for (int i = threadIdx.x; i < nt; i += kTailThreads) rows[i] = uniq_rows[lt * CH + i];
+  for (int i = threadIdx.x; i < nt; i += THREADS) rows[i] = uniq_rows[lt * CH + i];
   __syncthreads();
-  for (int u = threadIdx.x; u < nq; u += kTailThreads) {
+  for (int u = threadIdx.x; u < nq; u += THREADS) {
     const int32_t row = uniq_rows[lqs * CH + u];
     int lo = 0, hi = nt;
     while (lo < hi) {
