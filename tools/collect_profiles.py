@@ -63,3 +63,30 @@ if gk:
     out["frac_of_8TBps_at_kernel_trace_avg"] = bench["roofline"]["algorithmic_bytes_per_launch"] / (out["kernel_trace_avg_us"] * 1e-6) / 8e12
 json.dump(out, open(os.path.join(dst, f"{tag}_gather_pmc.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
+
+
+# ---- tools/profile_extras.sh: layers, the field-sharded step, the simulated rank, the replicated tail
+def last_json(path):
+    lines = [ln for ln in open(path) if ln.startswith("{")]
+    return json.loads(lines[-1]) if lines else None
+
+
+for name, to in (("layer_cin_kernel_stats.csv", "cin_cfg3_kernel_stats.csv"), ("layer_attn_kernel_stats.csv", "attention_cfg4_kernel_stats.csv"),
+                 ("sharded_dp1_kernel_stats.csv", "sharded_dp1_kernel_stats.csv"), ("sharded_sim1.txt", "sharded_sim_rank0_of_1.txt"),
+                 ("sharded_sim8.txt", "sharded_sim_rank0_of_8.txt"), ("replicated_tail.txt", "replicated_tail.txt"),
+                 ("layer_cin.txt", "cin_cfg3_layer_time.txt"), ("layer_attn.txt", "attention_cfg4_layer_time.txt")):
+    if os.path.exists(os.path.join(src, name)):
+        shutil.copy(os.path.join(src, name), os.path.join(dst, f"{tag}_{to}"))
+dp = {}
+for name, key in (("sharded_bench_untraced.json", "field_sharded_one_rank_rccl"), ("replicated_bench_untraced.json", "replicated_one_rank_rccl")):
+    path = os.path.join(src, name)
+    if os.path.exists(path):
+        b = last_json(path)
+        if b:
+            dp[key] = {k: b[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup")} | {"parallelism": b["config"]["parallelism"],
+                                                                                       "steps_per_graph": b["config"]["steps_per_graph"]}
+if dp:
+    dp["plain_single_gpu"] = {"value": bench["value"], "ms_per_step": bench["ms_per_step"]}
+    dp["command"] = "DFM_FORCE_DP_PATH=1 python3 bench.py --steps 200 --warmup 40 --no-cpu-baseline --no-extra-configs [--dp-mode replicated]"
+    json.dump(dp, open(os.path.join(dst, f"{tag}_dp_structure_one_gpu.json"), "w"), indent=1)
+    print(json.dumps(dp, indent=1))
