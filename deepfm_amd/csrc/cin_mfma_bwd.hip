@@ -277,17 +277,53 @@ struct CinWgradArgs {
   int64_t B;
   int F, H, MB, KT, slices, FP;  // KT: 32-wide column tiles over k' = h*FP + f (FP = padded F)
   int bias_col;                  // 1: column k' = F carries the bias gradient (needs FP > F)
+  unsigned long long* stamps;    // tools/microbench_cin_wgrad only (DFM_CIN_STAMPS build): per-wave phase sums
 };
 
-// grid (ceil(KT/4), slices); a wave owns one 32-column tile of k', all C rows.  One pipeline step
-// = kWgStep samples; dY fragments (A) go global -> registers -> LDS one step ahead, the
-// hidden / x0 pieces (B) global -> registers one step ahead.
-constexpr int kWgStep = 2;
+// grid (ceil(KT/4), slices); a wave owns one 32-column tile of k', all C rows; one pipeline step = one
+// sample (= one 32x32x16 k-step per row block).  dY fragments (A) go global -> registers -> LDS one step
+// ahead (split to bf16 hi / lo on the way), the hidden / x0 rows (B) global -> registers one step ahead.
+//
+// The loop is written to be ISSUE-lean (round 2: it ran 124 VALU + 66 SALU instructions per 12 MFMAs, 57 of
+// them v_mov — zero fills and exec-masked paths around conditional loads — and every unit's time simply
+// added up: 1.4 us per sample and workgroup).  Now every load is unconditional: rows / columns / samples
+// that do not exist are CLAMPED to ones that do (their accumulator rows and slab columns are never read
+// by the reduce kernel), the bias column reads a constant row of ones through a per-lane stride of 0, the
+// two LDS buffers are two unrolled copies of the step (immediate offsets), and three workgroups share a CU.
+// 16-byte load through a GLOBAL-address-space pointer: a select between two objects (kWgOnes / a tensor)
+// leaves the compiler with a generic pointer, and flat loads count against lgkmcnt too — every wait for an
+// LDS read would then also wait for the HBM loads in flight
+typedef float gf4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld4g(const float* p) {
+  const gf4 v = *reinterpret_cast<const __attribute__((address_space(1))) gf4*>(reinterpret_cast<uintptr_t>(p));
+  return float4{v.x, v.y, v.z, v.w};
+}
+__device__ const float kWgOnes[16] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+#ifndef WG_OCC
+#define WG_OCC 2
+#endif
+constexpr int kWgOcc = WG_OCC;          // workgroups per CU (<= 256 VGPRs)
+#ifndef WG_LB
+#define WG_LB 2
+#endif
+constexpr int kWgBound = WG_LB;
+#ifndef WG_DEPTH
+#define WG_DEPTH 1
+#endif
+constexpr int kWgDepth = WG_DEPTH;      // samples of global-load look-ahead (build-time tunables: tools/microbench_cin_wgrad)
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
 
 template <bool SPLIT>
-__global__ __launch_bounds__(256, 2) void cin_wgrad_mfma(CinWgradArgs a) {
-  constexpr int SLAB = kWgStep * 4 * 64 * 16;            // one hi (or lo) slab: samples x MB x 1 KiB
-  __shared__ __attribute__((aligned(16))) unsigned char wbuf[2 * 2 * SLAB];   // [buf][hi,lo]
+__global__ __launch_bounds__(256, kWgBound) void cin_wgrad_mfma(CinWgradArgs a) {
+  constexpr int SLAB = 4 * 64 * 16;                       // one sample: 4 row blocks x 64 lanes x 16 B (hi or lo)
+  __shared__ __attribute__((aligned(16))) unsigned char wbuf[2 * 2 * SLAB];   // [buf][hi, lo]
   const int lane = lane_id(), wave = wave_id_uniform(), tid = threadIdx.x;
   const int kt = blockIdx.x * 4 + wave;
   const int kcol = kt * 32 + (lane & 31), hf = lane >> 5;
@@ -298,132 +334,149 @@ __global__ __launch_bounds__(256, 2) void cin_wgrad_mfma(CinWgradArgs a) {
   const bool kbias = a.bias_col && kt < a.KT && h == 0 && f == a.F;
   const int64_t per = (a.B + a.slices - 1) / a.slices;
   const int64_t b0 = blockIdx.y * per, b1 = b0 + per < a.B ? b0 + per : a.B;
-  const int64_t nsteps = b1 > b0 ? (b1 - b0 + kWgStep - 1) / kWgStep : 0;
+  const int n = b1 > b0 ? static_cast<int>(b1 - b0) : 0;
   f32x16 acc[4] = {};
-  const int s_mb = tid >> 6, s_lane = tid & 63;
   // A operand: fragment (mb, lane = hf*32 + r) of a sample is dY[b][32 mb + r][8 hf .. 8 hf + 7] — 32
-  // contiguous bytes of fp32, the same bytes a pre-packed bf16 hi + lo pair would take; the split into
-  // bf16 hi / lo happens on the way into LDS (a separate cin_pack_dy pass cost 21 us per layer).
-  float4 rf[kWgStep][2] = {};
-  const int s_c = 32 * s_mb + (s_lane & 31);
-  auto load_a = [&](int64_t step) {
+  // contiguous bytes of fp32; this thread stages row s_c of every sample (rows past C: row C - 1 again)
+  const int s_mb = tid >> 6, s_lane = tid & 63;
+  const int s_c = min(32 * s_mb + (s_lane & 31), a.C - 1);
+  const float* pa = a.dY + b0 * a.C * 16;                                  // uniform; + sample * C * 16
+  const uint32_t off_a = static_cast<uint32_t>(s_c * 16 + 8 * (s_lane >> 5));
+  const int64_t stride_a = static_cast<int64_t>(a.C) * 16;
+  // B operand: z[j] = hidden[b][h][8 hf + j] * x0[b][f][8 hf + j] of this lane's column; columns that do
+  // not exist read (h, f) = (0, 0), the bias column reads ones twice with stride 0
+  const float* hp0 = kbias ? kWgOnes + 8 * hf : a.hidden + b0 * a.hidden_stride + (kvalid ? h : 0) * 16 + 8 * hf;
+  const float* xp0 = kbias ? kWgOnes + 8 * hf : a.x0 + (b0 * a.F + (kvalid ? f : 0)) * 16 + 8 * hf;
+  const uint32_t hs = kbias ? 0u : static_cast<uint32_t>(a.hidden_stride), xs = kbias ? 0u : static_cast<uint32_t>(a.F * 16);
+  // Global loads run kWgDepth samples ahead of their use, in a ring of register slots (compile-time slot
+  // numbers: the loop is unrolled by the ring size).  Measured with tools/microbench_cin_wgrad (H = 64
+  // layer, kernel + slab reduce): depth 1 168 us, depth 2 174, depth 4 209, depth 6 198 (one wave per
+  // SIMD) — more loads in flight only lengthen the TA queue.  Counters at depth 1 (rocprofv3 --pmc, three
+  // workgroups per CU): MFMA busy 45 %, TA busy 57 %, LDS array 23 %, VALU issue 39 %, waves parked in
+  // s_waitcnt / s_barrier 50 % of their cycles, no LDS bank conflicts: no unit is saturated, the step
+  // (LDS reads -> convert + LDS write -> split the B product -> 12 MFMAs -> barrier) is a dependent chain
+  // and two or three waves per SIMD do not cover it.  What would: a 64-column tile per wave (24 MFMAs per
+  // barrier and per A fragment read) — not done.
+  float4 rf0[kWgDepth], rf1[kWgDepth], hb0[kWgDepth], hb1[kWgDepth], xb0[kWgDepth], xb1[kWgDepth];
+  auto load_a = [&](int s, auto slot_tag) {     // s: sample of the slice, clamped by the caller
+    constexpr int SL = decltype(slot_tag)::value;
+    const float* p = pa + s * stride_a + off_a;
+    rf0[SL] = ld4g(p);
+    rf1[SL] = ld4g(p + 4);
+  };
+  auto load_b = [&](int s, auto slot_tag) {
+    constexpr int SL = decltype(slot_tag)::value;
+    const float* hp = hp0 + static_cast<uint64_t>(s) * hs;
+    const float* xp = xp0 + static_cast<uint64_t>(s) * xs;
+    hb0[SL] = ld4g(hp); hb1[SL] = ld4g(hp + 4); xb0[SL] = ld4g(xp); xb1[SL] = ld4g(xp + 4);
+  };
+  auto split8 = [](const float4& v0, const float4& v1, bf16x8& hi, bf16x8& lo) {
+    const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
-    for (int u = 0; u < kWgStep; ++u) {
-      const int64_t bb = b0 + step * kWgStep + u;
-      rf[u][0] = rf[u][1] = float4{0.f, 0.f, 0.f, 0.f};
-      if (s_c < a.C && bb < b1) {
-        const float* p = a.dY + (bb * a.C + s_c) * 16 + 8 * (s_lane >> 5);
-        rf[u][0] = ld4(p);
-        rf[u][1] = ld4(p + 4);
-      }
+    for (int j = 0; j < 8; ++j) {
+      hi[j] = static_cast<__bf16>(v[j]);
+      if (SPLIT) lo[j] = static_cast<__bf16>(v[j] - static_cast<float>(hi[j]));
     }
   };
-  auto store_a = [&](int buf) {
-    if (s_mb < a.MB) {
-      unsigned char* base = wbuf + buf * 2 * SLAB;
-#pragma unroll
-      for (int u = 0; u < kWgStep; ++u) {
-        const float v[8] = {rf[u][0].x, rf[u][0].y, rf[u][0].z, rf[u][0].w, rf[u][1].x, rf[u][1].y, rf[u][1].z, rf[u][1].w};
-        bf16x8 h, l;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          h[j] = static_cast<__bf16>(v[j]);
-          if (SPLIT) l[j] = static_cast<__bf16>(v[j] - static_cast<float>(h[j]));
-        }
-        reinterpret_cast<bf16x8*>(base)[(u * 4 + s_mb) * 64 + s_lane] = h;
-        if (SPLIT) reinterpret_cast<bf16x8*>(base + SLAB)[(u * 4 + s_mb) * 64 + s_lane] = l;
-      }
-    }
+  auto store_a = [&](unsigned char* base, auto slot_tag) {
+    constexpr int SL = decltype(slot_tag)::value;
+    bf16x8 hi, lo;
+    split8(rf0[SL], rf1[SL], hi, lo);
+    reinterpret_cast<bf16x8*>(base)[s_mb * 64 + s_lane] = hi;
+    if (SPLIT) reinterpret_cast<bf16x8*>(base + SLAB)[s_mb * 64 + s_lane] = lo;
   };
-  float4 hb[kWgStep][2] = {}, xb[kWgStep][2] = {};
-  auto load_b = [&](int64_t step) {
-#pragma unroll
-    for (int u = 0; u < kWgStep; ++u) {
-      const int64_t bb = b0 + step * kWgStep + u;
-      hb[u][0] = hb[u][1] = xb[u][0] = xb[u][1] = float4{0.f, 0.f, 0.f, 0.f};
-      if (kvalid && bb < b1) {
-        const float* hp = a.hidden + bb * a.hidden_stride + h * 16 + 8 * hf;
-        const float* xp = a.x0 + (bb * a.F + f) * 16 + 8 * hf;
-        hb[u][0] = ld4(hp); hb[u][1] = ld4(hp + 4); xb[u][0] = ld4(xp); xb[u][1] = ld4(xp + 4);
-      } else if (kbias && bb < b1) {
-        hb[u][0] = hb[u][1] = xb[u][0] = xb[u][1] = float4{1.f, 1.f, 1.f, 1.f};
-      }
-    }
-  };
-  if (nsteps > 0) {
-    load_a(0);
-    store_a(0);
-    load_b(0);
-    if (nsteps > 1) load_a(1);
-  }
-  __syncthreads();
-  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): see cin_dgrad_mfma
-  auto steps = [&](auto full_tag) {
+#ifdef DFM_CIN_STAMPS
+  unsigned long long st_a = 0, st_b = 0, st_m = 0, st_bar = 0;
+  const unsigned long long st_begin = wall_clock64();
+#define WG_STAMP(var) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = wall_clock64(); var += t_ - st_t; st_t = t_; }
+#else
+#define WG_STAMP(var)
+#endif
+  // step s: slot s % kWgDepth holds B(s) and, from here on, A(s + kWgDepth) / B(s + kWgDepth);
+  // slot (s + 1) % kWgDepth holds A(s + 1), which moves to the other LDS buffer now
+  auto step = [&](int s, auto unroll_tag, auto full_tag) {
     constexpr bool FULL = decltype(full_tag)::value;
-    for (int64_t step = 0; step < nsteps; ++step) {
-      const int cur = static_cast<int>(step & 1);
-      const unsigned char* base = wbuf + cur * 2 * SLAB;
-      bf16x8 ah[kWgStep][4], al[kWgStep][4];
-      if constexpr (FULL) {
+    constexpr int U = decltype(unroll_tag)::value;        // position in the unrolled loop body
+    constexpr int SL = U % kWgDepth, SN = (U + 1) % kWgDepth;
+    const std::integral_constant<int, SL> slot_tag{};
+    unsigned char* cur = wbuf + (U & 1) * 2 * SLAB;
+    unsigned char* nxt = wbuf + ((U & 1) ^ 1) * 2 * SLAB;
+#ifdef DFM_CIN_STAMPS
+    unsigned long long st_t = wall_clock64();
+#endif
+    bf16x8 ah[4];
+    if constexpr (FULL) {
 #pragma unroll
-        for (int u = 0; u < kWgStep; ++u) {
-#pragma unroll
-          for (int mb = 0; mb < 4; ++mb) {
-            ah[u][mb] = reinterpret_cast<const bf16x8*>(base)[(u * 4 + mb) * 64 + lane];
-            if (SPLIT) al[u][mb] = reinterpret_cast<const bf16x8*>(base + SLAB)[(u * 4 + mb) * 64 + lane];
-          }
-        }
-      }
-      if (step + 1 < nsteps) store_a(cur ^ 1);
-      if (step + 2 < nsteps) load_a(step + 2);
-      // B operands of this step from the registers loaded one step ago
-      bf16x8 bh[kWgStep], bl[kWgStep];
-#pragma unroll
-      for (int u = 0; u < kWgStep; ++u) {
-        const float z[8] = {hb[u][0].x * xb[u][0].x, hb[u][0].y * xb[u][0].y, hb[u][0].z * xb[u][0].z,
-                            hb[u][0].w * xb[u][0].w, hb[u][1].x * xb[u][1].x, hb[u][1].y * xb[u][1].y,
-                            hb[u][1].z * xb[u][1].z, hb[u][1].w * xb[u][1].w};
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          bh[u][j] = static_cast<__bf16>(z[j]);
-          if (SPLIT) bl[u][j] = static_cast<__bf16>(z[j] - static_cast<float>(bh[u][j]));
-        }
-      }
-      if (step + 1 < nsteps) load_b(step + 1);
-#pragma unroll
-      for (int u = 0; u < kWgStep; ++u) {
-        if constexpr (FULL) {
-#pragma unroll
-          for (int mb = 0; mb < 4; ++mb)
-            acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[u][mb], bh[u], acc[mb], 0, 0, 0);
-          if (SPLIT) {
-#pragma unroll
-            for (int mb = 0; mb < 4; ++mb)
-              acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[u][mb], bl[u], acc[mb], 0, 0, 0);
-#pragma unroll
-            for (int mb = 0; mb < 4; ++mb)
-              acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[u][mb], bh[u], acc[mb], 0, 0, 0);
-          }
-        } else {
-#pragma unroll
-          for (int mb = 0; mb < 4; ++mb) {
-            if (mb < a.MB) {
-              const bf16x8 a_h = reinterpret_cast<const bf16x8*>(base)[(u * 4 + mb) * 64 + lane];
-              acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, bh[u], acc[mb], 0, 0, 0);
-              if (SPLIT) {
-                const bf16x8 a_l = reinterpret_cast<const bf16x8*>(base + SLAB)[(u * 4 + mb) * 64 + lane];
-                acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, bl[u], acc[mb], 0, 0, 0);
-                acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_l, bh[u], acc[mb], 0, 0, 0);
-              }
-            }
-          }
-        }
-      }
-      __syncthreads();
+      for (int mb = 0; mb < 4; ++mb) ah[mb] = reinterpret_cast<const bf16x8*>(cur)[mb * 64 + lane];
     }
+    store_a(nxt, std::integral_constant<int, SN>{});     // sample s + 1 (the last step stores a copy nobody reads)
+    load_a(min(s + 1 + kWgDepth, n - 1), std::integral_constant<int, SN>{});
+#ifdef DFM_CIN_STAMPS
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+    WG_STAMP(st_a)
+    bf16x8 bh, bl;
+    {
+      const float4 z0 = {hb0[SL].x * xb0[SL].x, hb0[SL].y * xb0[SL].y, hb0[SL].z * xb0[SL].z, hb0[SL].w * xb0[SL].w};
+      const float4 z1 = {hb1[SL].x * xb1[SL].x, hb1[SL].y * xb1[SL].y, hb1[SL].z * xb1[SL].z, hb1[SL].w * xb1[SL].w};
+      split8(z0, z1, bh, bl);
+    }
+    load_b(min(s + kWgDepth, n - 1), slot_tag);
+    WG_STAMP(st_b)
+    if constexpr (FULL) {
+      // hi fragments first, the lo fragments only once the hi ones are dead (16 live registers of A)
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mb], bh, acc[mb], 0, 0, 0);
+      if (SPLIT) {
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mb], bl, acc[mb], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) ah[mb] = reinterpret_cast<const bf16x8*>(cur + SLAB)[mb * 64 + lane];
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mb], bh, acc[mb], 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb) {
+        if (mb < a.MB) {
+          const bf16x8 a_h = reinterpret_cast<const bf16x8*>(cur)[mb * 64 + lane];
+          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, bh, acc[mb], 0, 0, 0);
+          if (SPLIT) {
+            const bf16x8 a_l = reinterpret_cast<const bf16x8*>(cur + SLAB)[mb * 64 + lane];
+            acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, bl, acc[mb], 0, 0, 0);
+            acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_l, bh, acc[mb], 0, 0, 0);
+          }
+        }
+      }
+    }
+    WG_STAMP(st_m)
+    __syncthreads();
+    WG_STAMP(st_bar)
   };
-  if (a.MB == 4) steps(std::true_type{});
-  else steps(std::false_type{});
+  if (n > 0) {
+    constexpr int kUnroll = kWgDepth % 2 ? 2 * kWgDepth : kWgDepth;   // slots and the two LDS buffers both cycle
+    using S0 = std::integral_constant<int, 0>;
+    load_a(0, S0{});
+    static_for<0, kWgDepth>([&](auto i) { load_b(min(static_cast<int>(i), n - 1), i); });
+    store_a(wbuf, S0{});
+    static_for<1, kWgDepth>([&](auto i) { load_a(min(static_cast<int>(i), n - 1), i); });
+    load_a(min(kWgDepth, n - 1), S0{});
+    __syncthreads();
+    auto run = [&](auto full_tag) {
+      int s = 0;
+      for (; s + kUnroll - 1 < n; s += kUnroll) static_for<0, kUnroll>([&](auto i) { step(s + i, i, full_tag); });
+      static_for<0, kUnroll - 1>([&](auto i) { if (s + i < n) step(s + i, i, full_tag); });
+    };
+    if (a.MB == 4) run(std::true_type{});
+    else run(std::false_type{});
+  }
+#ifdef DFM_CIN_STAMPS
+  if (a.stamps && lane == 0) {
+    unsigned long long* o = a.stamps + ((static_cast<int64_t>(blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wave) * 8;
+    o[0] = st_begin; o[1] = wall_clock64(); o[2] = st_a; o[3] = st_b; o[4] = st_m; o[5] = st_bar; o[6] = n;
+  }
+#endif
   if (kt < a.KT) {
     // accumulator: col = k' column (lane&31), row = c = mb*32 + (r&3) + 8*(r>>2) + 4*hf
     float* out = a.slabs + (static_cast<int64_t>(blockIdx.y) * a.MB * 32 + 4 * hf) * (a.KT * 32) + kt * 32 + (lane & 31);
@@ -504,11 +557,11 @@ int cin_mfma_dgrad(const CinBwdArgs& args, int D, bool split, hipStream_t st) {
 }
 
 // Batch slices of the weight-gradient GEMM: the grid is (column groups) x (slices) workgroups of
-// equal work, two resident per CU, so the slice count is chosen to fill ONE round of 2 x 256
+// equal work, kWgOcc resident per CU, so the slice count is chosen to fill ONE round of kWgOcc x 256
 // workgroup slots (20 column groups x 32 slices = 640 workgroups ran a second round at 25 %
 // occupancy: 184 us where 118 us of work was needed).
 constexpr int kWgradMaxSlices = 64;
-constexpr int kWgSlots = 2 * 256;
+constexpr int kWgSlots = kWgOcc * 256;
 static int wgrad_slices(int64_t B, int KT) {
   const int cols = (KT + 3) / 4;
   int slices = kWgSlots / cols;
@@ -521,6 +574,8 @@ size_t cin_mfma_wgrad_workspace_bytes(int64_t B, int C, int H, int F) {
   const int KT = (H * FP + 31) / 32;
   return sizeof(float) * static_cast<size_t>(wgrad_slices(B, KT)) * MB * 32 * KT * 32 + 512;
 }
+
+unsigned long long* g_wgrad_stamps = nullptr;     // set by tools/microbench_cin_wgrad (stamped build) only
 
 // true: cin_mfma_wgrad also produces the bias gradient (a free padding column exists)
 bool cin_mfma_wgrad_has_bias(int F) { return F % 8 != 0; }
@@ -537,6 +592,7 @@ int cin_mfma_wgrad(const float* dY, const float* x0, const float* hidden, int64_
   a.dY = dY; a.C = C; a.x0 = x0; a.hidden = hidden; a.hidden_stride = hidden_stride; a.slabs = slabs;
   a.B = B; a.F = F; a.H = H; a.MB = MB; a.KT = KT; a.slices = slices; a.FP = FP;
   a.bias_col = db ? 1 : 0;
+  a.stamps = g_wgrad_stamps;
   const dim3 grid((KT + 3) / 4, slices);
   if (split) hipLaunchKernelGGL(cin_wgrad_mfma<true>, grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL(cin_wgrad_mfma<false>, grid, dim3(256), 0, st, a);
