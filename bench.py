@@ -246,7 +246,7 @@ def extra_config(name, args, dev, lib):
     else:
         io_bytes = 2.0 * 39 * D * 4 * B           # x in + out per sample
         out["roofline"] = {
-            "kernel": "field self-attention block (QKV GEMM, attn_core_fwd, out GEMM, LayerNorm; + backward)",
+            "kernel": "field self-attention block (attn_qkv_mfma_fwd: Q|K|V projection + softmax(QK^T)V on the fp32 matrix cores, out GEMM, LayerNorm; + backward)",
             "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
             "algorithmic_bytes_fwd": io_bytes, "fwd_ms": f_ms, "fwd_ms_min": f_min, "fwd_bwd_ms": t_ms,
             "fwd_bwd_ms_min": t_min, "achieved": io_bytes / (f_ms * 1e-3) / 1e9,
