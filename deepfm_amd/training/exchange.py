@@ -75,9 +75,12 @@ def allgather_step(local: Sequence[torch.Tensor], out: Sequence[torch.Tensor],
             dist.all_gather_into_tensor(dst, src, group=group)
 
 
+_LOGGED: set = set()
+
+
 def _log_once(key, message: str, *args) -> None:
-    if key not in _GROUPED:
-        _GROUPED[key] = True
+    if key not in _LOGGED:
+        _LOGGED.add(key)
         import logging
         logging.getLogger("deepfm_amd.exchange").info(message, *args)
 

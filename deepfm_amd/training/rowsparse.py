@@ -227,16 +227,21 @@ class RowSparseAdam:
         self.apply()
 
     # ------------------------------------------------------------------ checkpointing
+    def _table_state(self):
+        """[(table parameter, exp_avg, exp_avg_sq)] of every table a checkpoint covers."""
+        return list(zip(self._tables, self.exp_avg, self.exp_avg_sq))
+
     def _named(self):
         names = {id(p): n for n, p in self.model.named_parameters()}
-        return [(names[id(p)], p) for p in self._tables], [(names[id(p)], p) for p in self.dense_params]
+        return ([(names[id(p)], m, v) for p, m, v in self._table_state()],
+                [(names[id(p)], p) for p in self.dense_params])
 
     def state_dict(self) -> dict:
         """Adam state keyed by parameter NAME (``exp_avg`` / ``exp_avg_sq`` with the parameter's
         shape, like ``torch.optim.Adam``'s per-parameter state) plus the shared step count."""
         tables, dense = self._named()
         state = {}
-        for (name, _), m, v in zip(tables, self.exp_avg, self.exp_avg_sq):
+        for name, m, v in tables:
             state[name] = {"exp_avg": m.detach().clone().contiguous(), "exp_avg_sq": v.detach().clone().contiguous()}
         off = 0
         for name, p in dense:
@@ -270,11 +275,11 @@ class RowSparseAdam:
                     step = max(step, int(st["step"]))
             sd = {"step": step, "state": state}
         tables, dense = self._named()
-        want = {n for n, _ in tables} | {n for n, _ in dense}
+        want = {n for n, _, _ in tables} | {n for n, _ in dense}
         if set(sd["state"]) != want:
             raise KeyError(f"optimizer state keys differ: {sorted(set(sd['state']) ^ want)[:5]} ...")
         with torch.no_grad():
-            for (name, _), m, v in zip(tables, self.exp_avg, self.exp_avg_sq):
+            for name, m, v in tables:
                 m.copy_(sd["state"][name]["exp_avg"])
                 v.copy_(sd["state"][name]["exp_avg_sq"])
             off = 0

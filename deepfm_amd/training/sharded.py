@@ -149,6 +149,19 @@ class ShardedRowAdam(RowSparseAdam):
         self.split = True                     # d-weight slabs must be in the flat gradient before it travels
         self.dense_source: Optional[Tuple[torch.Tensor, int]] = None
 
+    def _table_state(self):
+        """Checkpoints cover EVERY table: the moments live in the packed row records, which
+        ``TableShard.restore_tables()`` (collective) brings back to every rank first."""
+        if self.shard.released:
+            raise RuntimeError("ShardedRowAdam.state_dict / load_state_dict: call shard.restore_tables() first "
+                               "(collective), and shard.release_foreign() afterwards to continue training")
+        emb, out = self.model.embedding, []
+        for name in self.shard.sparse_names:
+            rec = emb.packed[name]
+            out.append((emb.second_order_embeddings[name].weight, rec["m2"], rec["v2"]))
+            out.append((emb.first_order_embeddings[name].weight, rec["m1"], rec["v1"]))
+        return out
+
     @torch.no_grad()
     def exchange(self) -> None:
         rs = self.row_emb.rowsparse

@@ -84,8 +84,11 @@ def main():
     dump = os.environ.get("DFM_REHEARSAL_DUMP")
     if dump:                            # tensors for tolerance comparisons between the DP layouts
         import numpy as np
+        sd = opt.state_dict()                      # sharded: every table's moments (after restore_tables)
+        moments = torch.cat([sd["state"][n][k].reshape(-1) for n in sorted(sd["state"]) for k in ("exp_avg", "exp_avg_sq")])
         np.savez(f"{dump}.rank{rank}.npz", flat=opt.flat_param.detach().cpu().numpy(),
-                 tables=tables.detach().cpu().numpy(), loss=float(step.loss))
+                 tables=tables.detach().cpu().numpy(), moments=moments.cpu().numpy(), step=sd["step"],
+                 loss=float(step.loss))
     out = [None] * world
     dist.all_gather_object(out, mine)
     if rank == 0:

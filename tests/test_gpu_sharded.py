@@ -153,7 +153,8 @@ def test_two_ranks_sharded_vs_replicated(tmp_path):
     for r in range(2):
         a, b = np.load(f"{tmp_path}/sh.rank{r}.npz"), np.load(f"{tmp_path}/rep.rank{r}.npz")
         assert abs(float(a["loss"]) - float(b["loss"])) < 1e-5
-        for k in ("flat", "tables"):
+        assert int(a["step"]) == int(b["step"]) == 4
+        for k in ("flat", "tables", "moments"):             # moments: optimizer.state_dict() of either layout
             _close(torch.from_numpy(a[k]), torch.from_numpy(b[k]), f"rank {r} {k}")
 
 
