@@ -128,8 +128,8 @@ SIGNATURES = {
     "dfm_attention_qkv_core_forward": (_I, [_P, _P, _P, _L, _I, _I, _I, _I, _P, _P]),
     "dfm_attention_qkv_core_backward": (_I, [_P, _P, _P, _P, _L, _I, _I, _I, _I, _P, _P]),
     "dfm_layernorm_workspace_bytes": (_SZ, [_L, _I]),
-    "dfm_layernorm_forward": (_I, [_P, _P, _L, _I, _P, _P, _F, _P, _P, _P]),
-    "dfm_layernorm_backward": (_I, [_P, _P, _P, _P, _L, _I, _P, _P, _P, _P, _P, _P]),
+    "dfm_layernorm_forward": (_I, [_P, _P, _L, _I, _P, _P, _F, _P, _P, _L, _L, _P]),
+    "dfm_layernorm_backward": (_I, [_P, _P, _P, _P, _L, _I, _P, _P, _P, _P, _P, _L, _L, _P]),
     "dfm_linear_bn_workspace_bytes": (_SZ, [_L, _I]),
     "dfm_linear_bn_forward": (_I, [_P, _L, _P, _P, _L, _I, _I, _P, _P, _P]),
     "dfm_bn_relu_dropout_apply": (_I, [_P, _L, _I, _P, _P, _P, _P, _P, _P, _P, _F, _F, _F, _P, _I, _P, _P]),

@@ -344,7 +344,8 @@ __device__ __forceinline__ float sum4(const float4& v) { return (v.x + v.y) + (v
 __global__ __launch_bounds__(256) void layernorm_fwd4(const float* __restrict__ y, const float* __restrict__ res,
                                                       int64_t rows, int D, int l4, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, float eps,
-                                                      float* __restrict__ out, float* __restrict__ stats) {
+                                                      float* __restrict__ out, float* __restrict__ stats,
+                                                      int64_t group_rows, int64_t group_stride) {
   const int64_t t = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
   const int64_t r = t / l4;
   const int d = static_cast<int>(t % l4) * 4;
@@ -363,8 +364,11 @@ __global__ __launch_bounds__(256) void layernorm_fwd4(const float* __restrict__ 
   const float rstd = rsqrtf(var / D + eps);
   if (live) {
     const float4 ga = ld4(gamma + d), be = ld4(beta + d);
-    st4(out + r * D + d, make_float4(c.x * rstd * ga.x + be.x, c.y * rstd * ga.y + be.y, c.z * rstd * ga.z + be.z,
-                                     c.w * rstd * ga.w + be.w));
+    // group_rows > 0: row r = (sample r / group_rows, field r % group_rows) lands in a buffer whose samples
+    // are group_stride floats apart (the attention half of the tower's concatenated input)
+    const int64_t o = group_rows > 0 ? (r / group_rows) * group_stride + (r % group_rows) * D : r * D;
+    st4(out + o + d, make_float4(c.x * rstd * ga.x + be.x, c.y * rstd * ga.y + be.y, c.z * rstd * ga.z + be.z,
+                                 c.w * rstd * ga.w + be.w));
     if (d == 0) { stats[2 * r] = mu; stats[2 * r + 1] = rstd; }
   }
 }
@@ -373,7 +377,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd4(const float* __restrict__ 
                                                       const float* __restrict__ res,
                                                       const float* __restrict__ stats, int64_t rows, int D, int l4,
                                                       const float* __restrict__ gamma, float* __restrict__ g_s,
-                                                      float* __restrict__ partial) {
+                                                      float* __restrict__ partial, int64_t group_rows,
+                                                      int64_t group_stride) {
   __shared__ float4 red[2][256];
   const int rpp = 256 / l4;                        // rows per pass
   const int sr = threadIdx.x / l4, q = threadIdx.x % l4, d = q * 4;
@@ -392,7 +397,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd4(const float* __restrict__ 
       const float4 a = ld4(y + r * D + d), b = ld4(res + r * D + d);
       xh = make_float4((a.x + b.x - mu) * rstd, (a.y + b.y - mu) * rstd, (a.z + b.z - mu) * rstd,
                        (a.w + b.w - mu) * rstd);
-      gv = ld4(g + r * D + d);
+      gv = ld4(g + (group_rows > 0 ? (r / group_rows) * group_stride + (r % group_rows) * D : r * D) + d);
     }
     const float4 gg = make_float4(gv.x * ga.x, gv.y * ga.y, gv.z * ga.z, gv.w * ga.w);
     float m1 = sum4(gg), m2 = sum4(make_float4(gg.x * xh.x, gg.y * xh.y, gg.z * xh.z, gg.w * xh.w));
@@ -571,15 +576,21 @@ extern "C" size_t dfm_layernorm_workspace_bytes(int64_t rows, int dim) {
 
 extern "C" int dfm_layernorm_forward(const float* d_y, const float* d_res, int64_t rows, int dim,
                                      const float* d_gamma, const float* d_beta, float eps, float* d_out,
-                                     float* d_stats, dfm_stream_t stream) {
+                                     float* d_stats, int64_t out_group_rows, int64_t out_group_stride,
+                                     dfm_stream_t stream) {
   DFM_REQUIRE(d_y && d_res && d_gamma && d_beta && d_out && d_stats, "null argument");
   DFM_REQUIRE(rows >= 0 && dim > 0 && dim <= 64, "LayerNorm kernel supports 1 <= dim <= 64");
+  DFM_REQUIRE(out_group_rows >= 0 && (out_group_rows == 0 || (out_group_stride >= out_group_rows * dim &&
+                                                              out_group_stride % 4 == 0)), "bad output grouping");
   if (rows == 0) return DFM_OK;
+  DFM_REQUIRE(out_group_rows == 0 || ln_vec4(dim, d_y, d_res, d_out, d_gamma, d_beta),
+              "a grouped output needs dim % 4 == 0 and 16-byte aligned buffers");
   if (ln_vec4(dim, d_y, d_res, d_out, d_gamma, d_beta)) {
     const int l4 = ln_lanes(dim / 4);
     const int64_t threads = rows * l4;
     hipLaunchKernelGGL(layernorm_fwd4, dim3(static_cast<unsigned>((threads + 255) / 256)), dim3(256), 0,
-                       as_stream(stream), d_y, d_res, rows, dim, l4, d_gamma, d_beta, eps, d_out, d_stats);
+                       as_stream(stream), d_y, d_res, rows, dim, l4, d_gamma, d_beta, eps, d_out, d_stats, out_group_rows,
+                       out_group_stride);
     DFM_LAUNCH_CHECK();
     return DFM_OK;
   }
@@ -594,17 +605,22 @@ extern "C" int dfm_layernorm_forward(const float* d_y, const float* d_res, int64
 extern "C" int dfm_layernorm_backward(const float* d_g_out, const float* d_y, const float* d_res,
                                       const float* d_stats, int64_t rows, int dim, const float* d_gamma,
                                       float* d_g_sum, float* d_g_gamma, float* d_g_beta, void* d_workspace,
-                                      dfm_stream_t stream) {
+                                      int64_t g_group_rows, int64_t g_group_stride, dfm_stream_t stream) {
   DFM_REQUIRE(d_g_out && d_y && d_res && d_stats && d_gamma && d_g_sum && d_g_gamma && d_g_beta && d_workspace,
               "null argument");
   DFM_REQUIRE(rows >= 0 && dim > 0 && dim <= 64, "LayerNorm kernel supports 1 <= dim <= 64");
+  DFM_REQUIRE(g_group_rows >= 0 && (g_group_rows == 0 || (g_group_stride >= g_group_rows * dim && g_group_stride % 4 == 0)),
+              "bad gradient grouping");
   if (rows == 0) return DFM_OK;
+  DFM_REQUIRE(g_group_rows == 0 || (ln_vec4(dim, d_y, d_res, d_g_out, d_gamma, d_g_sum) &&
+                                    (reinterpret_cast<uintptr_t>(d_workspace) & 15) == 0),
+              "a grouped gradient needs dim % 4 == 0 and 16-byte aligned buffers");
   hipStream_t st = as_stream(stream);
   const int blocks = static_cast<int>((rows + kLnRows - 1) / kLnRows);
   float* partial = static_cast<float*>(d_workspace);
   if (ln_vec4(dim, d_y, d_res, d_g_out, d_gamma, d_g_sum) && (reinterpret_cast<uintptr_t>(partial) & 15) == 0)
     hipLaunchKernelGGL(layernorm_bwd4, dim3(blocks), dim3(256), 0, st, d_g_out, d_y, d_res, d_stats, rows, dim,
-                       ln_lanes(dim / 4), d_gamma, d_g_sum, partial);
+                       ln_lanes(dim / 4), d_gamma, d_g_sum, partial, g_group_rows, g_group_stride);
   else
     hipLaunchKernelGGL(layernorm_bwd, dim3(blocks), dim3(256), 0, st, d_g_out, d_y, d_res, d_stats, rows, dim,
                        ln_lanes(dim), d_gamma, d_g_sum, partial);

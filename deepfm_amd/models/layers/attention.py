@@ -38,6 +38,12 @@ class _AttentionBlock(nn.Module):
         # False (or an unsupported shape) selects the single fused LDS kernel of csrc/attention.hip
         self.gemm_path = True
 
+    def adjacent_parameters(self):
+        """Parameters an optimizer with ONE flat buffer should lay out back to back, in this order: the
+        kernels take W_q | W_k | W_v as one stacked (3A, D) weight, and with this layout the stack is a
+        view of the parameters (and of their gradients) instead of a torch.cat per step."""
+        return [[self.W_q.weight, self.W_k.weight, self.W_v.weight], [self.W_q.bias, self.W_k.bias, self.W_v.bias]]
+
     def _param_list(self):
         ps = [self.W_q.weight, self.W_q.bias, self.W_k.weight, self.W_k.bias, self.W_v.weight,
               self.W_v.bias, self.W_out.weight, self.W_out.bias]
@@ -75,6 +81,22 @@ class MultiHeadSelfAttention(nn.Module):
         return x
 
 
+def stacked_view(ts) -> "torch.Tensor | None":
+    """(sum of rows, cols) view over tensors that lie back to back in one storage (RowSparseAdam lays
+    W_q | W_k | W_v out that way, see ``_AttentionBlock.adjacent_parameters``), else None."""
+    t0 = ts[0]
+    cols = t0.shape[1] if t0.dim() == 2 else 1
+    nxt, store = t0.data_ptr(), t0.untyped_storage().data_ptr()
+    for t in ts:
+        # same storage, not merely neighbouring allocations: the view must stay inside one storage
+        if not t.is_contiguous() or t.data_ptr() != nxt or t.untyped_storage().data_ptr() != store \
+                or t.dtype != t0.dtype or (t.shape[1] if t.dim() == 2 else 1) != cols:
+            return None
+        nxt += t.numel() * t.element_size()
+    rows = sum(t.shape[0] for t in ts)
+    return torch.as_strided(t0, (rows, cols) if t0.dim() == 2 else (rows,), (cols, 1) if t0.dim() == 2 else (1,))
+
+
 def _ptrs(tensors):
     arr = (C.c_void_p * len(tensors))()
     for i, t in enumerate(tensors):
@@ -108,8 +130,10 @@ class _AttnGemmFn(torch.autograd.Function):
         A, H = block.attention_dim, block.num_heads
         M = B * F
         wq, bq, wk, bk, wv, bv, wo, bo = (p.contiguous() for p in params[:8])
-        w_qkv = torch.cat([wq, wk, wv], dim=0)                      # (3A, D)
-        b_qkv = torch.cat([bq, bk, bv], dim=0)
+        w_qkv = stacked_view([wq, wk, wv])                          # (3A, D): a view when the optimizer laid them out so
+        b_qkv = stacked_view([bq, bk, bv])
+        if w_qkv is None or b_qkv is None:
+            w_qkv, b_qkv = torch.cat([wq, wk, wv], dim=0), torch.cat([bq, bk, bv], dim=0)
         X = x.view(M, D)
         o = torch.empty(M, A, dtype=torch.float32, device=x.device)
         # projection inside the core kernel where its shape allows: the (M, 3A) Q|K|V is never materialised
@@ -128,11 +152,19 @@ class _AttnGemmFn(torch.autograd.Function):
         stats = None
         if block.use_residual:
             gamma, beta = params[8].contiguous(), params[9].contiguous()
-            out = torch.empty(M, D, dtype=torch.float32, device=x.device)
+            # out_into (fused training step, on its ctx stand-in): (buffer, floats between samples) — the block's
+            # output goes straight into a wider per-sample layout (the DNN's concatenated input)
+            into = getattr(ctx, "out_into", None)
+            out = into[0] if into is not None else torch.empty(M, D, dtype=torch.float32, device=x.device)
             stats = torch.empty(M, 2, dtype=torch.float32, device=x.device)
             _lib.check(lib.dfm_layernorm_forward(y.data_ptr(), X.data_ptr(), M, D, gamma.data_ptr(), beta.data_ptr(),
                                                  float(block.layer_norm.eps), out.data_ptr(), stats.data_ptr(),
+                                                 F if into is not None else 0, into[1] if into is not None else 0,
                                                  _lib.stream_handle()))
+            if into is not None:
+                ctx.block, ctx.dims = block, (B, F, D, A, H)
+                ctx.save_for_backward(X, qkv, o, y, stats, w_qkv, wo, gamma, b_qkv)
+                return out
         else:
             gamma = beta = None
             out = y
@@ -149,21 +181,36 @@ class _AttnGemmFn(torch.autograd.Function):
         M = B * F
         X, qkv, o, y, stats, w_qkv, wo, gamma, b_qkv = ctx.saved_tensors
         dev = X.device
-        g = g_out.contiguous().view(M, D)
+        # direct (set by the fused training step on its ctx stand-in): parameter gradients are written
+        # straight into the (zeroed) .grad views of the optimizer's flat buffer — no temporaries, no adds
+        direct = getattr(ctx, "direct", False)
+        gq = gb = None
+        if direct:
+            gq = stacked_view([block.W_q.weight.grad, block.W_k.weight.grad, block.W_v.weight.grad])
+            gb = stacked_view([block.W_q.bias.grad, block.W_k.bias.grad, block.W_v.bias.grad])
+            direct = gq is not None and gb is not None and block.W_out.weight.grad.is_contiguous()
+        # g_from (fused training step): the incoming gradient lives in a wider per-sample layout
+        # (floats between samples); only the residual LayerNorm's backward can read it that way
+        g_stride = getattr(ctx, "g_from", 0) if block.use_residual else 0
+        g = g_out if g_stride else g_out.contiguous().view(M, D)
         from deepfm_amd.models.layers.linear import ones_column
         grads = []
         if block.use_residual:
             g_y = torch.empty(M, D, dtype=torch.float32, device=dev)
-            d_gamma = torch.zeros(D, dtype=torch.float32, device=dev)
-            d_beta = torch.zeros(D, dtype=torch.float32, device=dev)
+            if direct:                           # accumulated into: zero at this point of the step
+                d_gamma, d_beta = block.layer_norm.weight.grad, block.layer_norm.bias.grad
+            else:
+                d_gamma = torch.zeros(D, dtype=torch.float32, device=dev)
+                d_beta = torch.zeros(D, dtype=torch.float32, device=dev)
             ws = torch.empty(max(lib.dfm_layernorm_workspace_bytes(M, D) // 4, 1), dtype=torch.float32, device=dev)
             _lib.check(lib.dfm_layernorm_backward(g.data_ptr(), y.data_ptr(), X.data_ptr(), stats.data_ptr(), M, D,
                                                   gamma.data_ptr(), g_y.data_ptr(), d_gamma.data_ptr(),
-                                                  d_beta.data_ptr(), ws.data_ptr(), _lib.stream_handle()))
+                                                  d_beta.data_ptr(), ws.data_ptr(), F if g_stride else 0, g_stride,
+                                                  _lib.stream_handle()))
         else:
             g_y = g
-        d_wo = torch.empty(D, A, dtype=torch.float32, device=dev)
-        d_bo = torch.empty(D, 1, dtype=torch.float32, device=dev)
+        d_wo = block.W_out.weight.grad if direct else torch.empty(D, A, dtype=torch.float32, device=dev)
+        d_bo = block.W_out.bias.grad.view(D, 1) if direct else torch.empty(D, 1, dtype=torch.float32, device=dev)
         if not _weight_grad(g_y, o, M, D, A, d_wo, d_bo):
             _gemm(g_y, D, False, o, A, False, d_wo, D, A, M)                     # dWo = g_y^T O
             _gemm(g_y, D, False, ones_column(M, dev), 1, False, d_bo, D, 1, M)
@@ -177,8 +224,8 @@ class _AttnGemmFn(torch.autograd.Function):
         else:
             _lib.check(lib.dfm_attention_core_backward(qkv.data_ptr(), d_o.data_ptr(), B, F, A, H, d_qkv.data_ptr(),
                                                        _lib.stream_handle()))
-        d_wqkv = torch.empty(3 * A, D, dtype=torch.float32, device=dev)
-        d_bqkv = torch.empty(3 * A, 1, dtype=torch.float32, device=dev)
+        d_wqkv = gq if direct else torch.empty(3 * A, D, dtype=torch.float32, device=dev)
+        d_bqkv = gb.view(3 * A, 1) if direct else torch.empty(3 * A, 1, dtype=torch.float32, device=dev)
         if not _weight_grad(d_qkv, X, M, 3 * A, D, d_wqkv, d_bqkv):
             _gemm(d_qkv, 3 * A, False, X, D, False, d_wqkv, 3 * A, D, M)         # dWqkv = dQKV^T X
             _gemm(d_qkv, 3 * A, False, ones_column(M, dev), 1, False, d_bqkv, 3 * A, 1, M)
@@ -188,6 +235,8 @@ class _AttnGemmFn(torch.autograd.Function):
         else:
             d_x = torch.empty(M, D, dtype=torch.float32, device=dev)
             _gemm(d_qkv, 3 * A, True, w_qkv, D, False, d_x, M, D, 3 * A)
+        if direct:
+            return (None, d_x.view(B, F, D))
         d_bqkv = d_bqkv.view(-1)
         grads = [d_wqkv[:A], d_bqkv[:A], d_wqkv[A:2 * A], d_bqkv[A:2 * A], d_wqkv[2 * A:], d_bqkv[2 * A:],
                  d_wo, d_bo.view(-1)]

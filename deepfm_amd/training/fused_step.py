@@ -377,14 +377,20 @@ class FusedAttentionDeepFMStep(_FusedTowerStep):
         from deepfm_amd.models.layers.attention import _AttnGemmFn
         x = self.fe
         self._ctxs = []
-        for block in self.blocks:
-            ctx = _Ctx()
-            x = _AttnGemmFn.forward(ctx, block, x, *block._param_list())
-            self._ctxs.append(ctx)
         FD = self.fe.shape[1] * self.fe.shape[2]
         lib, st = _lib.load(), _lib.stream_handle()
-        # dnn_in = cat([attention(fe).flatten(1), flat], dim=1)   (attention_deepfm.py:57-61)
-        _lib.check(lib.dfm_copy_2d(x.data_ptr(), FD, self.xcat.data_ptr(), 2 * FD, self.B, FD, st))
+        # dnn_in = cat([attention(fe).flatten(1), flat], dim=1)   (attention_deepfm.py:57-61): the last
+        # block's residual LayerNorm writes its rows straight into the first half of xcat
+        last = self.blocks[-1]
+        for block in self.blocks:
+            ctx = _Ctx()
+            ctx.direct = True          # parameter gradients straight into the flat buffer's .grad views
+            if block is last and block.use_residual:
+                ctx.out_into = (self.xcat, 2 * FD)
+            x = _AttnGemmFn.forward(ctx, block, x, *block._param_list())
+            self._ctxs.append(ctx)
+        if not last.use_residual:
+            _lib.check(lib.dfm_copy_2d(x.data_ptr(), FD, self.xcat.data_ptr(), 2 * FD, self.B, FD, st))
         _lib.check(lib.dfm_copy_2d(self.fe.data_ptr(), FD, self.xcat.data_ptr() + FD * 4, 2 * FD, self.B, FD, st))
         return self.fm
 
@@ -395,14 +401,19 @@ class FusedAttentionDeepFMStep(_FusedTowerStep):
         from deepfm_amd.models.layers.attention import _AttnGemmFn
         B, F, D = self.fe.shape
         FD = F * D
-        g = self.g_att.view(B, F, D)                                # d attention(fe): first half of d dnn_in
-        _lib.check(_lib.load().dfm_copy_2d(self.g_xcat.data_ptr(), 2 * FD, g.data_ptr(), FD, B, FD, _lib.stream_handle()))
-        grads: List[torch.Tensor] = []
+        # d attention(fe) = the first half of d dnn_in: read in place by the last block's LayerNorm backward
+        if self.blocks[-1].use_residual:
+            g = self.g_xcat
+            self._ctxs[-1].g_from = 2 * FD
+        else:
+            g = self.g_att.view(B, F, D)
+            _lib.check(_lib.load().dfm_copy_2d(self.g_xcat.data_ptr(), 2 * FD, g.data_ptr(), FD, B, FD, _lib.stream_handle()))
         for block, ctx in zip(reversed(self.blocks), reversed(self._ctxs)):
             out = _AttnGemmFn.backward(ctx, g)
             g = out[1]
-            grads = list(out[2:]) + grads
-        torch._foreach_add_([p.grad for p in self._att_params], [t.view_as(p) for t, p in zip(grads, self._att_params)])
+            if len(out) > 2:           # the flat buffer is not laid out for direct writes: add the temporaries
+                ps = block._param_list()
+                torch._foreach_add_([p.grad for p in ps], [t.view_as(p) for t, p in zip(out[2:], ps)])
         _lib.check(_lib.load().dfm_embedding_grad_combine(
             self.g_xcat.data_ptr() + FD * 4, 2 * FD, g.data_ptr(), self.g_logits.data_ptr(), self.fm_sum.data_ptr(),
             self.fe.data_ptr(), B, F, D, self.g_fe.data_ptr(), _lib.stream_handle()))

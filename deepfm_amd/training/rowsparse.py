@@ -94,6 +94,16 @@ class RowSparseAdam:
         emb_ids = {id(p) for p in emb_dense}
         others = [p for p in model.parameters()
                   if id(p) not in table_ids and id(p) not in emb_ids and p.requires_grad]
+        # modules may ask for groups of parameters to lie back to back (attention: W_q | W_k | W_v as one
+        # stacked weight without a copy): each group moves, in its order, to where its first member is
+        groups = [g for m in model.modules() if hasattr(m, "adjacent_parameters") for g in m.adjacent_parameters()]
+        for g in groups:
+            ids = {id(p) for p in g}
+            if all(any(p is q for q in others) for p in g):
+                first = min(i for i, q in enumerate(others) if id(q) in ids)
+                rest = [q for q in others if id(q) not in ids]
+                first -= sum(1 for q in others[:first] if id(q) in ids)
+                others = rest[:first] + list(g) + rest[first:]
         self.dense_params = emb_dense + others
         # every parameter starts on a 64-byte boundary (16 floats) so kernels can use 16-byte
         # vector loads on the views; the padding stays 0 (zero grad -> zero Adam update)

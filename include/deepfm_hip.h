@@ -346,11 +346,17 @@ int dfm_attention_qkv_core_backward(const float* d_x, const float* d_w_qkv, cons
                                     const float* d_g_o, int64_t batch, int num_fields, int embed_dim,
                                     int attention_dim, int num_heads, float* d_g_qkv, dfm_stream_t stream);
 size_t dfm_layernorm_workspace_bytes(int64_t rows, int dim);
+/* out_group_rows > 0: output row r is written at d_out + (r / out_group_rows) * out_group_stride +
+ * (r % out_group_rows) * dim (the attention output as the first half of the DNN's concatenated input,
+ * attention_deepfm.py:57-61, without a copy); 0: contiguous (rows, dim). */
 int dfm_layernorm_forward(const float* d_y, const float* d_res, int64_t rows, int dim, const float* d_gamma,
-                          const float* d_beta, float eps, float* d_out, float* d_stats, dfm_stream_t stream);
+                          const float* d_beta, float eps, float* d_out, float* d_stats, int64_t out_group_rows,
+                          int64_t out_group_stride, dfm_stream_t stream);
+/* g_group_rows / g_group_stride: the same addressing for the incoming gradient d_g_out. */
 int dfm_layernorm_backward(const float* d_g_out, const float* d_y, const float* d_res, const float* d_stats,
                            int64_t rows, int dim, const float* d_gamma, float* d_g_sum, float* d_g_gamma,
-                           float* d_g_beta, void* d_workspace, dfm_stream_t stream);
+                           float* d_g_beta, void* d_workspace, int64_t g_group_rows, int64_t g_group_stride,
+                           dfm_stream_t stream);
 
 /* ---------------------------------------------------------------------------------
  * DNN tower glue (reference deepfm/models/layers/dnn.py:45-55): BatchNorm1d (training

@@ -474,6 +474,12 @@ def test_fused_attention_deepfm_step_matches_the_autograd_step(layers):
         opt = RowSparseAdam(model, lr=1e-3, l2=1e-5, max_grad_norm=1.0)
         if fused:
             assert fused_step_class(model) is FusedAttentionDeepFMStep
+        # the optimizer lays W_q | W_k | W_v (and their gradients) out back to back: the stacked projection
+        # weight is a view, not a torch.cat per step (attention.py stacked_view)
+        from deepfm_amd.models.layers.attention import stacked_view
+        for blk in model.attention.layers:
+            for group in blk.adjacent_parameters():
+                assert stacked_view(group) is not None and stacked_view([p.grad for p in group]) is not None
         step = (FusedAttentionDeepFMStep if fused else RowSparseTrainStep)(model, opt, B, use_graph=False)
         losses, snap = [], None
         for i in range(4):

@@ -23,7 +23,7 @@ def test_layernorm_forward_backward(D, rows):
     out = torch.empty_like(y)
     stats = torch.empty(rows, 2, device="cuda")
     _lib.check(lib.dfm_layernorm_forward(y.data_ptr(), res.data_ptr(), rows, D, gamma.data_ptr(), beta.data_ptr(),
-                                         1e-5, out.data_ptr(), stats.data_ptr(), _lib.stream_handle()))
+                                         1e-5, out.data_ptr(), stats.data_ptr(), 0, 0, _lib.stream_handle()))
     s = (y + res).double().requires_grad_()
     ga, be = gamma.double().requires_grad_(), beta.double().requires_grad_()
     want = torch.nn.functional.layer_norm(s, (D,), ga, be, 1e-5)
@@ -35,10 +35,42 @@ def test_layernorm_forward_backward(D, rows):
     ws = torch.empty(max(lib.dfm_layernorm_workspace_bytes(rows, D) // 4, 1), device="cuda")
     _lib.check(lib.dfm_layernorm_backward(up.data_ptr(), y.data_ptr(), res.data_ptr(), stats.data_ptr(), rows, D,
                                           gamma.data_ptr(), g_s.data_ptr(), d_gamma.data_ptr(), d_beta.data_ptr(),
-                                          ws.data_ptr(), _lib.stream_handle()))
+                                          ws.data_ptr(), 0, 0, _lib.stream_handle()))
     torch.testing.assert_close(g_s.double(), s.grad, rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(d_gamma.double(), ga.grad, rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(d_beta.double(), be.grad, rtol=1e-4, atol=1e-4)
+
+
+def test_layernorm_grouped_rows_equal_contiguous():
+    """Output / incoming gradient addressed as (sample, field) rows inside a wider per-sample layout (the
+    attention half of AttentionDeepFM's concatenated DNN input): same bits as the contiguous call."""
+    lib = _lib.load()
+    B, F, D = 37, 39, 32
+    rows, wide = B * F, 2 * F * D
+    g = torch.Generator(device="cuda").manual_seed(3)
+    y, res, up = (torch.randn(rows, D, device="cuda", generator=g) for _ in range(3))
+    gamma, beta = torch.randn(D, device="cuda", generator=g), torch.randn(D, device="cuda", generator=g)
+    outs, grads = [], []
+    for grouped in (False, True):
+        out = torch.full((B, wide), 7.0, device="cuda") if grouped else torch.empty(rows, D, device="cuda")
+        stats = torch.empty(rows, 2, device="cuda")
+        _lib.check(lib.dfm_layernorm_forward(y.data_ptr(), res.data_ptr(), rows, D, gamma.data_ptr(), beta.data_ptr(), 1e-5,
+                                             out.data_ptr(), stats.data_ptr(), F if grouped else 0, wide if grouped else 0,
+                                             _lib.stream_handle()))
+        gin = torch.zeros(B, wide, device="cuda")
+        gin[:, :F * D] = up.view(B, F * D)
+        g_s, dg, db = torch.empty_like(y), torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda")
+        ws = torch.empty(max(lib.dfm_layernorm_workspace_bytes(rows, D) // 4, 1), device="cuda")
+        _lib.check(lib.dfm_layernorm_backward((gin if grouped else up).data_ptr(), y.data_ptr(), res.data_ptr(), stats.data_ptr(),
+                                              rows, D, gamma.data_ptr(), g_s.data_ptr(), dg.data_ptr(), db.data_ptr(),
+                                              ws.data_ptr(), F if grouped else 0, wide if grouped else 0, _lib.stream_handle()))
+        if grouped:
+            assert bool((out[:, F * D:] == 7.0).all())               # the other half is left alone
+            out = out[:, :F * D].reshape(rows, D)
+        outs.append(out.clone()); grads.append((g_s, dg, db))
+    assert torch.equal(outs[0], outs[1])
+    for a, b in zip(grads[0], grads[1]):
+        assert torch.equal(a, b)
 
 
 def _gemm(a, lda, a_kc, b, ldb, b_kc, c, m, n, k, bias=None, accumulate=False):
