@@ -307,7 +307,15 @@ def main():
     step.load_packed(records[0])
     # several steps per graph need the whole step inside ONE graph: one rank without the split exchange path
     spg = 1 if ((opt.split and not step.exchange_in_body) or args.no_graph) else args.steps_per_graph
-    step.capture(timed_variant=True, steps_per_graph=spg)
+    try:
+        step.capture(timed_variant=True, steps_per_graph=spg)
+    except Exception as exc:      # e.g. a runtime that refuses to capture the collectives: measure the eager step
+        if not dist.is_initialized():
+            raise
+        print(f"[bench rank {rank}] graph capture failed ({type(exc).__name__}: {exc}); running the step eagerly",
+              file=sys.stderr, flush=True)
+        step.release_graphs()
+        step.use_graph = False
 
     feed = None
     if args.h2d:
