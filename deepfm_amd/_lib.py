@@ -145,7 +145,7 @@ SIGNATURES = {
     "dfm_step_prepare_num_partials": (_L, [_I, _I, _I, _L]),
     "dfm_step_match_bytes": (_SZ, [_I, _I]),
     "dfm_step_prepare": (_I, [C.POINTER(Table), _I, _I, _I, _P, _P, _P, _P, _P, _F, _F, _P, _P, _L, _L,
-                              C.POINTER(SlabRef), _I, _P, _I, _L, _P, _P, _P]),
+                              C.POINTER(SlabRef), _I, _P, _I, _L, _P, _L, _P, _P]),
     "dfm_step_apply": (_I, [C.POINTER(Table), _I, _I, _I, _P, _P, _P, _P, _P, _P, _F, _F, _F, _F, _P, _P, _P, _P, _P,
                             _L, _I, _P]),
     "dfm_fm_forward": (_I, [_P, _L, _I, _I, _P, _P]),

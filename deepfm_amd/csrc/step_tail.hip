@@ -95,14 +95,15 @@ __global__ __launch_bounds__(kTailThreads) void step_prepare_kernel(
     const int32_t* __restrict__ num_uniq, float* __restrict__ row_g2, float* __restrict__ row_g1,
     int32_t* __restrict__ owner_flag, float grad_scale, float l2, float* __restrict__ g, const float* __restrict__ p,
     int64_t n, int64_t n_l2, SlabTable slabs, const float* __restrict__ dense_gathered, int world,
-    int64_t gathered_stride, float* __restrict__ partial, const uint8_t* __restrict__ match) {
+    int64_t gathered_stride, float* __restrict__ partial, int64_t dense_partial_offset,
+    const uint8_t* __restrict__ match) {
   const int blk = blockIdx.x;
   if (blk < merge_blocks)
     rowadam_merge_body(blk, tabs, S, D, L, uniq_rows, num_uniq, row_g2, row_g1, owner_flag, grad_scale, l2, partial,
                        match);
   else
     dense_prepare_slabs_body(blk - merge_blocks, g, p, n, n_l2, l2, slabs, dense_gathered, world, gathered_stride,
-                             grad_scale, partial + merge_blocks);
+                             grad_scale, partial + dense_partial_offset);
 }
 
 __global__ __launch_bounds__(kTailThreads) void step_apply_kernel(
@@ -203,7 +204,7 @@ extern "C" int dfm_step_prepare(const dfm_table* tables, int num_sparse, int dim
                                 float* d_row_g1, int32_t* d_owner_flag, float grad_scale, float l2, float* d_g,
                                 const float* d_p, int64_t n, int64_t n_l2, const dfm_slab_ref* slabs, int num_slabs,
                                 const float* d_dense_gathered, int world, int64_t gathered_stride, float* d_partials,
-                                void* d_match, dfm_stream_t stream) {
+                                int64_t dense_partial_offset, void* d_match, dfm_stream_t stream) {
   DFM_REQUIRE(tables && d_uniq_rows && d_num_uniq && d_row_g2 && d_row_g1 && d_owner_flag && d_partials && d_g && d_p,
               "null argument");
   DFM_REQUIRE(num_sparse > 0 && num_sparse <= DFM_MAX_FIELDS && num_lists > 0, "bad sizes");
@@ -221,6 +222,8 @@ extern "C" int dfm_step_prepare(const dfm_table* tables, int num_sparse, int dim
   SlabTable st = {};
   if (int rc = fill_slab_table(slabs, num_slabs, d_g, n, &st)) return rc;
   const int64_t mb = row_blocks(num_sparse, dim, num_lists), pb = prep_blocks(n);
+  if (dense_partial_offset == 0) dense_partial_offset = mb;
+  DFM_REQUIRE(dense_partial_offset >= mb, "the dense partials must not overlap the %lld row partials", (long long)mb);
   // with three or more lists (data-parallel ranks x chunks) the list memberships are resolved once,
   // through LDS, instead of by L-1 global binary searches per entry inside the merge
   uint8_t* match = (d_match && num_lists > 2) ? static_cast<uint8_t*>(d_match) : nullptr;
@@ -233,7 +236,7 @@ extern "C" int dfm_step_prepare(const dfm_table* tables, int num_sparse, int dim
   hipLaunchKernelGGL(step_prepare_kernel, dim3(static_cast<unsigned>(mb + pb)), dim3(kTailThreads), 0,
                      as_stream(stream), static_cast<int>(mb), ta, num_sparse, dim, num_lists, d_uniq_rows, d_num_uniq,
                      d_row_g2, d_row_g1, d_owner_flag, grad_scale, l2, d_g, d_p, n, n_l2, st, d_dense_gathered, world,
-                     gathered_stride, d_partials, match);
+                     gathered_stride, d_partials, dense_partial_offset, match);
   DFM_LAUNCH_CHECK();
   return DFM_OK;
 }

@@ -203,7 +203,8 @@ class RowSparseAdam:
                                         g2.data_ptr(), g1.data_ptr(), self._owner.data_ptr(), grad_scale, self.l2,
                                         self.flat_grad.data_ptr(), self.flat_param.data_ptr(), n_dense, self.n_l2,
                                         refs, n_refs, _lib.ptr(dense_gathered), max(self.world, 1), gathered_stride,
-                                        self._partials.data_ptr(), _lib.ptr(self._match), stream))
+                                        self._partials.data_ptr(), self._dense_partial_offset(lists),
+                                        _lib.ptr(self._match), stream))
         norm_ptr, n_norm = self._norm_partials(n_partials, lists)
         _lib.check(lib.dfm_grad_norm_finalize(norm_ptr, n_norm,
                                               self.max_grad_norm or 0.0, self.sq_norm.data_ptr(),
@@ -226,6 +227,10 @@ class RowSparseAdam:
 
     def _extra_partial_count(self, lists: int) -> int:
         """Floats kept free behind the norm partials (subclasses that exchange partial norms)."""
+        return 0
+
+    def _dense_partial_offset(self, lists: int) -> int:
+        """Where the dense buffer's norm partials start in ``_partials`` (0: right behind the row partials)."""
         return 0
 
     def _norm_partials(self, n_partials: int, lists: int):

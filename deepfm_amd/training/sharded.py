@@ -175,21 +175,31 @@ class ShardedRowAdam(RowSparseAdam):
         return self.dense_source
 
     def _row_partials(self, lists: int) -> int:
-        return _lib.load().dfm_rowadam_num_partials(self.num_sparse, self.dim, lists)
+        """Row partials of the rank with the MOST fields: every rank pads its own to this length (the tail
+        stays zero), so that the all-gather below has one size on all ranks."""
+        return _lib.load().dfm_rowadam_num_partials(max(self.shard.shards.count), self.dim, lists)
 
     def _extra_partial_count(self, lists: int) -> int:
-        return self.world * self._row_partials(lists)
+        lib = _lib.load()
+        own = lib.dfm_rowadam_num_partials(self.num_sparse, self.dim, lists)
+        return (self._row_partials(lists) - own) + self.world * self._row_partials(lists)
+
+    def _dense_partial_offset(self, lists: int) -> int:
+        return self._row_partials(lists)
 
     def _norm_partials(self, n_partials: int, lists: int):
+        # _partials = [row partials of this rank's rows, zero-padded to `rows` | dense partials (identical on
+        #              every rank) | every rank's padded row partials, all-gathered]
+        # and the norm is the sum from the second block on, in the same order on every rank
+        lib = _lib.load()
+        rows = self._row_partials(lists)
+        dense = n_partials - lib.dfm_rowadam_num_partials(self.num_sparse, self.dim, lists)
         if self.max_grad_norm is None:
             # no clip: nothing downstream reads the norm; the step / seed tick still happens in finalize
-            return self._partials.data_ptr(), n_partials
-        # [row partials of this rank's rows | dense partials (identical on every rank) | every rank's row
-        #  partials, all-gathered]: summed from the second block on, in the same order on every rank
-        rows = self._row_partials(lists)
-        exchange.all_gather_flat(self._partials[n_partials:n_partials + self.world * rows], self._partials[:rows],
+            return self._partials.data_ptr(), rows + dense
+        exchange.all_gather_flat(self._partials[rows + dense:rows + dense + self.world * rows], self._partials[:rows],
                                  self.group)
-        return self._partials.data_ptr() + 4 * rows, n_partials - rows + self.world * rows
+        return self._partials.data_ptr() + 4 * rows, dense + self.world * rows
 
 
 class ShardedStepMixin:

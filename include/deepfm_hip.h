@@ -517,7 +517,9 @@ int dfm_step_embedding_backward(const int32_t* d_dense_list, int num_dense, cons
  * d_dense_gathered (optional, data parallel): (world, n) — every rank's dense gradient buffer from
  * the step's exchange, rank r's at d_dense_gathered + r * gathered_stride floats (0 = n: contiguous);
  * d_g is then REPLACED by grad_scale * their sum in rank order (an all-reduce with a fixed summation
- * order and no launch of its own). */
+ * order and no launch of its own).  dense_partial_offset: where in d_partials the dense buffer's partials
+ * start (0 = right behind the dfm_rowadam_num_partials row partials; field-sharded tables pad the row part
+ * to the same length on every rank so that it can be all-gathered). */
 int64_t dfm_step_prepare_num_partials(int num_sparse, int dim, int num_lists, int64_t n);
 size_t dfm_step_match_bytes(int num_sparse, int num_lists);
 int dfm_step_prepare(const dfm_table* tables, int num_sparse, int dim, int num_lists,
@@ -525,7 +527,7 @@ int dfm_step_prepare(const dfm_table* tables, int num_sparse, int dim, int num_l
                      float* d_row_g1, int32_t* d_owner_flag, float grad_scale, float l2, float* d_g,
                      const float* d_p, int64_t n, int64_t n_l2, const dfm_slab_ref* slabs, int num_slabs,
                      const float* d_dense_gathered, int world, int64_t gathered_stride, float* d_partials,
-                     void* d_match, dfm_stream_t stream);
+                     int64_t dense_partial_offset, void* d_match, dfm_stream_t stream);
 /* dfm_rowadam_apply + dfm_dense_adam in one launch. */
 int dfm_step_apply(const dfm_table* tables, int num_sparse, int dim, int num_lists,
                    const int32_t* d_uniq_rows, const int32_t* d_num_uniq, const float* d_row_g2,
