@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o run -- python3 $root/tools/time_layers.py cin 12 > $out/time.txt 2> $out/trace.err || exit 1
 cp $(ls $out/trace/*kernel_stats.csv | head -1) $out/kernel_stats.csv
 : > $out/pmc.txt
-for c in SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT; do
+for c in SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_LDS_IDX_ACTIVE TA_TA_BUSY_sum; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_$c -o run -- python3 $root/tools/time_layers.py cin 4 > /dev/null 2> $out/pmc_$c.err || exit 1
   python3 $root/tools/pmc_summary.py $out/pmc_$c $c cin >> $out/pmc.txt
   echo "done $c"
