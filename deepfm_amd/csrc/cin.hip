@@ -59,8 +59,9 @@ int cin_bwd_pack_wt(const float* W, int C, int H, int F, bf16_t* hi, bf16_t* lo,
 int cin_mfma_dgrad(const CinBwdArgs& args, int D, bool split, hipStream_t st);
 size_t cin_mfma_wgrad_workspace_bytes(int64_t B, int C, int H, int F);
 bool cin_mfma_wgrad_has_bias(int F);
+bool cin_mfma_wgrad_supported(int64_t B, int D);
 int cin_mfma_wgrad(const float* dY, const float* x0, const float* hidden, int64_t hidden_stride, int64_t B,
-                   int F, int H, int C, float* dW, float* db, void* workspace, bool split, hipStream_t st);
+                   int F, int H, int C, int D, float* dW, float* db, void* workspace, bool split, hipStream_t st);
 size_t cin_bias_grad_workspace_bytes(int C);
 int cin_bias_grad_launch(const float* dY, int64_t B, int C, int D, float* db, float* partial, hipStream_t st);
 bool cin_mfma_supported(int F, int D, const int* C, const int* H, int L);
@@ -159,8 +160,9 @@ static size_t packed_wt_total(const Layout& lo) {
   for (int i = 0; i < lo.L; ++i) total += ((cin_bwd_packed_wt_elems(lo.H[i], lo.F, lo.C[i]) + 63) / 64) * 64;
   return total;
 }
-static bool mfma_bwd_ok(const Layout& lo) {
-  return cin_mode() != 2 && lo.D == 16 && cin_mfma_supported(lo.F, lo.D, lo.C.data(), lo.H.data(), lo.L);
+static bool mfma_bwd_ok(const Layout& lo, int64_t batch) {
+  return cin_mode() != 2 && cin_mfma_wgrad_supported(batch, lo.D) &&
+         cin_mfma_supported(lo.F, lo.D, lo.C.data(), lo.H.data(), lo.L);
 }
 
 extern "C" size_t dfm_cin_backward_workspace_bytes(const int32_t* layer_sizes, int num_layers,
@@ -248,7 +250,7 @@ extern "C" int dfm_cin_backward(const float* d_x0, int64_t batch, int num_fields
   if (batch == 0) return DFM_OK;
   hipStream_t st = as_stream(stream);
   for (int i = 0; i < lo.L; ++i) DFM_REQUIRE(weights[i] && g_weights[i] && g_biases[i], "layer %d: null parameter", i);
-  if (mfma_bwd_ok(lo)) {
+  if (mfma_bwd_ok(lo, batch)) {
     const bool split = cin_mode() == 0;
     float* dY_all = static_cast<float*>(d_workspace);
     bf16_t* hi = reinterpret_cast<bf16_t*>(dY_all + lo.saved_floats);
@@ -283,7 +285,7 @@ extern "C" int dfm_cin_backward(const float* d_x0, int64_t batch, int num_fields
       const CinBwdLayer& ly = args.layer[i];
       // the bias gradient rides in a padding column of the weight-gradient GEMM when there is one
       const bool fused_bias = cin_mfma_wgrad_has_bias(num_fields);
-      if (int rc = cin_mfma_wgrad(ly.dY, d_x0, ly.hidden, ly.hidden_stride, batch, num_fields, lo.H[i], lo.C[i],
+      if (int rc = cin_mfma_wgrad(ly.dY, d_x0, ly.hidden, ly.hidden_stride, batch, num_fields, lo.H[i], lo.C[i], dim,
                                   g_weights[i], fused_bias ? g_biases[i] : nullptr, wg_ws, split, st))
         return rc;
       // else: wgrad's slabs are consumed (stream order), its workspace doubles as the bias partials

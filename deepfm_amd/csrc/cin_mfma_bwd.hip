@@ -277,6 +277,7 @@ struct CinWgradArgs {
   int64_t B;
   int F, H, MB, KT, slices, FP;  // KT: 32-wide column tiles over k' = h*FP + f (FP = padded F)
   int bias_col;                  // 1: column k' = F carries the bias gradient (needs FP > F)
+  int64_t per;                   // samples per batch slice (even when D == 8: a k-step then spans two samples)
   unsigned long long* stamps;    // tools/microbench_cin_wgrad only (DFM_CIN_STAMPS build): per-wave phase sums
 };
 
@@ -298,7 +299,8 @@ __device__ __forceinline__ float4 ld4g(const float* p) {
   const gf4 v = *reinterpret_cast<const __attribute__((address_space(1))) gf4*>(reinterpret_cast<uintptr_t>(p));
   return float4{v.x, v.y, v.z, v.w};
 }
-__device__ const float kWgOnes[16] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+__device__ const float kWgOnes[32] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f,
+                                      1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
 #ifndef WG_OCC
 #define WG_OCC 2
 #endif
@@ -320,8 +322,11 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
-template <bool SPLIT>
+// D = embedding dim (8, 16 or 32): one pipeline step is one MFMA k-step = 16 consecutive (b, d) columns —
+// a sample (D = 16), half a sample (D = 32) or two samples (D = 8, lane half hf takes sample 2s + hf).
+template <bool SPLIT, int D>
 __global__ __launch_bounds__(256, kWgBound) void cin_wgrad_mfma(CinWgradArgs a) {
+  static_assert(D == 8 || D == 16 || D == 32, "k-steps of 16 columns need D in {8, 16, 32}");
   constexpr int SLAB = 4 * 64 * 16;                       // one sample: 4 row blocks x 64 lanes x 16 B (hi or lo)
   __shared__ __attribute__((aligned(16))) unsigned char wbuf[2 * 2 * SLAB];   // [buf][hi, lo]
   const int lane = lane_id(), wave = wave_id_uniform(), tid = threadIdx.x;
@@ -332,22 +337,29 @@ __global__ __launch_bounds__(256, kWgBound) void cin_wgrad_mfma(CinWgradArgs a) 
   // bias gradient for free: the first padding column of hidden row 0 (k' = F, present when F is not a
   // multiple of 8) multiplies dY by ones, so its slab column is db[c] = sum_{b,d} dY[c,b,d]
   const bool kbias = a.bias_col && kt < a.KT && h == 0 && f == a.F;
-  const int64_t per = (a.B + a.slices - 1) / a.slices;
+  const int64_t per = a.per;
   const int64_t b0 = blockIdx.y * per, b1 = b0 + per < a.B ? b0 + per : a.B;
-  const int n = b1 > b0 ? static_cast<int>(b1 - b0) : 0;
+  const int n = b1 > b0 ? static_cast<int>((b1 - b0) * D / 16) : 0;       // k-steps of this slice
   f32x16 acc[4] = {};
-  // A operand: fragment (mb, lane = hf*32 + r) of a sample is dY[b][32 mb + r][8 hf .. 8 hf + 7] — 32
-  // contiguous bytes of fp32; this thread stages row s_c of every sample (rows past C: row C - 1 again)
+  // A operand: fragment (mb, lane = hf*32 + r) of k-step s is dY[b][32 mb + r][d .. d + 7] with (b, d) the
+  // sample and offset of column 16 s + 8 hf — 32 contiguous bytes of fp32; this thread stages row s_c of
+  // every k-step (rows past C: row C - 1 again)
   const int s_mb = tid >> 6, s_lane = tid & 63;
   const int s_c = min(32 * s_mb + (s_lane & 31), a.C - 1);
-  const float* pa = a.dY + b0 * a.C * 16;                                  // uniform; + sample * C * 16
-  const uint32_t off_a = static_cast<uint32_t>(s_c * 16 + 8 * (s_lane >> 5));
-  const int64_t stride_a = static_cast<int64_t>(a.C) * 16;
+  const float* pa = a.dY + (b0 * a.C + s_c) * D;                           // + sample * C * D + d
+  const int64_t stride_a = static_cast<int64_t>(a.C) * D;
+  // (sample relative to b0, offset inside the sample) of the 8 columns a lane half takes in k-step s, split
+  // into a wave-uniform part that moves with s and a per-lane constant: D >= 16: sample 16 s / D, offset
+  // 16 s % D + 8 half; D = 8: sample 2 s + half, offset 0
+  auto sample_u = [](int s) { return D >= 16 ? (16 * s) / D : 2 * s; };
+  auto offset_u = [](int s) { return D >= 16 ? (16 * s) % D : 0; };
+  const uint32_t lane_a = D >= 16 ? 8u * (s_lane >> 5) : static_cast<uint32_t>((s_lane >> 5) * stride_a);
   // B operand: z[j] = hidden[b][h][8 hf + j] * x0[b][f][8 hf + j] of this lane's column; columns that do
   // not exist read (h, f) = (0, 0), the bias column reads ones twice with stride 0
-  const float* hp0 = kbias ? kWgOnes + 8 * hf : a.hidden + b0 * a.hidden_stride + (kvalid ? h : 0) * 16 + 8 * hf;
-  const float* xp0 = kbias ? kWgOnes + 8 * hf : a.x0 + (b0 * a.F + (kvalid ? f : 0)) * 16 + 8 * hf;
-  const uint32_t hs = kbias ? 0u : static_cast<uint32_t>(a.hidden_stride), xs = kbias ? 0u : static_cast<uint32_t>(a.F * 16);
+  const float* hp0 = kbias ? kWgOnes : a.hidden + b0 * a.hidden_stride + (kvalid ? h : 0) * D;
+  const float* xp0 = kbias ? kWgOnes : a.x0 + (b0 * a.F + (kvalid ? f : 0)) * D;
+  const uint32_t hs = kbias ? 0u : static_cast<uint32_t>(a.hidden_stride), xs = kbias ? 0u : static_cast<uint32_t>(a.F * D);
+  const uint32_t lane_h = D >= 16 ? 8u * hf : hf * hs, lane_x = D >= 16 ? 8u * hf : hf * xs;   // per-lane constants
   // Global loads run kWgDepth samples ahead of their use, in a ring of register slots (compile-time slot
   // numbers: the loop is unrolled by the ring size).  Measured with tools/microbench_cin_wgrad (H = 64
   // layer, kernel + slab reduce): depth 1 168 us, depth 2 174, depth 4 209, depth 6 198 (one wave per
@@ -360,14 +372,15 @@ __global__ __launch_bounds__(256, kWgBound) void cin_wgrad_mfma(CinWgradArgs a) 
   float4 rf0[kWgDepth], rf1[kWgDepth], hb0[kWgDepth], hb1[kWgDepth], xb0[kWgDepth], xb1[kWgDepth];
   auto load_a = [&](int s, auto slot_tag) {     // s: sample of the slice, clamped by the caller
     constexpr int SL = decltype(slot_tag)::value;
-    const float* p = pa + s * stride_a + off_a;
+    const float* p = pa + (sample_u(s) * stride_a + offset_u(s)) + lane_a;
     rf0[SL] = ld4g(p);
     rf1[SL] = ld4g(p + 4);
   };
   auto load_b = [&](int s, auto slot_tag) {
     constexpr int SL = decltype(slot_tag)::value;
-    const float* hp = hp0 + static_cast<uint64_t>(s) * hs;
-    const float* xp = xp0 + static_cast<uint64_t>(s) * xs;
+    const int bs = sample_u(s), od = offset_u(s);
+    const float* hp = hp0 + (static_cast<uint64_t>(bs) * hs + od) + lane_h;
+    const float* xp = xp0 + (static_cast<uint64_t>(bs) * xs + od) + lane_x;
     hb0[SL] = ld4g(hp); hb1[SL] = ld4g(hp + 4); xb0[SL] = ld4g(xp); xb1[SL] = ld4g(xp + 4);
   };
   auto split8 = [](const float4& v0, const float4& v1, bf16x8& hi, bf16x8& lo) {
@@ -549,8 +562,10 @@ static int launch_dgrad(const CinBwdArgs& args, bool split, hipStream_t st) {
 
 int cin_mfma_dgrad(const CinBwdArgs& args, int D, bool split, hipStream_t st) {
   const int FG = (args.F + 7) / 8;
-#define DFM_CASE(GG) \
-  if (D == 16 && FG == GG) return launch_dgrad<16, GG>(args, split, st);
+#define DFM_CASE(GG)                                                  \
+  if (D == 16 && FG == GG) return launch_dgrad<16, GG>(args, split, st); \
+  if (D == 8 && FG == GG) return launch_dgrad<8, GG>(args, split, st);   \
+  if (D == 32 && FG == GG) return launch_dgrad<32, GG>(args, split, st);
   DFM_CASE(1) DFM_CASE(2) DFM_CASE(3) DFM_CASE(4) DFM_CASE(5)
 #undef DFM_CASE
   return fail(DFM_ERR_UNSUPPORTED, "no MFMA CIN dgrad kernel for D=%d, F=%d", D, args.F);
@@ -580,10 +595,14 @@ unsigned long long* g_wgrad_stamps = nullptr;     // set by tools/microbench_cin
 // true: cin_mfma_wgrad also produces the bias gradient (a free padding column exists)
 bool cin_mfma_wgrad_has_bias(int F) { return F % 8 != 0; }
 
-// dW += dY^T (hidden (x) x0); db += sum_{b,d} dY when `db` is given (cin_mfma_wgrad_has_bias); D must be 16
+// D == 8 pairs samples in a k-step: the batch must be even
+bool cin_mfma_wgrad_supported(int64_t B, int D) { return D == 16 || D == 32 || (D == 8 && B % 2 == 0); }
+
+// dW += dY^T (hidden (x) x0); db += sum_{b,d} dY when `db` is given (cin_mfma_wgrad_has_bias)
 int cin_mfma_wgrad(const float* dY, const float* x0, const float* hidden, int64_t hidden_stride, int64_t B,
-                   int F, int H, int C, float* dW, float* db, void* workspace, bool split, hipStream_t st) {
+                   int F, int H, int C, int D, float* dW, float* db, void* workspace, bool split, hipStream_t st) {
   DFM_REQUIRE(!db || cin_mfma_wgrad_has_bias(F), "no padding column for the bias gradient (F = %d)", F);
+  DFM_REQUIRE(cin_mfma_wgrad_supported(B, D), "no MFMA weight-gradient kernel for D = %d, B = %lld", D, (long long)B);
   const int MB = (C + 31) / 32, FP = ((F + 7) / 8) * 8;
   const int KT = (H * FP + 31) / 32;
   float* slabs = static_cast<float*>(workspace);
@@ -592,10 +611,17 @@ int cin_mfma_wgrad(const float* dY, const float* x0, const float* hidden, int64_
   a.dY = dY; a.C = C; a.x0 = x0; a.hidden = hidden; a.hidden_stride = hidden_stride; a.slabs = slabs;
   a.B = B; a.F = F; a.H = H; a.MB = MB; a.KT = KT; a.slices = slices; a.FP = FP;
   a.bias_col = db ? 1 : 0;
+  a.per = (B + slices - 1) / slices;
+  if (D == 8) a.per = (a.per + 1) & ~int64_t(1);
   a.stamps = g_wgrad_stamps;
   const dim3 grid((KT + 3) / 4, slices);
-  if (split) hipLaunchKernelGGL(cin_wgrad_mfma<true>, grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL(cin_wgrad_mfma<false>, grid, dim3(256), 0, st, a);
+#define DFM_WG(DD)                                                                         \
+  if (D == DD) {                                                                           \
+    if (split) hipLaunchKernelGGL((cin_wgrad_mfma<true, DD>), grid, dim3(256), 0, st, a);  \
+    else hipLaunchKernelGGL((cin_wgrad_mfma<false, DD>), grid, dim3(256), 0, st, a);       \
+  }
+  DFM_WG(8) DFM_WG(16) DFM_WG(32)
+#undef DFM_WG
   DFM_LAUNCH_CHECK();
   const int64_t n = static_cast<int64_t>(C) * H * F + (db ? C : 0);
   hipLaunchKernelGGL(cin_wgrad_reduce_mfma, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, st, slabs,

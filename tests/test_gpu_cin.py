@@ -73,14 +73,19 @@ def test_cin_cfg3_batch_vs_oracle():
         assert_close_mostly(npy(p.grad), grads[k], 2e-2, rtol=2e-4, what=k)
 
 
-@pytest.mark.parametrize("F,sizes,split", [
-    (12, [48, 40, 24], True),     # MFMA backward, generic paths: < 128 channels (MB < 4, KS < 8); bias in a padding column
-    (8, [32, 16], True),          # F a multiple of 8: no padding column -> separate bias-gradient kernels
-    (16, [128, 128], False),      # 128-channel specialisation without split, bias fallback
-    (39, [128, 64, 128], True),   # mixed: specialised and generic layers in one launch
+@pytest.mark.parametrize("F,sizes,split,D,B", [
+    (12, [48, 40, 24], True, 16, 96),    # MFMA backward, generic paths: < 128 channels (MB < 4, KS < 8); bias in a padding column
+    (8, [32, 16], True, 16, 96),         # F a multiple of 8: no padding column -> separate bias-gradient kernels
+    (16, [128, 128], False, 16, 96),     # 128-channel specialisation without split, bias fallback
+    (39, [128, 64, 128], True, 16, 96),  # mixed: specialised and generic layers in one launch
+    (12, [48, 40, 24], True, 8, 96),     # D = 8: a k-step of the weight gradient spans two samples
+    (39, [128, 64, 128], True, 8, 50),   #        batch slices rounded to even sample counts
+    (12, [48, 40, 24], True, 32, 96),    # D = 32: two k-steps per sample
+    (39, [128, 64, 128], True, 32, 37),
+    (8, [32, 16], True, 8, 33),          # D = 8 with an odd batch: the exact-fp32 VALU backward takes over
 ])
-def test_cin_mfma_backward_paths_vs_oracle(F, sizes, split):
-    """D = 16 takes the MFMA forward/backward kernels; shapes chosen to reach every code path of
+def test_cin_mfma_backward_paths_vs_oracle(F, sizes, split, D, B):
+    """D in {8, 16, 32} takes the MFMA forward/backward kernels; shapes chosen to reach every code path of
     csrc/cin_mfma.hip / cin_mfma_bwd.hip (specialised vs generic inner loops, fused vs separate bias
     gradient).  The biases are set to +6 (live channel) / -6 (dead channel, every third) so that no
     pre-activation sits near the ReLU kink: the split-bf16 arithmetic (relative error ~1e-5) would
@@ -89,15 +94,14 @@ def test_cin_mfma_backward_paths_vs_oracle(F, sizes, split):
     from deepfm_amd.models.layers.cin import CIN
     rng = np.random.default_rng(100 + F)
     torch.manual_seed(F)
-    cin = CIN(F, 16, sizes, split).cuda()
+    cin = CIN(F, D, sizes, split).cuda()
     with torch.no_grad():
         for conv in cin.conv_layers:
             c = torch.arange(conv.bias.numel(), device="cuda")
             conv.bias.copy_(torch.where(c % 3 == 2, -6.0, 6.0))
             conv.weight.mul_(0.25)            # keeps |W Z| well inside the +-6 offsets in every layer
     params = {k: v.detach().cpu().numpy() for k, v in cin.state_dict().items()}
-    B = 96
-    x = (rng.standard_normal((B, F, 16)) * 0.7).astype(np.float32)
+    x = (rng.standard_normal((B, F, D)) * 0.7).astype(np.float32)
     up = rng.standard_normal((B, cin.output_dim)).astype(np.float32)
     t = torch.from_numpy(x).cuda().requires_grad_()
     out = cin(t)
