@@ -24,7 +24,6 @@ the same deterministic merge (``csrc/rowadam.hip``) so replicas stay bit-identic
 
 from __future__ import annotations
 
-import ctypes as C
 from typing import Optional
 
 import torch
