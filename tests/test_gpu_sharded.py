@@ -173,15 +173,6 @@ def test_three_ranks_uneven_field_blocks(tmp_path):
             _close(torch.from_numpy(a[k]), torch.from_numpy(b[k]), f"rank {r} {k}")
 
 
-def test_four_ranks_stay_consistent():
-    """26 fields over 4 ranks (7, 7, 6, 6; four ranks + the launcher + this process is what a GPU box lets
-    one user run at once): dense replicas bit-identical, every owner's rows restored identically everywhere."""
-    sh = _launch(4, ["eager", "2", "sharded"], {})
-    assert len({r["flat"] for r in sh}) == 1, "dense replicas diverged"
-    assert len({r["tables"] for r in sh}) == 1
-    assert all(math.isfinite(r["loss"]) for r in sh) and sh[0]["moved"] > 0.5
-
-
 def test_one_rank_rccl_collectives_inside_the_graph():
     eager = _launch(1, ["eager", "4", "sharded", "nccl"], {})[0]
     graph = _launch(1, ["graph", "4", "sharded", "nccl"], {})[0]
