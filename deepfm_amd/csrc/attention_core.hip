@@ -470,6 +470,10 @@ int attn_qkv_mfma_forward(const float* x, const float* w, const float* bias, int
                           float* o, hipStream_t st);
 int attn_qkv_mfma_backward(const float* x, const float* w, const float* bias, const float* d_o, int64_t B, int F, int D,
                            int A, int heads, float* d_qkv, hipStream_t st);
+bool attn_block_mfma_supported(int F, int D, int A, int heads);
+int attn_block_mfma_forward(const float* x, const float* w, const float* bias, const float* wo, const float* bo,
+                            const float* gamma, const float* beta, float eps, int64_t B, int F, int D, int A, float* o,
+                            float* y, float* out, float* stats, int64_t out_group_stride, hipStream_t st);
 }  // namespace dfm
 
 // Attention core with the Q | K | V projection inside (attention_mfma.hip): x (B*F, D), stacked weight
@@ -490,6 +494,31 @@ extern "C" int dfm_attention_qkv_core_forward(const float* d_x, const float* d_w
   if (batch == 0) return DFM_OK;
   return attn_qkv_mfma_forward(d_x, d_w_qkv, d_b_qkv, batch, num_fields, embed_dim, attention_dim, num_heads, d_o,
                                as_stream(stream));
+}
+
+// The whole block forward in one launch (attention_mfma.hip): + W_out, bias, residual LayerNorm.
+extern "C" int dfm_attention_block_supported(int num_fields, int embed_dim, int attention_dim, int num_heads) {
+  return attn_block_mfma_supported(num_fields, embed_dim, attention_dim, num_heads) ? 1 : 0;
+}
+
+extern "C" int dfm_attention_block_forward(const float* d_x, const float* d_w_qkv, const float* d_b_qkv,
+                                           const float* d_w_out, const float* d_b_out, const float* d_gamma,
+                                           const float* d_beta, float eps, int64_t batch, int num_fields,
+                                           int embed_dim, int attention_dim, int num_heads, float* d_o, float* d_y,
+                                           float* d_out, float* d_stats, int64_t out_group_stride,
+                                           dfm_stream_t stream) {
+  DFM_REQUIRE(d_x && d_w_qkv && d_b_qkv && d_w_out && d_b_out && d_o && d_y && d_out, "null argument");
+  DFM_REQUIRE((d_gamma == nullptr) == (d_beta == nullptr) && (d_gamma == nullptr || d_stats != nullptr),
+              "residual LayerNorm needs gamma, beta and the statistics buffer together");
+  DFM_REQUIRE(attn_block_mfma_supported(num_fields, embed_dim, attention_dim, num_heads),
+              "unsupported shape (dfm_attention_block_supported)");
+  DFM_REQUIRE(al16(d_x) && al16(d_w_qkv) && al16(d_b_qkv) && al16(d_w_out) && al16(d_o), "16-byte aligned buffers only");
+  DFM_REQUIRE(out_group_stride == 0 || out_group_stride >= static_cast<int64_t>(num_fields) * embed_dim, "bad output grouping");
+  DFM_REQUIRE(batch >= 0 && batch < (int64_t(1) << 31), "batch out of range");
+  if (batch == 0) return DFM_OK;
+  return attn_block_mfma_forward(d_x, d_w_qkv, d_b_qkv, d_w_out, d_b_out, d_gamma, d_beta, eps, batch, num_fields,
+                                 embed_dim, attention_dim, d_o, d_y, d_out, d_stats, out_group_stride,
+                                 as_stream(stream));
 }
 
 extern "C" int dfm_attention_qkv_core_backward(const float* d_x, const float* d_w_qkv, const float* d_b_qkv,

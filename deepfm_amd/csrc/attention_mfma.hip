@@ -355,6 +355,99 @@ __global__ __launch_bounds__(kUnitsPerBlock * 64) void attn_qkv_mfma_fwd(
   }
 }
 
+// The whole forward of an _AttentionBlock (attention.py:91-120) in ONE launch, for num_heads == 4 (the four
+// waves of a workgroup are the four heads of one sample): projection + softmax(QK^T)V as above, then each
+// wave multiplies its head's output rows by its 16 columns of W_out (the accumulator of P V is already the
+// row fragment that product wants), the four partial (F, D) results meet in LDS, and the workgroup finishes
+// y = sum + b_out, and — with the residual — LayerNorm(y + x): mean / rstd per row by a 32- or 64-lane
+// reduction.  o (head outputs, for dW_out), y (for the LayerNorm backward) and the statistics are written
+// for the backward pass; the separate output GEMM and LayerNorm launches and their re-reads of o and y go.
+template <int NT, int KD, bool RES>
+__global__ __launch_bounds__(kUnitsPerBlock * 64) void attn_block_mfma_fwd(
+    const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+    const float* __restrict__ wo, const float* __restrict__ bo, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float eps, int64_t B, int F, int A, float* __restrict__ o, float* __restrict__ y,
+    float* __restrict__ out, float* __restrict__ stats, int64_t out_group_stride) {
+  constexpr int D = 16 * KD, YS = D + 4;                  // row stride of the partial images
+  extern __shared__ __attribute__((aligned(16))) float lds[];      // [4 heads][16 NT tokens][YS]
+  const int lane = lane_id(), wave = wave_id_uniform();
+  const int64_t b = blockIdx.x;                            // heads == kUnitsPerBlock: one sample per workgroup
+  const int h = wave;
+  const int c = lane & 15, g = lane >> 4;
+  {
+    Proj<NT, KD> pj;
+    pj.load_x(x, b * F, F, D, c, g);
+    float4 wq[KD], wk[KD], wv[KD];
+    pj.load_w(w, h * kHd, D, wq);
+    pj.load_w(w, A + h * kHd, D, wk);
+    pj.load_w(w, 2 * A + h * kHd, D, wv);
+    float4 qf[NT], kf[NT];
+    float va[NT][4];
+    pj.transposed(wq, bias, h * kHd, 0.25f, qf);
+    pj.transposed(wk, bias, A + h * kHd, 1.f, kf);
+    pj.direct(wv, bias, 2 * A + h * kHd, F, false, va);
+    f32x4 pt[NT][NT];
+    scores_softmax<NT>(kf, qf, F, g, pt);
+    float4 wof[KD];                                        // W_out[e = 16 et + c][h * 16 + 4 g ..]
+#pragma unroll
+    for (int et = 0; et < KD; ++et) wof[et] = ld4(wo + static_cast<int64_t>(16 * et + c) * A + h * kHd + 4 * g);
+    float* mine = lds + static_cast<size_t>(wave) * (16 * NT) * YS;
+#pragma unroll
+    for (int tq = 0; tq < NT; ++tq) {
+      f32x4 ot = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int tk = 0; tk < NT; ++tk)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ot = mfma4(va[tk][r], pt[tk][tq][r], ot);
+      const int query = 16 * tq + c;
+      const float4 of = make_float4(ot[0], ot[1], ot[2], ot[3]);      // O[query c][4 g ..]: a row fragment
+      if (query < F) st4(o + (b * F + query) * A + h * kHd + 4 * g, of);
+#pragma unroll
+      for (int et = 0; et < KD; ++et) {
+        f32x4 yp = {0.f, 0.f, 0.f, 0.f};
+        yp = mfma_frag(of, wof[et], yp);                   // yp[r] = partial y[token 16 tq + 4 g + r][e = 16 et + c]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mine[(16 * tq + 4 * g + r) * YS + 16 * et + c] = yp[r];
+      }
+    }
+  }
+  __syncthreads();
+  // rows of the sample, round-robin over the waves; LPT lanes per row (32 for D <= 32: two rows per pass)
+  constexpr int LPT = D <= 32 ? 32 : 64, RPP = 64 / LPT;
+  const int e = lane % LPT, sub = lane / LPT;
+  const bool elive = e < D;
+  const float bo_e = elive ? bo[e] : 0.f;
+  const float ga = (RES && elive) ? gamma[e] : 0.f, be = (RES && elive) ? beta[e] : 0.f;
+  for (int t0 = wave * RPP; t0 < F; t0 += kUnitsPerBlock * RPP) {
+    const int t = t0 + sub;
+    const bool live = elive && t < F;
+    const int tc = t < F ? t : F - 1;
+    float v = bo_e;
+#pragma unroll
+    for (int hh = 0; hh < kUnitsPerBlock; ++hh) v += elive ? lds[(static_cast<size_t>(hh) * 16 * NT + tc) * YS + e] : 0.f;
+    const int64_t row = b * F + tc;
+    if (live) y[row * D + e] = v;
+    if (!RES) {
+      if (live) out[out_group_stride ? b * out_group_stride + static_cast<int64_t>(tc) * D + e : row * D + e] = v;
+      continue;
+    }
+    const float s = elive ? v + x[row * D + e] : 0.f;
+    float mu = group_sum<16>(s);
+    mu += __shfl_xor(mu, 16, kWave);
+    if (LPT == 64) mu += __shfl_xor(mu, 32, kWave);
+    mu /= D;
+    const float cz = elive ? s - mu : 0.f;
+    float var = group_sum<16>(cz * cz);
+    var += __shfl_xor(var, 16, kWave);
+    if (LPT == 64) var += __shfl_xor(var, 32, kWave);
+    const float rstd = rsqrtf(var / D + eps);
+    if (live) {
+      out[out_group_stride ? b * out_group_stride + static_cast<int64_t>(tc) * D + e : row * D + e] = cz * rstd * ga + be;
+      if (e == 0) { stats[2 * row] = mu; stats[2 * row + 1] = rstd; }
+    }
+  }
+}
+
 // d_qkv (B*F, 3A) = gradient of the projection's output, from d_o; Q, K, V recomputed from x.
 template <int NT, int KD>
 __global__ __launch_bounds__(kUnitsPerBlock * 64) void attn_qkv_mfma_bwd(
@@ -509,6 +602,39 @@ int attn_qkv_mfma_backward(const float* x, const float* w, const float* bias, co
     case 3: return launch_qkv_bwd<3>(x, w, bias, d_o, B, F, D, A, heads, d_qkv, st);
     default: return launch_qkv_bwd<4>(x, w, bias, d_o, B, F, D, A, heads, d_qkv, st);
   }
+}
+
+bool attn_block_mfma_supported(int F, int D, int A, int heads) {
+  return attn_qkv_mfma_supported(F, D, A, heads) && heads == kUnitsPerBlock;
+}
+
+template <int KD, bool RES>
+static int launch_block_fwd(const float* x, const float* w, const float* bias, const float* wo, const float* bo,
+                            const float* gamma, const float* beta, float eps, int64_t B, int F, int A, float* o,
+                            float* y, float* out, float* stats, int64_t out_group_stride, hipStream_t st) {
+  const int nt = (F + 15) / 16;
+  const size_t lds = sizeof(float) * kUnitsPerBlock * (16 * nt) * (16 * KD + 4);
+  const dim3 grid(static_cast<unsigned>(B)), block(kUnitsPerBlock * 64);
+#define DFM_BLK(NT_)                                                                                              \
+  hipLaunchKernelGGL((attn_block_mfma_fwd<NT_, KD, RES>), grid, block, lds, st, x, w, bias, wo, bo, gamma, beta, eps, \
+                     B, F, A, o, y, out, stats, out_group_stride)
+  if (nt == 1) DFM_BLK(1); else if (nt == 2) DFM_BLK(2); else DFM_BLK(3);
+#undef DFM_BLK
+  DFM_LAUNCH_CHECK();
+  return DFM_OK;
+}
+
+int attn_block_mfma_forward(const float* x, const float* w, const float* bias, const float* wo, const float* bo,
+                            const float* gamma, const float* beta, float eps, int64_t B, int F, int D, int A, float* o,
+                            float* y, float* out, float* stats, int64_t out_group_stride, hipStream_t st) {
+  const bool res = gamma != nullptr;
+#define DFM_KD(K_)                                                                                                  \
+  if (D == 16 * K_)                                                                                                 \
+    return res ? launch_block_fwd<K_, true>(x, w, bias, wo, bo, gamma, beta, eps, B, F, A, o, y, out, stats, out_group_stride, st) \
+               : launch_block_fwd<K_, false>(x, w, bias, wo, bo, gamma, beta, eps, B, F, A, o, y, out, stats, out_group_stride, st)
+  DFM_KD(1); DFM_KD(2); DFM_KD(3); DFM_KD(4);
+#undef DFM_KD
+  return fail(DFM_ERR_UNSUPPORTED, "attention block kernel: embed_dim %d", D);
 }
 
 }  // namespace dfm

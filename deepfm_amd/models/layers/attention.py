@@ -37,6 +37,8 @@ class _AttentionBlock(nn.Module):
         # projections as GEMMs over the B*F rows (dfm_gemm_f32) + per-(sample, head) core kernel;
         # False (or an unsupported shape) selects the single fused LDS kernel of csrc/attention.hip
         self.gemm_path = True
+        # the forward as ONE kernel where its shape allows (4 heads of 16); False: core + GEMM + LayerNorm launches
+        self.whole_block_kernel = True
 
     def adjacent_parameters(self):
         """Parameters an optimizer with ONE flat buffer should lay out back to back, in this order: the
@@ -136,8 +138,30 @@ class _AttnGemmFn(torch.autograd.Function):
             w_qkv, b_qkv = torch.cat([wq, wk, wv], dim=0), torch.cat([bq, bk, bv], dim=0)
         X = x.view(M, D)
         o = torch.empty(M, A, dtype=torch.float32, device=x.device)
+        aligned = X.data_ptr() % 16 == 0 and w_qkv.data_ptr() % 16 == 0 and b_qkv.data_ptr() % 16 == 0
+        # out_into (fused training step, on its ctx stand-in): (buffer, floats between samples) — the block's
+        # output goes straight into a wider per-sample layout (the DNN's concatenated input)
+        into = getattr(ctx, "out_into", None) if block.use_residual else None
+        if block.whole_block_kernel and aligned and wo.data_ptr() % 16 == 0 \
+                and lib.dfm_attention_block_supported(F, D, A, H):
+            # ONE launch: projection, softmax(QK^T)V, W_out, bias, residual LayerNorm (csrc/attention_mfma.hip)
+            y = torch.empty(M, D, dtype=torch.float32, device=x.device)
+            gamma = beta = stats = None
+            if block.use_residual:
+                gamma, beta = params[8].contiguous(), params[9].contiguous()
+                stats = torch.empty(M, 2, dtype=torch.float32, device=x.device)
+                out = into[0] if into is not None else torch.empty(M, D, dtype=torch.float32, device=x.device)
+            else:
+                out = y
+            _lib.check(lib.dfm_attention_block_forward(
+                X.data_ptr(), w_qkv.data_ptr(), b_qkv.data_ptr(), wo.data_ptr(), bo.data_ptr(), _lib.ptr(gamma),
+                _lib.ptr(beta), float(block.layer_norm.eps) if block.use_residual else 0.0, B, F, D, A, H, o.data_ptr(),
+                y.data_ptr(), out.data_ptr(), _lib.ptr(stats), into[1] if into is not None else 0, _lib.stream_handle()))
+            ctx.block, ctx.dims = block, (B, F, D, A, H)
+            ctx.save_for_backward(X, None, o, y, stats, w_qkv, wo, gamma, b_qkv)
+            return out if into is not None else out.view(B, F, D)
         # projection inside the core kernel where its shape allows: the (M, 3A) Q|K|V is never materialised
-        inside = bool(lib.dfm_attention_qkv_core_supported(F, D, A, H)) and X.data_ptr() % 16 == 0
+        inside = bool(lib.dfm_attention_qkv_core_supported(F, D, A, H)) and aligned
         if inside:
             qkv = None
             _lib.check(lib.dfm_attention_qkv_core_forward(X.data_ptr(), w_qkv.data_ptr(), b_qkv.data_ptr(), B, F, D, A,
@@ -152,9 +176,6 @@ class _AttnGemmFn(torch.autograd.Function):
         stats = None
         if block.use_residual:
             gamma, beta = params[8].contiguous(), params[9].contiguous()
-            # out_into (fused training step, on its ctx stand-in): (buffer, floats between samples) — the block's
-            # output goes straight into a wider per-sample layout (the DNN's concatenated input)
-            into = getattr(ctx, "out_into", None)
             out = into[0] if into is not None else torch.empty(M, D, dtype=torch.float32, device=x.device)
             stats = torch.empty(M, 2, dtype=torch.float32, device=x.device)
             _lib.check(lib.dfm_layernorm_forward(y.data_ptr(), X.data_ptr(), M, D, gamma.data_ptr(), beta.data_ptr(),

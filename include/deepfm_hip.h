@@ -345,6 +345,18 @@ int dfm_attention_qkv_core_forward(const float* d_x, const float* d_w_qkv, const
 int dfm_attention_qkv_core_backward(const float* d_x, const float* d_w_qkv, const float* d_b_qkv,
                                     const float* d_g_o, int64_t batch, int num_fields, int embed_dim,
                                     int attention_dim, int num_heads, float* d_g_qkv, dfm_stream_t stream);
+/* The whole forward of one _AttentionBlock (attention.py:91-120) in ONE launch, num_heads == 4 (a workgroup's
+ * four waves are the four heads of a sample): projection + softmax(QK^T / sqrt(hd)) V + W_out + b_out and, when
+ * d_gamma / d_beta are given, LayerNorm(y + x).  Writes what the backward needs: d_o (batch * num_fields,
+ * attention_dim) head outputs, d_y (batch * num_fields, embed_dim) = the block's output before the residual,
+ * d_stats (rows, 2) mean / rstd; d_out as dfm_layernorm_forward (out_group_stride > 0: sample b's rows at
+ * d_out + b * out_group_stride).  _supported(): dfm_attention_qkv_core_supported and num_heads == 4. */
+int dfm_attention_block_supported(int num_fields, int embed_dim, int attention_dim, int num_heads);
+int dfm_attention_block_forward(const float* d_x, const float* d_w_qkv, const float* d_b_qkv, const float* d_w_out,
+                                const float* d_b_out, const float* d_gamma, const float* d_beta, float eps,
+                                int64_t batch, int num_fields, int embed_dim, int attention_dim, int num_heads,
+                                float* d_o, float* d_y, float* d_out, float* d_stats, int64_t out_group_stride,
+                                dfm_stream_t stream);
 size_t dfm_layernorm_workspace_bytes(int64_t rows, int dim);
 /* out_group_rows > 0: output row r is written at d_out + (r / out_group_rows) * out_group_stride +
  * (r % out_group_rows) * dim (the attention output as the first half of the DNN's concatenated input,

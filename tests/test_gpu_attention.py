@@ -90,10 +90,12 @@ def test_shapes_the_core_kernel_rejects_vs_oracle(shape):
         assert_close(npy(p.grad), grads[k], what=k, floor=1e-4 if k.endswith("W_k.bias") else 0.0)
 
 
-def _check_vs_oracle(c):
+def _check_vs_oracle(c, whole_block_kernel=True):
     from deepfm_amd.models.layers.attention import MultiHeadSelfAttention
     torch.manual_seed(c["F"])
     att = MultiHeadSelfAttention(c["D"], c["heads"], c["A"], c["layers"], c["residual"]).cuda()
+    for blk in att.layers:
+        blk.whole_block_kernel = whole_block_kernel
     with torch.no_grad():
         for p in att.parameters():
             p.uniform_(-0.4, 0.4)
@@ -112,25 +114,31 @@ def _check_vs_oracle(c):
 
 
 @pytest.mark.parametrize("shape,path", [
-    (dict(B=37, F=39, D=32, heads=4, A=64, layers=2, residual=True), "qkv_inside"),     # config 4's shape
+    (dict(B=37, F=39, D=32, heads=4, A=64, layers=2, residual=True), "whole_block"),    # config 4's shape: one launch
+    (dict(B=37, F=39, D=32, heads=4, A=64, layers=2, residual=True), "qkv_inside"),     # the same through core + GEMM + LayerNorm
     (dict(B=21, F=20, D=16, heads=2, A=32, layers=1, residual=True), "qkv_inside"),     # two token tiles
     (dict(B=13, F=48, D=64, heads=1, A=16, layers=1, residual=False), "qkv_inside"),    # full tiles, widest input
-    (dict(B=50, F=7, D=48, heads=4, A=64, layers=1, residual=True), "qkv_inside"),      # one tile, three chunks
+    (dict(B=50, F=7, D=48, heads=4, A=64, layers=1, residual=True), "whole_block"),     # one tile, three chunks, 64-lane rows
+    (dict(B=19, F=26, D=16, heads=4, A=64, layers=1, residual=False), "whole_block"),   # no residual / LayerNorm
+    (dict(B=11, F=33, D=64, heads=4, A=64, layers=1, residual=True), "whole_block"),    # widest rows
     (dict(B=29, F=39, D=40, heads=4, A=64, layers=1, residual=True), "mfma_core"),      # embed_dim % 16 != 0
     (dict(B=29, F=26, D=32, heads=8, A=64, layers=1, residual=True), "vector_core"),    # head_dim 8
 ])
 def test_every_core_variant_vs_oracle(shape, path):
-    """The three routes of the GEMM path (models/layers/attention.py ``_AttnGemmFn``): projection inside
-    the matrix-core kernel, projection GEMM + matrix-core kernel, projection GEMM + vector kernel."""
+    """The routes of the GEMM path (models/layers/attention.py ``_AttnGemmFn``): the whole forward in one
+    kernel (4 heads), projection inside the matrix-core kernel, projection GEMM + matrix-core kernel,
+    projection GEMM + vector kernel."""
     from deepfm_amd import _lib
     lib = _lib.load()
     c = shape
     inside = bool(lib.dfm_attention_qkv_core_supported(c["F"], c["D"], c["A"], c["heads"]))
     assert lib.dfm_attention_core_supported(c["F"], c["A"], c["heads"])
-    assert inside == (path == "qkv_inside")
+    assert inside == (path in ("qkv_inside", "whole_block"))
+    if path == "whole_block":
+        assert lib.dfm_attention_block_supported(c["F"], c["D"], c["A"], c["heads"])
     if path == "vector_core":
         assert c["A"] // c["heads"] != 16
-    _check_vs_oracle(c)
+    _check_vs_oracle(c, whole_block_kernel=(path == "whole_block"))
 
 
 def test_indivisible_heads_raise():
