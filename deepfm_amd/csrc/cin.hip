@@ -56,6 +56,8 @@ struct CinBwdArgs {
 };
 size_t cin_bwd_packed_wt_elems(int H, int F, int C);
 int cin_bwd_pack_wt(const float* W, int C, int H, int F, bf16_t* hi, bf16_t* lo, hipStream_t st);
+int cin_bwd_pack_wt_all(const float* const* W, const int* C, const int* H, int L, int F, bf16_t* hi, bf16_t* lo,
+                        const size_t* offs, hipStream_t st);
 int cin_mfma_dgrad(const CinBwdArgs& args, int D, bool split, hipStream_t st);
 size_t cin_mfma_wgrad_workspace_bytes(int64_t B, int C, int H, int F);
 bool cin_mfma_wgrad_has_bias(int F);
@@ -67,6 +69,8 @@ int cin_bias_grad_launch(const float* dY, int64_t B, int C, int D, float* db, fl
 bool cin_mfma_supported(int F, int D, const int* C, const int* H, int L);
 size_t cin_mfma_packed_elems(int H, int F, int C);
 int cin_mfma_pack(const float* W, int C, int H, int F, bf16_t* hi, bf16_t* lo, hipStream_t st);
+int cin_mfma_pack_all(const float* const* W, const int* C, const int* H, int L, int F, bf16_t* hi, bf16_t* lo,
+                      const size_t* offs, hipStream_t st);
 int cin_mfma_forward(const CinMfmaArgs& args, int D, bool split, hipStream_t st);
 }  // namespace dfm
 
@@ -206,6 +210,7 @@ extern "C" int dfm_cin_forward(const float* d_x0, int64_t batch, int num_fields,
     bf16_t* lop = hi + ((packed_total_elems(lo) + 63) / 64) * 64;
     size_t off = 0;
     int hid_rows = 2;
+    size_t pack_offs[kCinMaxLayers] = {};
     for (int i = 0; i < lo.L; ++i) {
       CinMfmaLayer& ly = args.layer[i];
       ly.w_hi = hi + off; ly.w_lo = lop + off; ly.bias = biases[i];
@@ -214,10 +219,11 @@ extern "C" int dfm_cin_forward(const float* d_x0, int64_t batch, int num_fields,
       ly.direct = lo.direct[i]; ly.next_off = lo.next_off[i];
       ly.next_count = i < lo.L - 1 ? lo.H[i + 1] : 0;
       ly.out_col = lo.out_col[i];
-      if (int rc = cin_mfma_pack(weights[i], lo.C[i], lo.H[i], num_fields, hi + off, lop + off, st)) return rc;
+      pack_offs[i] = off;
       off += cin_mfma_packed_elems(lo.H[i], num_fields, lo.C[i]);
       hid_rows = 2 * ly.HP > hid_rows ? 2 * ly.HP : hid_rows;
     }
+    if (int rc = cin_mfma_pack_all(weights, lo.C.data(), lo.H.data(), lo.L, num_fields, hi, lop, pack_offs, st)) return rc;
     const int fg8 = ((num_fields + 7) / 8) * 8;
     args.hid_rows = hid_rows > fg8 ? hid_rows : fg8;
     return cin_mfma_forward(args, dim, cin_mode() == 0, st);
@@ -263,6 +269,7 @@ extern "C" int dfm_cin_backward(const float* d_x0, int64_t batch, int num_fields
     args.L = lo.L; args.out_dim = lo.out_dim;
     size_t off = 0;
     int dh_rows = 4;
+    size_t pack_offs[kCinMaxLayers] = {};
     for (int i = 0; i < lo.L; ++i) {
       CinBwdLayer& ly = args.layer[i];
       ly.wt_hi = hi + off; ly.wt_lo = lop + off;
@@ -274,10 +281,11 @@ extern "C" int dfm_cin_backward(const float* d_x0, int64_t batch, int num_fields
       ly.direct = lo.direct[i]; ly.next_off = lo.next_off[i];
       ly.next_count = i < lo.L - 1 ? lo.H[i + 1] : 0;
       ly.out_col = lo.out_col[i];
-      if (int rc = cin_bwd_pack_wt(weights[i], lo.C[i], lo.H[i], num_fields, hi + off, lop + off, st)) return rc;
+      pack_offs[i] = off;
       off += ((cin_bwd_packed_wt_elems(lo.H[i], num_fields, lo.C[i]) + 63) / 64) * 64;
       dh_rows = 4 * ly.HQ > dh_rows ? 4 * ly.HQ : dh_rows;
     }
+    if (int rc = cin_bwd_pack_wt_all(weights, lo.C.data(), lo.H.data(), lo.L, num_fields, hi, lop, pack_offs, st)) return rc;
     const int fg8 = ((num_fields + 7) / 8) * 8;
     args.dh_rows = dh_rows > fg8 ? dh_rows : fg8;
     if (int rc = cin_mfma_dgrad(args, dim, split, st)) return rc;

@@ -55,10 +55,29 @@ struct CinMfmaArgs {
 // ---- weight packing -----------------------------------------------------------------
 // W (C, H*F) fp32 -> hi/lo bf16 fragments [ks = hp*FG+fg][mb][lane = hf*32+r][j]:
 //   value = W[c = mb*32+r][h = 2*hp+hf][f = fg*8+j]  (0 outside C/H/F)
-__global__ __launch_bounds__(256) void cin_pack_weights(const float* __restrict__ W, int C, int H, int F,
-                                                        int HP, int FG, int MB,
-                                                        __bf16* __restrict__ hi, __bf16* __restrict__ lo) {
-  const int64_t t = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+// Every layer of the stack in ONE launch (the weights change every training step: three launches of ~5 us
+// each were 1 % of an xDeepFM step): workgroup -> layer by a prefix table of workgroup counts.
+struct CinPackJob {
+  const float* W;
+  __bf16* hi;
+  __bf16* lo;
+  int C, H, p0, p1;          // forward: p0 = HP, p1 = MB; backward (W^T fragments): p0 = HQ, p1 = KS
+};
+struct CinPackJobs {
+  CinPackJob job[kCinMaxLayers];
+  int first_block[kCinMaxLayers + 1];
+  int count, F, FG;
+};
+__device__ __forceinline__ int cin_pack_find(const CinPackJobs& jobs, int blk) {
+  int i = 0;
+  while (i + 1 < jobs.count && blk >= jobs.first_block[i + 1]) ++i;
+  return i;
+}
+
+__device__ __forceinline__ void cin_pack_weights_body(int blk, const float* __restrict__ W, int C, int H, int F,
+                                                      int HP, int FG, int MB,
+                                                      __bf16* __restrict__ hi, __bf16* __restrict__ lo) {
+  const int64_t t = static_cast<int64_t>(blk) * 256 + threadIdx.x;
   const int64_t total = static_cast<int64_t>(HP) * FG * MB * 64 * 8;
   if (t >= total) return;
   const int j = t & 7;
@@ -73,6 +92,16 @@ __global__ __launch_bounds__(256) void cin_pack_weights(const float* __restrict_
   const __bf16 vh = static_cast<__bf16>(v);
   hi[t] = vh;
   lo[t] = static_cast<__bf16>(v - static_cast<float>(vh));
+}
+__global__ __launch_bounds__(256) void cin_pack_weights(const float* __restrict__ W, int C, int H, int F,
+                                                        int HP, int FG, int MB,
+                                                        __bf16* __restrict__ hi, __bf16* __restrict__ lo) {
+  cin_pack_weights_body(blockIdx.x, W, C, H, F, HP, FG, MB, hi, lo);
+}
+__global__ __launch_bounds__(256) void cin_pack_weights_all(CinPackJobs jobs) {
+  const int i = cin_pack_find(jobs, blockIdx.x);
+  const CinPackJob& j = jobs.job[i];
+  cin_pack_weights_body(blockIdx.x - jobs.first_block[i], j.W, j.C, j.H, jobs.F, j.p0, jobs.FG, j.p1, j.hi, j.lo);
 }
 
 // ---- the fused forward ----------------------------------------------------------------
@@ -313,6 +342,25 @@ int cin_mfma_pack(const float* W, int C, int H, int F, __bf16* hi, __bf16* lo, h
   const size_t total = cin_mfma_packed_elems(H, F, C);
   hipLaunchKernelGGL(cin_pack_weights, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, st, W, C,
                      H, F, HP, FG, MB, hi, lo);
+  DFM_LAUNCH_CHECK();
+  return DFM_OK;
+}
+
+// all layers' forward fragments: hi / lo + offs[i] (elements) receive layer i
+int cin_mfma_pack_all(const float* const* W, const int* C, const int* H, int L, int F, __bf16* hi, __bf16* lo,
+                      const size_t* offs, hipStream_t st) {
+  DFM_REQUIRE(L > 0 && L <= kCinMaxLayers, "1..%d layers", kCinMaxLayers);
+  CinPackJobs jobs;
+  memset(&jobs, 0, sizeof(jobs));
+  jobs.count = L; jobs.F = F; jobs.FG = (F + 7) / 8;
+  int blocks = 0;
+  for (int i = 0; i < L; ++i) {
+    jobs.job[i] = CinPackJob{W[i], hi + offs[i], lo + offs[i], C[i], H[i], (H[i] + 1) / 2, (C[i] + 31) / 32};
+    jobs.first_block[i] = blocks;
+    blocks += static_cast<int>((cin_mfma_packed_elems(H[i], F, C[i]) + 255) / 256);
+  }
+  jobs.first_block[L] = blocks;
+  hipLaunchKernelGGL(cin_pack_weights_all, dim3(blocks), dim3(256), 0, st, jobs);
   DFM_LAUNCH_CHECK();
   return DFM_OK;
 }

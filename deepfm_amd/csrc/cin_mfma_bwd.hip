@@ -54,10 +54,9 @@ struct CinBwdArgs {
 
 // W (C, H*F) fp32 -> W^T fragments [blk = hq*FG+fg][ks][lane = hf*32 + r][j]:
 //   value = W[c = ks*16 + 8*hf + j][h = 4*hq + (r>>3)][f = fg*8 + (r&7)]
-__global__ __launch_bounds__(256) void cin_pack_wt(const float* __restrict__ W, int C, int H, int F, int HQ,
-                                                   int FG, int KS, __bf16* __restrict__ hi,
-                                                   __bf16* __restrict__ lo) {
-  const int64_t t = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+__device__ __forceinline__ void cin_pack_wt_body(int wg, const float* __restrict__ W, int C, int H, int F, int HQ,
+                                                 int FG, int KS, __bf16* __restrict__ hi, __bf16* __restrict__ lo) {
+  const int64_t t = static_cast<int64_t>(wg) * 256 + threadIdx.x;
   const int64_t total = static_cast<int64_t>(HQ) * FG * KS * 64 * 8;
   if (t >= total) return;
   const int j = t & 7;
@@ -73,6 +72,26 @@ __global__ __launch_bounds__(256) void cin_pack_wt(const float* __restrict__ W, 
   const __bf16 vh = static_cast<__bf16>(v);
   hi[t] = vh;
   lo[t] = static_cast<__bf16>(v - static_cast<float>(vh));
+}
+__global__ __launch_bounds__(256) void cin_pack_wt(const float* __restrict__ W, int C, int H, int F, int HQ,
+                                                   int FG, int KS, __bf16* __restrict__ hi,
+                                                   __bf16* __restrict__ lo) {
+  cin_pack_wt_body(blockIdx.x, W, C, H, F, HQ, FG, KS, hi, lo);
+}
+// every layer in one launch (see cin_pack_weights_all in cin_mfma.hip)
+struct CinPackWtJobs {
+  const float* W[kBwdMaxLayers];
+  __bf16* hi[kBwdMaxLayers];
+  __bf16* lo[kBwdMaxLayers];
+  int C[kBwdMaxLayers], H[kBwdMaxLayers], HQ[kBwdMaxLayers], KS[kBwdMaxLayers];
+  int first_block[kBwdMaxLayers + 1];
+  int count, F, FG;
+};
+__global__ __launch_bounds__(256) void cin_pack_wt_all(CinPackWtJobs jobs) {
+  int i = 0;
+  while (i + 1 < jobs.count && static_cast<int>(blockIdx.x) >= jobs.first_block[i + 1]) ++i;
+  cin_pack_wt_body(blockIdx.x - jobs.first_block[i], jobs.W[i], jobs.C[i], jobs.H[i], jobs.F, jobs.HQ[i], jobs.FG,
+                   jobs.KS[i], jobs.hi[i], jobs.lo[i]);
 }
 
 template <int D, int FG, bool SPLIT>
@@ -535,6 +554,25 @@ int cin_bwd_pack_wt(const float* W, int C, int H, int F, __bf16* hi, __bf16* lo,
   const size_t total = cin_bwd_packed_wt_elems(H, F, C);
   hipLaunchKernelGGL(cin_pack_wt, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, st, W, C, H, F,
                      HQ, FG, KS, hi, lo);
+  DFM_LAUNCH_CHECK();
+  return DFM_OK;
+}
+
+int cin_bwd_pack_wt_all(const float* const* W, const int* C, const int* H, int L, int F, __bf16* hi, __bf16* lo,
+                        const size_t* offs, hipStream_t st) {
+  DFM_REQUIRE(L > 0 && L <= kBwdMaxLayers, "1..%d layers", kBwdMaxLayers);
+  CinPackWtJobs jobs;
+  memset(&jobs, 0, sizeof(jobs));
+  jobs.count = L; jobs.F = F; jobs.FG = (F + 7) / 8;
+  int blocks = 0;
+  for (int i = 0; i < L; ++i) {
+    jobs.W[i] = W[i]; jobs.hi[i] = hi + offs[i]; jobs.lo[i] = lo + offs[i];
+    jobs.C[i] = C[i]; jobs.H[i] = H[i]; jobs.HQ[i] = (H[i] + 3) / 4; jobs.KS[i] = (C[i] + 15) / 16;
+    jobs.first_block[i] = blocks;
+    blocks += static_cast<int>((cin_bwd_packed_wt_elems(H[i], F, C[i]) + 255) / 256);
+  }
+  jobs.first_block[L] = blocks;
+  hipLaunchKernelGGL(cin_pack_wt_all, dim3(blocks), dim3(256), 0, st, jobs);
   DFM_LAUNCH_CHECK();
   return DFM_OK;
 }
