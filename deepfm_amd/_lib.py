@@ -63,7 +63,7 @@ class FmBwd(C.Structure):
 class SlabRef(C.Structure):
     """struct dfm_slab_ref"""
     _fields_ = [("workspace", C.c_void_p), ("g_w", C.c_void_p), ("batch", C.c_int64), ("out_features", C.c_int32),
-                ("in_features", C.c_int32)]
+                ("in_features", C.c_int32), ("splits", C.c_int32), ("reserved", C.c_int32)]
 
 
 class HeadTail(C.Structure):
@@ -143,7 +143,7 @@ SIGNATURES = {
     "dfm_linear_backward_finish": (_I, [C.POINTER(SlabRef), _I, _P]),
     "dfm_linear_backward_splits": (_I, [_L, _I, _I]),
     "dfm_step_embedding_backward": (_I, [_P, _I, C.POINTER(_P), C.POINTER(FieldGrad), C.POINTER(C.c_int32), _I, _I, _I,
-                                         _L, _P, _P, _P, _P, _P, _P, _P, _P]),
+                                         _L, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _L, _P]),
     "dfm_step_prepare_num_partials": (_L, [_I, _I, _I, _L]),
     "dfm_step_match_bytes": (_SZ, [_I, _I]),
     "dfm_step_prepare": (_I, [C.POINTER(Table), _I, _I, _I, _P, _P, _P, _P, _P, _F, _F, _P, _P, _L, _L,

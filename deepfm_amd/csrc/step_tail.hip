@@ -74,10 +74,11 @@ __global__ __launch_bounds__(kTailThreads) void step_embedding_backward_kernel(
     int dense_blocks, const int32_t* __restrict__ dense_list, PtrTable in, GradTable gt, int64_t B, int F, int D,
     const float* __restrict__ g_first, const float* __restrict__ g_field, FieldMap fmap, int S, int lists,
     const int32_t* __restrict__ sorted_pos, const int32_t* __restrict__ seg_start,
-    const int32_t* __restrict__ num_uniq, float* __restrict__ row_g2, float* __restrict__ row_g1) {
+    const int32_t* __restrict__ num_uniq, float* __restrict__ row_g2, float* __restrict__ row_g1,
+    DensePartials dp) {
   const int blk = blockIdx.x;
   if (blk < dense_blocks)
-    dense_fields_uniform_body(blk, dense_list, in, gt, B, F, D, g_first, g_field);
+    dense_fields_uniform_body(blk, dense_list, in, gt, B, F, D, g_first, g_field, dp);
   else
     rowgrad_body(blk - dense_blocks, fmap, S, F, D, lists, g_first, g_field, sorted_pos, seg_start, num_uniq, row_g2,
                  row_g1);
@@ -150,7 +151,8 @@ extern "C" int dfm_step_embedding_backward(const int32_t* d_dense_list, int num_
                                            const float* d_g_first, const float* d_g_field,
                                            const int32_t* d_sorted_pos, const int32_t* d_seg_start,
                                            const int32_t* d_num_uniq, float* d_row_g2, float* d_row_g1,
-                                           dfm_stream_t stream) {
+                                           float* d_dense_partials, int dense_parts, const float* d_dense_grad_base,
+                                           int64_t dense_grad_elems, dfm_stream_t stream) {
   DFM_REQUIRE(d_g_first && d_g_field, "null argument");
   DFM_REQUIRE(num_dense >= 0 && num_sparse >= 0 && num_dense + num_sparse > 0 && num_fields <= DFM_MAX_FIELDS &&
                   num_dense + num_sparse <= num_fields, "bad field counts");
@@ -182,11 +184,28 @@ extern "C" int dfm_step_embedding_backward(const int32_t* d_dense_list, int num_
     lists = static_cast<int>((batch + CH - 1) / CH) * num_sparse;
     rg_blocks = (static_cast<int64_t>(lists) * CH * (dim / 4) + kTailThreads - 1) / kTailThreads;
   }
-  const int dense_blocks = num_dense * (dim / 4 + 1);
+  int dense_blocks = num_dense * (dim / 4 + 1);
+  DensePartials dp = {nullptr, nullptr, 0, 0, 0};
+  if (d_dense_partials && num_dense > 0) {
+    DFM_REQUIRE(dense_parts >= 1 && dense_parts <= 64 && d_dense_grad_base && dense_grad_elems > 0, "bad dense slices");
+    for (int i = 0; i < num_fields; ++i) {
+      const dfm_field_grad& g = gt.g[i];
+      if (!g.w2) continue;
+      DFM_REQUIRE(g.w2 >= d_dense_grad_base && g.w2 + dim <= d_dense_grad_base + dense_grad_elems &&
+                      g.b2 >= d_dense_grad_base && g.b2 + dim <= d_dense_grad_base + dense_grad_elems &&
+                      g.w1 >= d_dense_grad_base && g.w1 < d_dense_grad_base + dense_grad_elems &&
+                      g.b1 >= d_dense_grad_base && g.b1 < d_dense_grad_base + dense_grad_elems,
+                  "field %d: a DENSE-field gradient buffer lies outside the sliced range", i);
+    }
+    dp.out = d_dense_partials; dp.base = d_dense_grad_base; dp.elems = dense_grad_elems;
+    dp.rows = (batch + dense_parts - 1) / dense_parts;
+    dp.per_slice = dense_blocks;
+    dense_blocks *= dense_parts;
+  }
   hipLaunchKernelGGL(step_embedding_backward_kernel, dim3(static_cast<unsigned>(dense_blocks + rg_blocks)),
                      dim3(kTailThreads), 0, as_stream(stream), dense_blocks, d_dense_list, in, gt, batch, num_fields, dim,
                      d_g_first, d_g_field, fm, num_sparse, lists, d_sorted_pos, d_seg_start, d_num_uniq, d_row_g2,
-                     d_row_g1);
+                     d_row_g1, dp);
   DFM_LAUNCH_CHECK();
   return DFM_OK;
 }

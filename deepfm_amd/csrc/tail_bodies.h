@@ -86,8 +86,24 @@ __device__ __forceinline__ void block_sum2(float& a, float& b2) {
 
 // DENSE fields of a uniform plan: workgroup (field i, column group jq) sums 4 columns of the field's
 // gradient over the batch with 16-byte loads; jq == D/4 handles the first-order Linear(1,1).
-__device__ __forceinline__ void dense_fields_uniform_body(int blk, const int32_t* __restrict__ dense_list, PtrTable in, GradTable gt, int64_t B, int F, int D, const float* __restrict__ g_first, const float* __restrict__ g_field) {
+// Batch slices (DensePartials): slice p = blk / (fields * groups) covers rows [p * rows, (p + 1) * rows) and
+// STORES its sums at out[p * elems + (address of the gradient element - base)] instead of adding them in place.
+struct DensePartials {
+  float* out;            // nullptr: one slice over the whole batch, added into the gradient buffers
+  const float* base;
+  int64_t elems, rows;
+  int per_slice;         // workgroups per slice = fields * groups
+};
+__device__ __forceinline__ void dense_fields_uniform_body(int blk, const int32_t* __restrict__ dense_list, PtrTable in, GradTable gt, int64_t B, int F, int D, const float* __restrict__ g_first, const float* __restrict__ g_field, DensePartials dp = DensePartials{nullptr, nullptr, 0, 0, 0}) {
   const int groups = D / 4 + 1;      // column groups per field (+ the first-order Linear)
+  int64_t b_lo = 0, b_hi = B;
+  int slice = 0;
+  if (dp.out) {
+    slice = blk / dp.per_slice;
+    blk -= slice * dp.per_slice;
+    b_lo = slice * dp.rows;
+    b_hi = b_lo + dp.rows < B ? b_lo + dp.rows : B;
+  }
   const int f = dense_list[blk / groups];
   const int jq = blk % groups;
   const float* x = static_cast<const float*>(in.p[f]);
@@ -95,7 +111,7 @@ __device__ __forceinline__ void dense_fields_uniform_body(int blk, const int32_t
   if (jq * 4 < D) {
     const float* g = g_field + static_cast<int64_t>(f) * D + jq * 4;
 #pragma unroll 8
-    for (int64_t b = threadIdx.x; b < B; b += 256) {
+    for (int64_t b = b_lo + threadIdx.x; b < b_hi; b += 256) {
       const float4 v = ld4(g + b * F * D);
       const float xb = x[b];
       sw[0] = fmaf(xb, v.x, sw[0]); sw[1] = fmaf(xb, v.y, sw[1]);
@@ -103,7 +119,7 @@ __device__ __forceinline__ void dense_fields_uniform_body(int blk, const int32_t
       sb[0] += v.x; sb[1] += v.y; sb[2] += v.z; sb[3] += v.w;
     }
   } else {
-    for (int64_t b = threadIdx.x; b < B; b += 256) {
+    for (int64_t b = b_lo + threadIdx.x; b < b_hi; b += 256) {
       const float v = g_first[b];
       sw[0] = fmaf(x[b], v, sw[0]);
       sb[0] += v;
@@ -113,7 +129,15 @@ __device__ __forceinline__ void dense_fields_uniform_body(int blk, const int32_t
   for (int u = 0; u < 4; ++u) block_sum2(sw[u], sb[u]);
   if (threadIdx.x == 0) {
     const dfm_field_grad g = gt.g[f];
-    if (jq * 4 < D) {
+    if (dp.out) {
+      float* o = dp.out + slice * dp.elems;
+      if (jq * 4 < D) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { o[(g.w2 + jq * 4 + u) - dp.base] = sw[u]; o[(g.b2 + jq * 4 + u) - dp.base] = sb[u]; }
+      } else {
+        o[g.w1 - dp.base] = sw[0]; o[g.b1 - dp.base] = sb[0];
+      }
+    } else if (jq * 4 < D) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) { g.w2[jq * 4 + u] += sw[u]; g.b2[jq * 4 + u] += sb[u]; }
     } else {
@@ -371,7 +395,7 @@ inline int fill_slab_table(const dfm_slab_ref* slabs, int num_slabs, const float
     st->slabs[i] = static_cast<const float*>(h.workspace);
     st->g[i] = h.g_w;
     st->elems[i] = elems;
-    st->splits[i] = dfm_linear_backward_splits(h.batch, h.out_features, h.in_features);
+    st->splits[i] = h.splits > 0 ? h.splits : dfm_linear_backward_splits(h.batch, h.out_features, h.in_features);
   }
   st->count = num_slabs;
   return DFM_OK;

@@ -759,6 +759,7 @@ extern "C" int dfm_linear_backward_finish(const dfm_slab_ref* refs, int count, d
     DFM_REQUIRE(elems % 4 == 0 && aligned16(h.g_w) && aligned16(h.workspace), "d weight must be float4-addressable");
     int splits, kps;
     dw_split_plan(h.out_features, h.in_features, static_cast<int>(h.batch), &splits, &kps);
+    if (h.splits > 0) splits = h.splits;
     r.slabs[i] = static_cast<const float*>(h.workspace);
     r.g[i] = h.g_w;
     r.elems4[i] = static_cast<int>(elems / 4);

@@ -354,11 +354,16 @@ class FeatureEmbedding(nn.Module):
         return fo, fe, flat, fm_out
 
     def backward_rowsparse(self, inputs: List[torch.Tensor], g_fo: torch.Tensor, g_fe: torch.Tensor,
-                           dense_grads: Dict[int, torch.Tensor], sparse: bool = True) -> None:
+                           dense_grads: Dict[int, torch.Tensor], sparse: bool = True,
+                           dense_slices: Optional[Tuple[torch.Tensor, int, torch.Tensor]] = None) -> None:
         """Row-sparse backward: DENSE-field Linear gradients are ADDED into ``dense_grads``
         ({id(param): buffer}); one gradient row per distinct id goes to ``self.rowsparse``
         (whose row plan must have been built from the same ``inputs``).  ``sparse=False``: the
-        DENSE fields only (field-sharded tables: the SPARSE fields' gradients travel to their owners)."""
+        DENSE fields only (field-sharded tables: the SPARSE fields' gradients travel to their owners).
+        ``dense_slices = (partials (parts * n), parts, flat)``: the DENSE-field gradients are computed over
+        ``parts`` batch slices and STORED into ``partials`` at each element's offset inside ``flat`` (the flat
+        gradient buffer whose first n elements hold every ``dense_grads`` view); whoever owns ``flat`` adds the
+        slices (training/fused_step.py registers them as a slab reference)."""
         B, F, D = g_fe.shape
         if B == 0:
             return
@@ -377,7 +382,10 @@ class FeatureEmbedding(nn.Module):
                 self._dense_list.data_ptr(), nd, self._ptr_array(inputs), self._grad_struct(dense_grads), fmap, S, F, D,
                 B, g_fo.data_ptr(), g_fe.data_ptr(), rs.sorted_pos.data_ptr() if S else None,
                 rs.seg_start.data_ptr() if S else None, rs.num_uniq.data_ptr() if S else None,
-                rs.row_g2.data_ptr() if S else None, rs.row_g1.data_ptr() if S else None, _lib.stream_handle()))
+                rs.row_g2.data_ptr() if S else None, rs.row_g1.data_ptr() if S else None,
+                dense_slices[0].data_ptr() if dense_slices else None, dense_slices[1] if dense_slices else 0,
+                dense_slices[2].data_ptr() if dense_slices else None,
+                dense_slices[0].numel() // dense_slices[1] if dense_slices else 0, _lib.stream_handle()))
             if S:
                 rs.has_grad = True
             return

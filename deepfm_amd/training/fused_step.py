@@ -63,6 +63,11 @@ class _FusedTowerStep(RowSparseTrainStep):
     def __init__(self, model, optimizer: RowSparseAdam, batch_size: int, use_graph: bool = True) -> None:
         super().__init__(model, optimizer, batch_size, use_graph)
         self._slab_refs = None
+        # DENSE-field Linear gradients over 4 batch slices, added with the tower's d-weight slabs: as one
+        # slice the 65 workgroups of that part walk the whole batch (a ~11 us latency chain)
+        self._dense_parts = 4 if (optimizer.n_l2 > 0 and self.n_dense > 0) else 0
+        self._dense_partial = (torch.zeros(self._dense_parts * optimizer.n_l2, dtype=torch.float32,
+                                           device=optimizer.device) if self._dense_parts else None)
         if not self.eligible(model):
             raise ValueError(f"{type(self).__name__}: model/configuration not eligible (use RowSparseTrainStep)")
         lib = _lib.load()
@@ -196,20 +201,31 @@ class _FusedTowerStep(RowSparseTrainStep):
                     None, C.byref(fmb) if fmb is not None else None, 3, self.ws_lin[i].data_ptr(), st))
         self._finish_embedding_grad()
         # the batch-split d weight products of all layers -> the flat gradient buffer, one launch
-        refs = (_lib.SlabRef * self.L)()
+        n_refs = self.L + (1 if self._dense_parts else 0)
+        refs = (_lib.SlabRef * n_refs)()
         for i in range(self.L):
             r, lin = refs[i], self.lin[i]
             r.workspace, r.g_w = self.ws_lin[i].data_ptr(), lin.weight.grad.data_ptr()
             r.batch, r.out_features, r.in_features = B, lin.out_features, lin.in_features
+        if self._dense_parts:            # the sliced DENSE-field gradients: the flat buffer's first n_l2 floats
+            r = refs[self.L]
+            r.workspace, r.g_w = self._dense_partial.data_ptr(), self.opt.flat_grad.data_ptr()
+            r.batch, r.out_features, r.in_features, r.splits = 1, 1, self.opt.n_l2, self._dense_parts
         if self.slabs_travel:
-            self._slab_refs = (refs, self.L)         # summed by the gradient pack kernel (field-sharded tables)
+            self._slab_refs = (refs, n_refs)         # summed by the gradient pack kernel (field-sharded tables)
         elif not self.opt.split:
-            self.opt.slab_refs = (refs, self.L)      # summed by the optimizer's prepare launch
-        else:
-            _lib.check(lib.dfm_linear_backward_finish(refs, self.L, st))    # must precede the all-reduce
+            self.opt.slab_refs = (refs, n_refs)      # summed by the optimizer's prepare launch
         if not inline:
             cur.wait_stream(self.side)
         self._embedding_backward(self.g_logits, self.g_fe)
+        if not self.slabs_travel and self.opt.split:
+            # replicated tables, exchange outside the graph: every slab must be in the flat gradient first
+            _lib.check(lib.dfm_linear_backward_finish(refs, n_refs, st))
+
+    def _dense_slices(self):
+        if not self._dense_parts:
+            return None
+        return self._dense_partial, self._dense_parts, self.opt.flat_grad
 
 
 class FusedDeepFMStep(_FusedTowerStep):

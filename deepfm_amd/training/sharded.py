@@ -312,7 +312,8 @@ class ShardedStepMixin:
         lib, st, sh = _lib.load(), _lib.stream_handle(), self.shard
         B, F, D = g_fe.shape
         # DENSE-field Linear gradients -> the flat dense gradient (complete after this launch)
-        self.emb.backward_rowsparse(self.local_inputs, g_fo, g_fe, self.dense_grads, sparse=False)
+        self.emb.backward_rowsparse(self.local_inputs, g_fo, g_fe, self.dense_grads, sparse=False,
+                                    dense_slices=self._dense_slices())
         flat = self.opt.flat_grad
         refs, n_refs = self._slab_refs if self._slab_refs is not None else (None, 0)
         _lib.check(lib.dfm_shard_pack(self._first, self._count, sh.world, self._fmap, len(self.emb._sparse_pos), F, D, B,

@@ -177,7 +177,11 @@ class RowSparseTrainStep:
     def _embedding_backward(self, g_fo: torch.Tensor, g_fe: torch.Tensor) -> None:
         """d first_order (B, 1), d field_embeddings (B, F, D) -> DENSE-field Linear gradients and one
         gradient row per distinct id."""
-        self.emb.backward_rowsparse(self.inputs, g_fo, g_fe, self.dense_grads)
+        self.emb.backward_rowsparse(self.inputs, g_fo, g_fe, self.dense_grads, dense_slices=self._dense_slices())
+
+    def _dense_slices(self):
+        """Batch-sliced DENSE-field gradients (see FeatureEmbedding.backward_rowsparse), or None."""
+        return None
 
     def _body_a(self) -> None:
         self.opt.zero_grad()

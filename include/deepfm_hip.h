@@ -499,6 +499,10 @@ typedef struct dfm_slab_ref {
   int64_t batch;
   int32_t out_features;
   int32_t in_features;
+  int32_t splits;          /* 0: the batch split dfm_linear_backward chose for (batch, out, in); > 0: that many
+                            * slabs of out * in floats from any producer (dfm_step_embedding_backward's
+                            * batch-split DENSE-field gradients) */
+  int32_t reserved;
 } dfm_slab_ref;
 int dfm_linear_backward_finish(const dfm_slab_ref* refs, int count, dfm_stream_t stream);
 /* Number of batch splits (slabs) dfm_linear_backward leaves in its workspace for this shape. */
@@ -519,7 +523,14 @@ int dfm_step_embedding_backward(const int32_t* d_dense_list, int num_dense, cons
                                 const float* d_g_first, const float* d_g_field,
                                 const int32_t* d_sorted_pos, const int32_t* d_seg_start,
                                 const int32_t* d_num_uniq, float* d_row_g2, float* d_row_g1,
-                                dfm_stream_t stream);
+                                float* d_dense_partials, int dense_parts, const float* d_dense_grad_base,
+                                int64_t dense_grad_elems, dfm_stream_t stream);
+/* d_dense_partials (optional): instead of adding into the dense_grads buffers, the DENSE-field gradients are
+ * computed over dense_parts batch slices (dense_parts x as many workgroups: the single-slice form is a
+ * latency chain over the whole batch on 65 workgroups) and slice p's values are STORED at
+ * d_dense_partials[p * dense_grad_elems + (address of the element - d_dense_grad_base)]; every dense_grads
+ * buffer must lie inside [d_dense_grad_base, + dense_grad_elems).  The slices are added by whoever consumes
+ * the dfm_slab_ref {d_dense_partials, d_dense_grad_base, 1, 1, dense_grad_elems, dense_parts}. */
 /* dfm_rowadam_merge + dfm_dense_grad_prepare in one launch; `slabs` (optional) are dfm_linear_backward
  * workspaces whose batch-split products are added into their d_g views first (replaces
  * dfm_linear_backward_finish).  d_partials: dfm_step_prepare_num_partials floats, to be summed by
