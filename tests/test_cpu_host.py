@@ -107,3 +107,54 @@ def test_cpu_tensors_fail_loudly_no_fallback():
         DNN(4, [])
     with pytest.raises(ValueError):
         DNN(4, [2], activation="nope")
+
+
+# ---- data-parallel host logic (training/sharded.py, training/exchange.py) ------------------------
+@pytest.mark.parametrize("num_sparse,world", [(26, 1), (26, 2), (26, 3), (26, 8), (26, 26), (7, 4)])
+def test_field_shards_cover_every_field_once(num_sparse, world):
+    from deepfm_amd.training.sharded import FieldShards
+    sh = FieldShards(num_sparse, world)
+    assert sum(sh.count) == num_sparse and max(sh.count) - min(sh.count) <= 1
+    assert sh.first == [sum(sh.count[:r]) for r in range(world)]
+    owners = [sh.owner(s) for s in range(num_sparse)]
+    assert [r * 1000 + j for r, j in owners] == sorted(r * 1000 + j for r, j in owners)     # contiguous, in rank order
+    assert sorted({r for r, _ in owners}) == list(range(world))
+
+
+def test_field_shards_reject_more_ranks_than_fields():
+    from deepfm_amd.training.sharded import FieldShards
+    with pytest.raises(ValueError):
+        FieldShards(3, 4)
+    with pytest.raises(ValueError):
+        FieldShards(3, 0)
+
+
+def test_stacked_view_only_inside_one_storage():
+    """W_q | W_k | W_v as one stacked weight: a view when the three lie back to back in ONE storage (the
+    optimizer's flat buffer), None otherwise — even for allocations that happen to be neighbours."""
+    import torch
+    from deepfm_amd.models.layers.attention import stacked_view
+    flat = torch.arange(3 * 8 * 4, dtype=torch.float32)
+    parts = [flat[i * 32:(i + 1) * 32].view(8, 4) for i in range(3)]
+    v = stacked_view(parts)
+    assert v is not None and v.shape == (24, 4) and v.data_ptr() == flat.data_ptr()
+    assert torch.equal(v, flat.view(24, 4))
+    assert stacked_view([parts[0], parts[2]]) is None                       # a gap
+    assert stacked_view([parts[0].clone(), parts[1].clone()]) is None       # separate storages
+    biases = [flat[i * 8:(i + 1) * 8] for i in range(3)]
+    assert stacked_view(biases).shape == (24,)
+    assert stacked_view([parts[0], parts[1].t().contiguous().t()]) is None  # not contiguous
+
+
+def test_exchange_without_a_process_group_is_a_copy():
+    import torch
+    from deepfm_amd.training import exchange
+    src = torch.arange(10, dtype=torch.float32)
+    dst = torch.zeros(10)
+    exchange.all_to_all(dst, src, [10], [10])
+    assert torch.equal(dst, src)
+    out = torch.zeros(4)
+    exchange.all_gather_flat(out, torch.tensor([1.0, 2.0, 3.0, 4.0]))
+    assert out.tolist() == [1.0, 2.0, 3.0, 4.0]
+    with pytest.raises(RuntimeError):
+        exchange.all_to_all(dst, src, [5, 5], [5, 5])                       # several peers need a process group
