@@ -147,7 +147,9 @@ class _FusedTowerStep(RowSparseTrainStep):
         # The row plan (needs only the ids) runs IN LINE.  On a side stream it overlapped the forward
         # "for free" — and cost more than its own 27 us: the concurrent sort slowed the widest GEMM by
         # 7 us, and the fork/join put the graph on two hardware queues with ~10 us per cross-queue edge
-        # (measured 0.253 ms in line vs 0.255 overlapped when the sort still took 38 us).
+        # (measured 0.253 ms in line vs 0.255 overlapped when the sort still took 38 us).  Round 2 tried ONE
+        # fork / join per four-step graph with all four plans built ahead on the side branch: 0.227 ms/step
+        # against 0.217 in line — a graph that spans two queues is slower as a whole.
         inline = not self.rowplan_side_stream
         if inline:
             self._build_rowplan()
