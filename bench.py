@@ -54,6 +54,9 @@ def parse():
                     help="N > 1 ranks: embedding tables sharded by field over the ranks (rows and gradients of the batch "
                          "travel by all-to-all, every row update is local) or replicated on every rank (row lists "
                          "all-gathered, every replica applies every rank's row updates)")
+    ap.add_argument("--ids", choices=("uniform", "zipf"), default="uniform",
+                    help="id distribution of the synthetic batches: uniform over [1, V) (the headline: worst case for "
+                         "caches) or Zipf(1.05) clipped to [1, V) (SURVEY.md 8d's secondary, Criteo-like skew)")
     ap.add_argument("--unpacked", action="store_true", help="keep the tables as separate contiguous tensors")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-extra-configs", action="store_true",
@@ -81,10 +84,16 @@ def gather_bytes_per_sample(n_sparse: int, n_dense: int, dim: int) -> int:
     return reads + writes
 
 
-def make_pool(n_batches, n_sparse, n_dense, B, V, seed, device):
+def make_pool(n_batches, n_sparse, n_dense, B, V, seed, device, dist_name="uniform"):
     g = torch.Generator(device=device)
     g.manual_seed(seed)
-    ids = torch.randint(1, V, (n_batches, n_sparse, B), generator=g, device=device, dtype=torch.int64)
+    if dist_name == "zipf":
+        # SURVEY.md section 8(d), secondary distribution: Zipf(s = 1.05) clipped to [1, V) — Criteo-like skew,
+        # many duplicates inside a batch (the row plan's skewed-bucket path, cache-friendly gathers)
+        z = np.random.default_rng(seed).zipf(1.05, size=(n_batches, n_sparse, B))
+        ids = torch.from_numpy(np.clip(z, 1, V - 1).astype(np.int64)).to(device)
+    else:
+        ids = torch.randint(1, V, (n_batches, n_sparse, B), generator=g, device=device, dtype=torch.int64)
     pad = torch.rand((n_batches, n_sparse, B), generator=g, device=device) < 0.01
     ids.masked_fill_(pad, 0)                                       # 1 % padding ids
     dense = torch.rand((n_batches, n_dense, B), generator=g, device=device)
@@ -302,7 +311,7 @@ def main():
     model, opt, step, fields, cfg, hp, fused = build_step("deepfm", V, D, B, dev, args)
 
     total = args.steps + args.warmup
-    ids, dense, labels = make_pool(total, n_sparse, n_dense, B, V, 1 + rank, dev)
+    ids, dense, labels = make_pool(total, n_sparse, n_dense, B, V, 1 + rank, dev, args.ids)
     records = step.pack_batches(ids, dense, labels)      # one record per batch, resident in HBM
     step.load_packed(records[0])
     # several steps per graph need the whole step inside ONE graph: one rank without the split exchange path
@@ -412,6 +421,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
+                "ids": args.ids,
                 "workload": f"DeepFM synthetic Criteo-shape: {n_sparse} sparse x {V} vocab, {n_dense} dense, "
                             f"embed_dim {D}, batch {B}/GPU; step = fwd + BCE + L2 + bwd + clip + "
                             "row-wise Adam on touched rows (lazy L2) + dense Adam",

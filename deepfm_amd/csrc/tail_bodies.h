@@ -154,39 +154,135 @@ struct SampleSegments {
   int64_t stride;
 };
 
-// One row gradient per distinct id: sum of its contributions in sample order.
+// One row gradient per distinct id.  Runs of up to kLongRun contributions are summed in sample order by the
+// row's own D/4 lanes (bit-exact against a sequential reduction).  Longer runs — a hot id under a skewed
+// distribution: Zipf(1.05) clipped to the vocabulary puts ~2 000 of a batch's 4 096 ids of a field on ONE
+// row, and one lane group walking them took 0.9 ms — are summed by the whole workgroup: 256 / (D/4) lane
+// groups take every (256 / (D/4))-th contribution each, the partial sums are added in group order (fixed
+// tree: still bitwise reproducible, 64 x shorter chain at D = 16).
+constexpr int kLongRun = 64;
+constexpr int kRowgradLds = 2048;       // floats: groups x (D + 4) = 1024 + 1024 / (D/4) <= 2048
+
+__device__ __forceinline__ void rowgrad_load(const float* __restrict__ g_field, const float* __restrict__ g_first,
+                                             int64_t b, int F, int f, int D, int q, const SampleSegments& segs,
+                                             float4& g, float& g1) {
+  int64_t off = 0;
+  if (segs.samples > 0) {
+    const int64_t sg = b / segs.samples;
+    off = sg * segs.stride;
+    b -= sg * segs.samples;
+  }
+  g = ld4(g_field + off + (b * F + f) * D + q * 4);
+  g1 = q == 0 ? g_first[off + b] : 0.f;
+}
+// contributions pos[p], p = p0, p0 + step, ... < p1, added in that order; eight positions, then their eight
+// rows in flight at a time (the loads do not depend on each other — only the additions are ordered)
+constexpr int kRunBatch = 8;
+__device__ __forceinline__ void rowgrad_run(const float* __restrict__ g_field, const float* __restrict__ g_first,
+                                            const int32_t* __restrict__ pos, int p0, int p1, int step, int F, int f,
+                                            int D, int q, const SampleSegments& segs, float4& acc, float& acc1) {
+  // every batch is predicated, the last one included: a tail walked one contribution at a time pays two
+  // dependent memory latencies per contribution (7 of a 31-long strided run cost more than its 3 batches)
+  for (int p = p0; p < p1; p += kRunBatch * step) {
+    float4 g[kRunBatch];
+    float g1[kRunBatch];
+    int32_t b[kRunBatch];
+#pragma unroll
+    for (int u = 0; u < kRunBatch; ++u) b[u] = p + u * step < p1 ? pos[p + u * step] : 0;
+#pragma unroll
+    for (int u = 0; u < kRunBatch; ++u) {
+      g[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      g1[u] = 0.f;
+      if (p + u * step < p1) rowgrad_load(g_field, g_first, b[u], F, f, D, q, segs, g[u], g1[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < kRunBatch; ++u) {
+      if (p + u * step < p1) {                   // (no "+ 0.f": -0.f + 0.f would turn into +0.f)
+        acc.x += g[u].x; acc.y += g[u].y; acc.z += g[u].z; acc.w += g[u].w;
+        acc1 += g1[u];
+      }
+    }
+  }
+}
+
 __device__ __forceinline__ void rowgrad_body(int blk, FieldMap fmap, int S, int F, int D, int lists, const float* __restrict__ g_first,
     const float* __restrict__ g_field, const int32_t* __restrict__ sorted_pos,
     const int32_t* __restrict__ seg_start, const int32_t* __restrict__ num_uniq,
     float* __restrict__ row_g2, float* __restrict__ row_g1, SampleSegments segs = SampleSegments{0, 0}) {
-  const int lpr = D / 4;
-  const int64_t t = static_cast<int64_t>(blk) * kTailThreads + threadIdx.x;
-  const int q = static_cast<int>(t % lpr);
-  const int64_t entry = t / lpr;  // (list, u)
-  const int64_t list = entry / CH;
-  const int u = static_cast<int>(entry % CH);
-  if (list >= lists) return;
-  if (u >= num_uniq[list]) return;
-  const int s = static_cast<int>(list % S);
-  const int f = fmap.f[s];
-  const int32_t* seg = seg_start + list * (CH + 1);
-  const int32_t* pos = sorted_pos + list * CH;
-  const int p0 = seg[u], p1 = seg[u + 1];
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  float acc1 = 0.f;
-  for (int p = p0; p < p1; ++p) {
-    int64_t b = pos[p], off = 0;
-    if (segs.samples > 0) {
-      const int64_t sg = b / segs.samples;
-      off = sg * segs.stride;
-      b -= sg * segs.samples;
-    }
-    const float4 g = ld4(g_field + off + (b * F + f) * D + q * 4);
-    acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
-    if (q == 0) acc1 += g_first[off + b];
+  __shared__ float red[kRowgradLds];
+  __shared__ int s_long;
+  const int lpr = D / 4, groups = kTailThreads / lpr;       // lane groups (= list entries) per workgroup
+  // (lane groups that do not tile the workgroup — D/4 not a power of two — keep the linear mapping and the
+  // sequential sum)
+  const bool coop = kTailThreads % lpr == 0;
+  const int q = threadIdx.x % lpr, grp = threadIdx.x / lpr;
+  // entry of this lane group.  The workgroups of a list INTERLEAVE its entries (workgroup bl of the list's nbl
+  // takes u = bl, bl + nbl, ...): ids are sorted, so under a skewed distribution the hot rows are neighbours
+  // (ids 1, 2, 3, ... of a Zipf law; every row of a 50-id field) and a workgroup that owned 64 consecutive
+  // entries walked all of their long runs one after the other (238 us for 64 ids x 64 contributions).
+  const int nbl = coop ? CH / groups : 1;
+  int64_t list;
+  int u;
+  if (coop) {
+    list = blk / nbl;
+    u = grp * nbl + blk % nbl;
+  } else {
+    const int64_t entry = (static_cast<int64_t>(blk) * kTailThreads + threadIdx.x) / lpr;
+    list = entry / CH;
+    u = static_cast<int>(entry % CH);
   }
-  st4(row_g2 + (list * CH + u) * D + q * 4, acc);
-  if (q == 0) row_g1[list * CH + u] = acc1;
+  const bool valid = threadIdx.x < groups * lpr && list < lists && u < num_uniq[list];
+  int p0 = 0, p1 = 0;
+  if (valid) {
+    const int32_t* seg = seg_start + list * (CH + 1);
+    p0 = seg[u]; p1 = seg[u + 1];
+  }
+  if (threadIdx.x == 0) s_long = 0;
+  __syncthreads();
+  const bool is_long = coop && valid && p1 - p0 > kLongRun;
+  if (is_long && q == 0) atomicOr(&s_long, 1);
+  if (valid && !is_long) {
+    const int f = fmap.f[static_cast<int>(list % S)];
+    const int32_t* pos = sorted_pos + list * CH;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float acc1 = 0.f;
+    rowgrad_run(g_field, g_first, pos, p0, p1, 1, F, f, D, q, segs, acc, acc1);
+    st4(row_g2 + (list * CH + u) * D + q * 4, acc);
+    if (q == 0) row_g1[list * CH + u] = acc1;
+  }
+  __syncthreads();
+  if (!s_long) return;                                      // uniform: the usual case ends here
+  // ---- long runs of this workgroup's entries, one after the other, by all lane groups ----
+  for (int e = 0; e < groups; ++e) {
+    const int64_t ls = list;                                // coop: one list per workgroup
+    const int ue = e * nbl + blk % nbl;
+    if (ls >= lists || ue >= num_uniq[ls]) continue;        // uniform across the workgroup
+    const int32_t* seg = seg_start + ls * (CH + 1);
+    const int q0 = seg[ue], q1 = seg[ue + 1];
+    if (q1 - q0 <= kLongRun) continue;                      // uniform
+    const int f = fmap.f[static_cast<int>(ls % S)];
+    const int32_t* pos = sorted_pos + ls * CH;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float acc1 = 0.f;
+    if (grp < groups) rowgrad_run(g_field, g_first, pos, q0 + grp, q1, groups, F, f, D, q, segs, acc, acc1);
+    if (grp < groups) {
+      st4(red + grp * (D + 4) + q * 4, acc);
+      if (q == 0) red[grp * (D + 4) + D] = acc1;
+    }
+    __syncthreads();
+    if (grp == 0) {                                         // group 0 adds the partial sums in group order
+      float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
+      float tot1 = 0.f;
+      for (int gi = 0; gi < groups; ++gi) {
+        const float4 v = ld4(red + gi * (D + 4) + q * 4);
+        tot.x += v.x; tot.y += v.y; tot.z += v.z; tot.w += v.w;
+        if (q == 0) tot1 += red[gi * (D + 4) + D];
+      }
+      st4(row_g2 + (ls * CH + ue) * D + q * 4, tot);
+      if (q == 0) row_g1[ls * CH + ue] = tot1;
+    }
+    __syncthreads();
+  }
 }
 
 __device__ __forceinline__ int find_row(const int32_t* __restrict__ rows, int n, int32_t row) {

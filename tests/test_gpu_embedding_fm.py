@@ -140,3 +140,55 @@ def test_fm_odd_shapes(shape):
     # a single field gives exactly 0 in exact arithmetic: absolute floor for that case
     assert_close(npy(out), O.fm_forward(x), what="fm", floor=1e-6)
     assert_close(npy(t.grad), O.fm_backward(x, g), what="fm bwd", floor=1e-6)
+
+
+def test_row_gradients_with_hot_ids_vs_oracle():
+    """A skewed batch (most samples of a field on ONE id): runs far longer than the 64 contributions a row's
+    own lanes sum in sample order go through the workgroup-wide reduction of csrc/tail_bodies.h::rowgrad_body
+    — against the oracle's reduction (tolerance: the summation tree differs), and bitwise equal from run to run."""
+    import numpy as np
+    import torch
+    from deepfm_amd import _lib
+    from oracle import ctr_oracle as O
+    lib = _lib.load()
+    rng = np.random.default_rng(9)
+    S, F, D, B, V = 3, 5, 16, 4096 + 300, 50
+    ids = np.where(rng.random((S, B)) < 0.55, V - 1, rng.integers(1, V, size=(S, B))).astype(np.int64)
+    ids[1, :] = 7                                                     # a field with a single id: one run of B
+    g_fe = rng.standard_normal((B, F, D)).astype(np.float32)
+    g_fo = rng.standard_normal(B).astype(np.float32)
+    fmap = [0, 2, 4]
+    t_ids = torch.from_numpy(ids).cuda()
+    t_fe, t_fo = torch.from_numpy(g_fe).cuda(), torch.from_numpy(g_fo).cuda()
+    CH = _lib.ROWPLAN_CHUNK
+    chunks = (B + CH - 1) // CH
+    i32 = dict(dtype=torch.int32, device="cuda")
+    sorted_pos, uniq = torch.empty(chunks, S, CH, **i32), torch.empty(chunks, S, CH, **i32)
+    seg, num = torch.empty(chunks, S, CH + 1, **i32), torch.zeros(chunks, S, **i32)
+    err = torch.zeros(1, **i32)
+    import ctypes as C
+    idp = (C.c_void_p * S)(*[t_ids[s].data_ptr() for s in range(S)])
+    vocab = (C.c_int32 * S)(*([V] * S))
+    _lib.check(lib.dfm_rowplan_build(idp, vocab, S, B, sorted_pos.data_ptr(), uniq.data_ptr(), seg.data_ptr(),
+                                     num.data_ptr(), err.data_ptr(), _lib.stream_handle()))
+    outs = []
+    for _ in range(2):
+        g2 = torch.zeros(chunks, S, CH, D, device="cuda")
+        g1 = torch.zeros(chunks, S, CH, device="cuda")
+        _lib.check(lib.dfm_rowgrad_build((C.c_int32 * S)(*fmap), S, F, D, B, t_fo.data_ptr(), t_fe.data_ptr(),
+                                         sorted_pos.data_ptr(), seg.data_ptr(), num.data_ptr(), g2.data_ptr(),
+                                         g1.data_ptr(), _lib.stream_handle()))
+        outs.append((g2.cpu().numpy(), g1.cpu().numpy()))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    nu, un = num.cpu().numpy(), uniq.cpu().numpy()
+    longest = 0
+    for c in range(chunks):
+        lo, hi = c * CH, min(B, (c + 1) * CH)
+        for s in range(S):
+            u, a2, a1 = O.rowsparse_reduce_fast(ids[s, lo:hi], g_fe[lo:hi, fmap[s]], g_fo[lo:hi])
+            n = int(nu[c, s])
+            assert np.array_equal(un[c, s, :n], u)
+            np.testing.assert_allclose(outs[0][0][c, s, :n], a2, rtol=1e-4, atol=1e-3)
+            np.testing.assert_allclose(outs[0][1][c, s, :n], a1, rtol=1e-4, atol=1e-3)
+            longest = max(longest, int(np.bincount(ids[s, lo:hi]).max()))
+    assert longest > 2000
