@@ -210,7 +210,7 @@ __device__ __forceinline__ void rowgrad_body(int blk, FieldMap fmap, int S, int 
     const int32_t* __restrict__ seg_start, const int32_t* __restrict__ num_uniq,
     float* __restrict__ row_g2, float* __restrict__ row_g1, SampleSegments segs = SampleSegments{0, 0}) {
   __shared__ float red[kRowgradLds];
-  __shared__ int s_long;
+  __shared__ int s_long, s_ent[kTailThreads], s_p0[kTailThreads], s_p1[kTailThreads];   // the workgroup's long runs
   const int lpr = D / 4, groups = kTailThreads / lpr;       // lane groups (= list entries) per workgroup
   // (lane groups that do not tile the workgroup — D/4 not a power of two — keep the linear mapping and the
   // sequential sum)
@@ -240,7 +240,10 @@ __device__ __forceinline__ void rowgrad_body(int blk, FieldMap fmap, int S, int 
   if (threadIdx.x == 0) s_long = 0;
   __syncthreads();
   const bool is_long = coop && valid && p1 - p0 > kLongRun;
-  if (is_long && q == 0) atomicOr(&s_long, 1);
+  if (is_long && q == 0) {                 // (the order of this list does not matter: the runs are independent)
+    const int i = atomicAdd(&s_long, 1);
+    s_ent[i] = u; s_p0[i] = p0; s_p1[i] = p1;
+  }
   if (valid && !is_long) {
     const int f = fmap.f[static_cast<int>(list % S)];
     const int32_t* pos = sorted_pos + list * CH;
@@ -253,13 +256,11 @@ __device__ __forceinline__ void rowgrad_body(int blk, FieldMap fmap, int S, int 
   __syncthreads();
   if (!s_long) return;                                      // uniform: the usual case ends here
   // ---- long runs of this workgroup's entries, one after the other, by all lane groups ----
-  for (int e = 0; e < groups; ++e) {
+  // (found in LDS: asking global memory for every entry's run length again was 64 dependent loads, ~40 us)
+  const int n_long = s_long;
+  for (int e = 0; e < n_long; ++e) {
     const int64_t ls = list;                                // coop: one list per workgroup
-    const int ue = e * nbl + blk % nbl;
-    if (ls >= lists || ue >= num_uniq[ls]) continue;        // uniform across the workgroup
-    const int32_t* seg = seg_start + ls * (CH + 1);
-    const int q0 = seg[ue], q1 = seg[ue + 1];
-    if (q1 - q0 <= kLongRun) continue;                      // uniform
+    const int ue = s_ent[e], q0 = s_p0[e], q1 = s_p1[e];
     const int f = fmap.f[static_cast<int>(ls % S)];
     const int32_t* pos = sorted_pos + ls * CH;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
