@@ -189,18 +189,19 @@ def event_ms(fn, iters, warm=3):
     return sum(ts) / len(ts), min(ts)
 
 
-def extra_config(name, args, dev, lib):
+def extra_config(name, args, dev, lib, ids_dist="uniform"):
     """One of BASELINE.json's configurations 3 / 4 on one GPU: the same timed loop as the headline
     (batches resident in HBM, packed records, HIP graph), then the roofline of the model's own
-    interaction layer from HIP events around isolated launches of it at the same shapes."""
+    interaction layer from HIP events around isolated launches of it at the same shapes.  name "deepfm":
+    the headline model again on another id distribution (SURVEY.md 8d's secondary, Zipf), step time only."""
     B, V = args.batch, args.vocab
-    D = 32 if name == "attention_deepfm" else 16
+    D = 32 if name == "attention_deepfm" else (args.dim if name == "deepfm" else 16)
     cin_sizes = [128, 128, 128] if name == "xdeepfm" else None
     model, opt, step, fields, cfg, hp, fused = build_step(name, V, D, B, dev, args, cin_sizes)
     n_sparse, n_dense = 26, 13
     G = 1 if (args.no_graph or (opt.split and not step.exchange_in_body)) else args.steps_per_graph
     warm, steps = -(-10 // G) * G, max(args.extra_steps // G, 1) * G                   # whole graph launches
-    ids, dense, labels = make_pool(warm + steps, n_sparse, n_dense, B, V, 101, dev)     # every batch used once
+    ids, dense, labels = make_pool(warm + steps, n_sparse, n_dense, B, V, 101, dev, ids_dist)     # every batch used once
     records = step.pack_batches(ids, dense, labels)
     step.load_packed(records[0])
     step.capture(steps_per_graph=G)
@@ -213,13 +214,17 @@ def extra_config(name, args, dev, lib):
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     out = {
-        "workload": (f"{'xDeepFM' if name == 'xdeepfm' else 'AttentionDeepFM'} synthetic Criteo-shape: {n_sparse} sparse x {V} "
-                     f"vocab, {n_dense} dense, embed_dim {D}, batch {B}"
-                     + (f", cin.layer_sizes={cin_sizes}" if cin_sizes else f", attention.num_heads={cfg.attention.num_heads}")),
+        "workload": (f"{dict(xdeepfm='xDeepFM', attention_deepfm='AttentionDeepFM', deepfm='DeepFM')[name]} synthetic "
+                     f"Criteo-shape: {n_sparse} sparse x {V} vocab, {n_dense} dense, embed_dim {D}, batch {B}"
+                     + (f", cin.layer_sizes={cin_sizes}" if cin_sizes else
+                        (f", attention.num_heads={cfg.attention.num_heads}" if name == "attention_deepfm" else ""))),
+        "ids": ids_dist,
         "ms_per_step": el / steps * 1e3, "samples_per_s": steps * B / el, "steps": steps, "warmup": warm,
         "step": type(step).__name__, "hip_graph": not args.no_graph, "steps_per_graph": G,
         "final_loss": float(step.loss.item()),
     }
+    if name == "deepfm":
+        return out
     # ---- the interaction layer alone, at the step's shapes, on this stream
     fe = step.fe.detach().clone().requires_grad_()
     if name == "xdeepfm":
@@ -466,6 +471,8 @@ def main():
             del step, opt, model, records
             torch.cuda.empty_cache()
             out["extra_configs"] = [extra_config(n, args, dev, lib) for n in ("xdeepfm", "attention_deepfm")]
+            if args.ids == "uniform":        # the headline model on the secondary id distribution
+                out["extra_configs"].append(extra_config("deepfm", args, dev, lib, ids_dist="zipf"))
         print(json.dumps(out), file=json_out, flush=True)
     if dist.is_initialized():
         if "step" in locals():
