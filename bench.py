@@ -57,6 +57,9 @@ def parse():
     ap.add_argument("--ids", choices=("uniform", "zipf"), default="uniform",
                     help="id distribution of the synthetic batches: uniform over [1, V) (the headline: worst case for "
                          "caches) or Zipf(1.05) clipped to [1, V) (SURVEY.md 8d's secondary, Criteo-like skew)")
+    ap.add_argument("--vocab-profile", choices=("equal", "criteo"), default="equal",
+                    help="equal: --vocab ids in every SPARSE field (BASELINE.json's shape); criteo: the 26 vocabulary sizes "
+                         "of the public Criteo Kaggle set (3 ... 10 M ids, 33.8 M rows in all), uniform ids inside a field")
     ap.add_argument("--unpacked", action="store_true", help="keep the tables as separate contiguous tensors")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-extra-configs", action="store_true",
@@ -87,7 +90,12 @@ def gather_bytes_per_sample(n_sparse: int, n_dense: int, dim: int) -> int:
 def make_pool(n_batches, n_sparse, n_dense, B, V, seed, device, dist_name="uniform"):
     g = torch.Generator(device=device)
     g.manual_seed(seed)
-    if dist_name == "zipf":
+    if isinstance(V, (list, tuple)):          # one vocabulary per field: uniform ids inside each
+        hi = torch.tensor(V, device=device, dtype=torch.float64).view(1, n_sparse, 1)
+        u = torch.rand((n_batches, n_sparse, B), generator=g, device=device, dtype=torch.float64)
+        ids = (1 + (u * (hi - 1)).floor()).to(torch.int64).clamp_(max=int(max(V)) - 1)
+        ids = torch.minimum(ids, (hi - 1).to(torch.int64))
+    elif dist_name == "zipf":
         # SURVEY.md section 8(d), secondary distribution: Zipf(s = 1.05) clipped to [1, V) — Criteo-like skew,
         # many duplicates inside a batch (the row plan's skewed-bucket path, cache-friendly gathers)
         z = np.random.default_rng(seed).zipf(1.05, size=(n_batches, n_sparse, B))
@@ -146,8 +154,8 @@ def build_step(name, V, D, B, dev, args, cin_sizes=None):
     from deepfm_amd.training.rowsparse import RowSparseAdam
     from deepfm_amd.training.step import RowSparseTrainStep
     from tests.helpers import schema_from_fields
-    from tools_shared import criteo_fields
-    fields = criteo_fields(V, D)
+    from tools_shared import CRITEO_KAGGLE_CARDINALITIES, criteo_fields
+    fields = criteo_fields([c + 1 for c in CRITEO_KAGGLE_CARDINALITIES] if args.vocab_profile == "criteo" else V, D)
     cfg = ExperimentConfig()
     cfg.feature.fm_embed_dim = D
     if cin_sizes:
@@ -316,7 +324,8 @@ def main():
     model, opt, step, fields, cfg, hp, fused = build_step("deepfm", V, D, B, dev, args)
 
     total = args.steps + args.warmup
-    ids, dense, labels = make_pool(total, n_sparse, n_dense, B, V, 1 + rank, dev, args.ids)
+    pool_v = [f["vocab"] for f in fields if f["type"] == "sparse"] if args.vocab_profile == "criteo" else V
+    ids, dense, labels = make_pool(total, n_sparse, n_dense, B, pool_v, 1 + rank, dev, args.ids)
     records = step.pack_batches(ids, dense, labels)      # one record per batch, resident in HBM
     step.load_packed(records[0])
     # several steps per graph need the whole step inside ONE graph: one rank without the split exchange path
@@ -427,6 +436,7 @@ def main():
             "data": "synthetic",
             "config": {
                 "ids": args.ids,
+                "vocab_profile": args.vocab_profile,
                 "workload": f"DeepFM synthetic Criteo-shape: {n_sparse} sparse x {V} vocab, {n_dense} dense, "
                             f"embed_dim {D}, batch {B}/GPU; step = fwd + BCE + L2 + bwd + clip + "
                             "row-wise Adam on touched rows (lazy L2) + dense Adam",
