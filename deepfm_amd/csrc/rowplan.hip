@@ -30,15 +30,19 @@ using tail::FieldMap;
 }  // namespace
 
 // KeyT = uint64 (id << 32 | pos) for any vocabulary, or uint32 (id << 12 | pos) when every id of the
-// launch fits 20 bits (vocabulary < 2^20 - 1: the 1M-row Criteo tables): the sort is LDS-bound
-// (78 compare-exchange sweeps over 4096 keys), so half the key bytes is close to half the time.
+// launch fits 20 bits (vocabulary < 2^20 - 1: the 1M-row Criteo tables): the bitonic network is LDS-bound
+// (78 compare-exchange sweeps over 4096 keys), so half the key bytes is close to half the time.  The
+// counting-sort fast path runs with either key width (round 2: it was 32-bit only, so ONE table of a million
+// rows or more — any real data set — put every field of the launch on the bitonic network: 27 vs 13 us).
 template <typename KeyT, int SHIFT>
 __global__ __launch_bounds__(SORT_THREADS) void rowplan_sort(
     IdTable ids, int S, int64_t n, int32_t* __restrict__ sorted_pos, int32_t* __restrict__ uniq_rows,
     int32_t* __restrict__ seg_start, int32_t* __restrict__ num_uniq, int32_t* error_flag, int ablate) {
   constexpr KeyT SENTINEL = static_cast<KeyT>(~static_cast<KeyT>(0));
   constexpr KeyT POS_MASK = (static_cast<KeyT>(1) << SHIFT) - 1;
-  __shared__ KeyT keys[CH];
+  // dynamic LDS (rowplan_lds_bytes): [keys | tmp | cnt | start] — 64 KB with 32-bit keys, 96 KB with 64-bit ones
+  extern __shared__ __attribute__((aligned(16))) unsigned char rp_lds[];
+  KeyT* keys = reinterpret_cast<KeyT*>(rp_lds);
   __shared__ int wave_tot[SORT_THREADS / kWave];
   const int s = blockIdx.x, c = blockIdx.y;
   const int tid = threadIdx.x;
@@ -62,7 +66,7 @@ __global__ __launch_bounds__(SORT_THREADS) void rowplan_sort(
   }
   __syncthreads();
 
-  // ---- fast path: counting sort over 4096 id buckets (32-bit keys only) -------------------------
+  // ---- fast path: counting sort over 4096 id buckets -------------------------------------------
   // With ids spread over the vocabulary a bucket (id * 4096 / vocab: monotone in id, so bucket
   // order is key order) holds about one key: histogram, exclusive scan, scatter into the bucket's
   // range, then every key ranks itself among the handful of keys of its bucket.  LDS atomics decide
@@ -70,11 +74,11 @@ __global__ __launch_bounds__(SORT_THREADS) void rowplan_sort(
   // the result is the same sorted array the bitonic network produces.  Skewed ids (any bucket with
   // more than kMaxBucket keys) take the bitonic network below instead.
   bool sorted = false;
-  if constexpr (sizeof(KeyT) == 4) {
+  {
     constexpr int kMaxBucket = 16;
-    __shared__ int cnt[CH];        // keys per bucket, then the scatter cursor
-    __shared__ int start[CH];      // first output slot of every bucket
-    __shared__ KeyT tmp[CH];
+    KeyT* tmp = keys + CH;
+    int* cnt = reinterpret_cast<int*>(tmp + CH);       // keys per bucket, then the scatter cursor
+    int* start = cnt + CH;                             // first output slot of every bucket
     __shared__ int wave_sum[SORT_THREADS / kWave];
     __shared__ int s_max;
 #pragma unroll
@@ -292,11 +296,21 @@ int dfm_rowplan_build(const int64_t* const* ids, const int32_t* vocab, int num_s
   int max_vocab = 0;
   for (int s = 0; s < num_sparse; ++s) max_vocab = vocab[s] > max_vocab ? vocab[s] : max_vocab;
   static_assert(CH == 4096, "the 32-bit key packs the position into 12 bits");
-  if (max_vocab < (1 << 20) - 1)     // ids (< vocab) leave the all-ones key free for the sentinel
-    hipLaunchKernelGGL((rowplan_sort<uint32_t, 12>), dim3(num_sparse, chunks), dim3(SORT_THREADS), 0, as_stream(stream),
+  // ids (< vocab) below 2^20 - 1 leave the all-ones 32-bit key free for the sentinel
+  const bool narrow = max_vocab < (1 << 20) - 1;
+  const void* func = narrow ? reinterpret_cast<const void*>(rowplan_sort<uint32_t, 12>)
+                            : reinterpret_cast<const void*>(rowplan_sort<unsigned long long, 32>);
+  const unsigned lds = static_cast<unsigned>((narrow ? 4 : 8) * 2 * CH + 2 * CH * sizeof(int));
+  static bool allowed[2] = {false, false};          // more than 64 KB of dynamic LDS: allowed once per kernel
+  if (!allowed[narrow ? 0 : 1]) {
+    DFM_HIP_TRY(hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    allowed[narrow ? 0 : 1] = true;
+  }
+  if (narrow)
+    hipLaunchKernelGGL((rowplan_sort<uint32_t, 12>), dim3(num_sparse, chunks), dim3(SORT_THREADS), lds, as_stream(stream),
                        t, num_sparse, n, d_sorted_pos, d_uniq_rows, d_seg_start, d_num_uniq, d_error_flag, g_rp_ablate);
   else
-    hipLaunchKernelGGL((rowplan_sort<unsigned long long, 32>), dim3(num_sparse, chunks), dim3(SORT_THREADS), 0,
+    hipLaunchKernelGGL((rowplan_sort<unsigned long long, 32>), dim3(num_sparse, chunks), dim3(SORT_THREADS), lds,
                        as_stream(stream), t, num_sparse, n, d_sorted_pos, d_uniq_rows, d_seg_start, d_num_uniq,
                        d_error_flag, g_rp_ablate);
   DFM_LAUNCH_CHECK();
