@@ -21,6 +21,7 @@ namespace {
 using tail::CH;
 constexpr int SORT_THREADS = 1024;
 constexpr int PER_THREAD = CH / SORT_THREADS;  // 4
+constexpr int kTinyVocab = 64;                 // vocabularies up to this take the counting-by-ballot sort
 
 struct IdTable {
   const int64_t* p[DFM_MAX_FIELDS];
@@ -74,8 +75,66 @@ __global__ __launch_bounds__(SORT_THREADS) void rowplan_sort(
   // the result is the same sorted array the bitonic network produces.  Skewed ids (any bucket with
   // more than kMaxBucket keys) take the bitonic network below instead.
   bool sorted = false;
-  {
-    constexpr int kMaxBucket = 16;
+  // ---- tiny vocabularies (<= 64 ids: Criteo has fields with 3, 4, 10 ... 27): every id fills a run of B / V
+  // keys, far beyond what the bucket ranking below can take, and the launch would wait for these fields on the
+  // bitonic network.  Keys of one id differ by position only, so the stable order is a COUNT: keys of the
+  // same id at lower positions = earlier rounds + lower waves of the round + lower lanes of the wave (ballots).
+  if (vocab <= kTinyVocab) {
+    int* wcnt = reinterpret_cast<int*>(keys + 2 * CH);        // [PER_THREAD rounds][16 waves][64 ids]
+    int* idstart = wcnt + PER_THREAD * (SORT_THREADS / kWave) * kTinyVocab;     // [64 + 1]
+    constexpr int kW = SORT_THREADS / kWave;
+    for (int i = tid; i < PER_THREAD * kW * kTinyVocab; i += SORT_THREADS) wcnt[i] = 0;
+    __syncthreads();
+    const int lane = lane_id(), w = tid >> 6;
+    KeyT mykey[PER_THREAD];
+    int myid[PER_THREAD], myrank[PER_THREAD];
+#pragma unroll
+    for (int r = 0; r < PER_THREAD; ++r) {
+      mykey[r] = keys[tid + r * SORT_THREADS];                // round r: positions r * 1024 + tid
+      myid[r] = mykey[r] != SENTINEL ? static_cast<int>(mykey[r] >> SHIFT) : -1;
+      myrank[r] = 0;
+      bool pending = myid[r] >= 0;
+      while (true) {
+        const unsigned long long active = __ballot(pending);
+        if (!active) break;
+        const int cur = __shfl(myid[r], __ffsll(static_cast<long long>(active)) - 1, kWave);
+        const unsigned long long mask = __ballot(pending && myid[r] == cur);
+        if (pending && myid[r] == cur) {
+          myrank[r] = __popcll(mask & ((1ull << lane) - 1ull));
+          pending = false;
+          if (myrank[r] == 0) wcnt[(r * kW + w) * kTinyVocab + cur] = __popcll(mask);
+        }
+      }
+    }
+    __syncthreads();
+    // id v: exclusive prefix of its counts over (round, wave) in position order; then the ids' start slots
+    if (tid < kTinyVocab) {
+      int run = 0;
+      for (int i = 0; i < PER_THREAD * kW; ++i) {
+        const int c = wcnt[i * kTinyVocab + tid];
+        wcnt[i * kTinyVocab + tid] = run;
+        run += c;
+      }
+      idstart[tid + 1] = run;                                  // count of id tid (made a prefix below)
+    }
+    __syncthreads();
+    if (tid == 0) {
+      idstart[0] = 0;
+      for (int v = 0; v < kTinyVocab; ++v) idstart[v + 1] += idstart[v];
+    }
+    __syncthreads();
+    const int total_valid = idstart[kTinyVocab];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < PER_THREAD; ++r)
+      if (myid[r] >= 0) keys[CH + idstart[myid[r]] + wcnt[(r * kW + w) * kTinyVocab + myid[r]] + myrank[r]] = mykey[r];
+    __syncthreads();
+    for (int i = tid; i < CH; i += SORT_THREADS) keys[i] = i < total_valid ? keys[CH + i] : SENTINEL;
+    __syncthreads();
+    sorted = true;
+  }
+  if (!sorted) {
+    constexpr int kMaxBucket = 64;
     KeyT* tmp = keys + CH;
     int* cnt = reinterpret_cast<int*>(tmp + CH);       // keys per bucket, then the scatter cursor
     int* start = cnt + CH;                             // first output slot of every bucket
