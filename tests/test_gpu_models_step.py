@@ -391,11 +391,12 @@ def test_run_from_record_equals_load_then_run(fused):
         assert np.array_equal(results[0][0][k], results[1][0][k]), k
 
 
-@pytest.mark.parametrize("vocab", [1000, (1 << 20) - 2, (1 << 20) - 1, 3_000_000])
+@pytest.mark.parametrize("vocab", [3, 64, 65, 200, 1000, (1 << 20) - 2, (1 << 20) - 1, 3_000_000])
 def test_rowplan_key_widths_vs_oracle(vocab):
     """dfm_rowplan_build sorts 32-bit keys (id << 12 | pos) when every vocabulary is below 2^20 - 1 and
     64-bit keys otherwise: both against the oracle's ordered reduction, with duplicates, padding ids, the
-    largest id and an odd tail (two chunks).  Bit-exact for every row with at most 64 contributions (summed
+    largest id and an odd tail (two chunks).  Vocabularies of <= 64 ids take the counting-by-ballot sort,
+    65 / 200 the bucket ranking with long buckets or the bitonic network.  Bit-exact for every row with at most 64 contributions (summed
     in sample order); longer runs (the 50-id field: ~80 per row) go through the workgroup-wide fixed tree of
     rowgrad_body and are held to rounding."""
     from deepfm_amd import _lib
@@ -436,7 +437,8 @@ def test_rowplan_key_widths_vs_oracle(vocab):
             short = runs <= 64
             got2, got1 = npy(row_g2)[c, s, :n], npy(row_g1)[c, s, :n]
             assert np.array_equal(got2[short], r2[short]) and np.array_equal(got1[short], r1[short])
-            np.testing.assert_allclose(got2[~short], r2[~short], rtol=1e-5, atol=2e-5)
-            np.testing.assert_allclose(got1[~short], r1[~short], rtol=1e-5, atol=2e-5)
-            if s == 1 and c == 0:
+            # (a run of n standard normals sums to ~sqrt(n); two fp32 summation orders differ by ~n * 6e-8 of that)
+            np.testing.assert_allclose(got2[~short], r2[~short], rtol=1e-4, atol=5e-4)
+            np.testing.assert_allclose(got1[~short], r1[~short], rtol=1e-4, atol=5e-4)
+            if s == 1 and c == 0 and vocab >= 50:
                 assert (~short).any()
