@@ -442,7 +442,7 @@ def main():
                             "row-wise Adam on touched rows (lazy L2) + dense Adam",
                 "global_batch": B * world,
                 "parallelism": f"dp{world}" + ("" if not dist.is_initialized() else
-                                                f" ({'field-sharded tables, 3 all-to-alls + 1 scalar all-gather per step' if step.exchange_in_body else 'replicated tables, one grouped all-gather per step'})"),
+                                                f" ({'field-sharded tables, 3 all-to-alls + 1 small all-gather per step' if step.exchange_in_body else 'replicated tables, one grouped all-gather per step'})"),
                 "hip_graph": not args.no_graph,
                 "steps_per_graph": G,
                 "input": "host memory -> pinned staging -> H2D ring (PCIe-inclusive)" if args.h2d else "resident in HBM",
