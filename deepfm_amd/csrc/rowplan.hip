@@ -4,9 +4,9 @@
 // accumulates duplicate ids; row 0 = padding_idx gets no gradient).
 //
 // One 1024-thread workgroup sorts one chunk of up to 4096 ids of one field entirely in
-// LDS (bitonic network on 64-bit keys id<<32 | position: keys are distinct, so the order
-// is "by id, then by sample position" = stable).  Ids 0 / out of range become a sentinel
-// that sorts to the end.  Run heads are found with a block scan.  The plan depends on the
+// LDS (keys id<<shift | position: keys are distinct, so the order is "by id, then by sample
+// position" = stable; a counting sort over 4096 id buckets for spread-out ids, a ballot-counting
+// radix sort for skewed ones).  Ids 0 / out of range become a sentinel that sorts to the end.  Run heads are found with a block scan.  The plan depends on the
 // ids only, so the host can enqueue it ahead of the forward pass.
 //
 // rowgrad: D/4 lanes per distinct id add that id's contributions in sorted (= sample)
@@ -21,7 +21,6 @@ namespace {
 using tail::CH;
 constexpr int SORT_THREADS = 1024;
 constexpr int PER_THREAD = CH / SORT_THREADS;  // 4
-constexpr int kTinyVocab = 64;                 // vocabularies up to this take the counting-by-ballot sort
 
 struct IdTable {
   const int64_t* p[DFM_MAX_FIELDS];
@@ -31,10 +30,8 @@ using tail::FieldMap;
 }  // namespace
 
 // KeyT = uint64 (id << 32 | pos) for any vocabulary, or uint32 (id << 12 | pos) when every id of the
-// launch fits 20 bits (vocabulary < 2^20 - 1: the 1M-row Criteo tables): the bitonic network is LDS-bound
-// (78 compare-exchange sweeps over 4096 keys), so half the key bytes is close to half the time.  The
-// counting-sort fast path runs with either key width (round 2: it was 32-bit only, so ONE table of a million
-// rows or more — any real data set — put every field of the launch on the bitonic network: 27 vs 13 us).
+// launch fits 20 bits (vocabulary < 2^20 - 1: the 1M-row Criteo tables): the sorts are LDS-bound, so half the
+// key bytes is a good part of the time.  Both sorts run with either key width (dynamic LDS: 64 / 96 KB).
 template <typename KeyT, int SHIFT>
 __global__ __launch_bounds__(SORT_THREADS) void rowplan_sort(
     IdTable ids, int S, int64_t n, int32_t* __restrict__ sorted_pos, int32_t* __restrict__ uniq_rows,
@@ -72,65 +69,114 @@ __global__ __launch_bounds__(SORT_THREADS) void rowplan_sort(
   // order is key order) holds about one key: histogram, exclusive scan, scatter into the bucket's
   // range, then every key ranks itself among the handful of keys of its bucket.  LDS atomics decide
   // only the transient slot inside a bucket; the final position depends on key comparisons alone, so
-  // the result is the same sorted array the bitonic network produces.  Skewed ids (any bucket with
-  // more than kMaxBucket keys) take the bitonic network below instead.
+  // the result is THE sorted array.  Skewed ids (any bucket with more than kMaxBucket keys) take the
+  // radix sort instead.
   bool sorted = false;
-  // ---- tiny vocabularies (<= 64 ids: Criteo has fields with 3, 4, 10 ... 27): every id fills a run of B / V
-  // keys, far beyond what the bucket ranking below can take, and the launch would wait for these fields on the
-  // bitonic network.  Keys of one id differ by position only, so the stable order is a COUNT: keys of the
-  // same id at lower positions = earlier rounds + lower waves of the round + lower lanes of the wave (ballots).
-  if (vocab <= kTinyVocab) {
-    int* wcnt = reinterpret_cast<int*>(keys + 2 * CH);        // [PER_THREAD rounds][16 waves][64 ids]
-    int* idstart = wcnt + PER_THREAD * (SORT_THREADS / kWave) * kTinyVocab;     // [64 + 1]
-    constexpr int kW = SORT_THREADS / kWave;
-    for (int i = tid; i < PER_THREAD * kW * kTinyVocab; i += SORT_THREADS) wcnt[i] = 0;
-    __syncthreads();
+  // ---- stable LSD radix sort on the id bits, 7 bits a pass (the input is in position order, so sorting by id
+  // stably IS the (id, position) order).  A key's slot inside its digit is a COUNT — keys of the same digit in
+  // earlier rounds + lower waves of the round + lower lanes of the wave, from ballots — so the cost does not
+  // depend on the distribution: hot ids (Zipf), a field with three ids, every bucket of the counting sort
+  // below overflowing ... all take bits / 7 passes of ~3 us (20-bit ids: 22 us a launch against 14 for the
+  // counting sort).  Used for vocabularies of <= 128 ids (one pass)
+  // and whenever the counting sort's buckets overflow (that case used to run a bitonic network of 78
+  // compare-exchange sweeps: 27 ... 30 us).
+  constexpr int kDigits = 128, kW = SORT_THREADS / kWave;
+  __shared__ int dstart[kDigits + 1];
+  __shared__ int segsum[SORT_THREADS];
+  KeyT* const buf1 = keys + CH;
+  int* const wcnt = reinterpret_cast<int*>(keys + 2 * CH);     // [PER_THREAD rounds][16 waves][128 digits] = 32 KB
+  // one pass: src -> dst by digit (key >> (SHIFT + shift)) & 127; nvalid < 0: the valid keys are the
+  // non-sentinels of all CH slots (first pass), else slots [0, nvalid).  Returns the number of valid keys.
+  auto radix_pass = [&](const KeyT* src, KeyT* dst, int shift, int nvalid) -> int {
     const int lane = lane_id(), w = tid >> 6;
+    for (int i = tid; i < PER_THREAD * kW * kDigits; i += SORT_THREADS) wcnt[i] = 0;
+    __syncthreads();
     KeyT mykey[PER_THREAD];
-    int myid[PER_THREAD], myrank[PER_THREAD];
+    int mydig[PER_THREAD], myrank[PER_THREAD];
 #pragma unroll
     for (int r = 0; r < PER_THREAD; ++r) {
-      mykey[r] = keys[tid + r * SORT_THREADS];                // round r: positions r * 1024 + tid
-      myid[r] = mykey[r] != SENTINEL ? static_cast<int>(mykey[r] >> SHIFT) : -1;
-      myrank[r] = 0;
-      bool pending = myid[r] >= 0;
-      while (true) {
-        const unsigned long long active = __ballot(pending);
-        if (!active) break;
-        const int cur = __shfl(myid[r], __ffsll(static_cast<long long>(active)) - 1, kWave);
-        const unsigned long long mask = __ballot(pending && myid[r] == cur);
-        if (pending && myid[r] == cur) {
-          myrank[r] = __popcll(mask & ((1ull << lane) - 1ull));
-          pending = false;
-          if (myrank[r] == 0) wcnt[(r * kW + w) * kTinyVocab + cur] = __popcll(mask);
-        }
+      const int i = tid + r * SORT_THREADS;                   // round r: array slots r * 1024 + tid, in order
+      mykey[r] = src[i];
+      const bool ok = nvalid < 0 ? mykey[r] != SENTINEL : i < nvalid;
+      mydig[r] = ok ? static_cast<int>((mykey[r] >> (SHIFT + shift)) & (kDigits - 1)) : -1;
+      // lanes of the wave holding the same digit: one ballot per digit bit (cost independent of the ids)
+      unsigned long long mask = __ballot(ok);
+#pragma unroll
+      for (int bit = 0; bit < 7; ++bit) {
+        const unsigned long long bm = __ballot((mydig[r] >> bit) & 1);
+        mask &= ((mydig[r] >> bit) & 1) ? bm : ~bm;
       }
+      myrank[r] = __popcll(mask & ((1ull << lane) - 1ull));
+      if (ok && myrank[r] == 0) wcnt[(r * kW + w) * kDigits + mydig[r]] = __popcll(mask);
     }
     __syncthreads();
-    // id v: exclusive prefix of its counts over (round, wave) in position order; then the ids' start slots
-    if (tid < kTinyVocab) {
-      int run = 0;
-      for (int i = 0; i < PER_THREAD * kW; ++i) {
-        const int c = wcnt[i * kTinyVocab + tid];
-        wcnt[i * kTinyVocab + tid] = run;
-        run += c;
+    {                               // per digit: exclusive prefix of its counts over (round, wave) = slot order;
+      constexpr int kSeg = SORT_THREADS / kDigits, kPer = PER_THREAD * kW / kSeg;   // 8 threads a digit, 8 counts each
+      const int d = tid & (kDigits - 1), sg = tid / kDigits;
+      int cn[kPer], sum = 0;
+#pragma unroll
+      for (int q = 0; q < kPer; ++q) {
+        cn[q] = wcnt[(sg * kPer + q) * kDigits + d];
+        sum += cn[q];
       }
-      idstart[tid + 1] = run;                                  // count of id tid (made a prefix below)
+      segsum[sg * kDigits + d] = sum;
+      __syncthreads();
+      int run = 0, tot = 0;
+#pragma unroll
+      for (int q = 0; q < kSeg; ++q) {
+        const int v = segsum[q * kDigits + d];
+        run += q < sg ? v : 0;
+        tot += v;
+      }
+#pragma unroll
+      for (int q = 0; q < kPer; ++q) {
+        wcnt[(sg * kPer + q) * kDigits + d] = run;
+        run += cn[q];
+      }
+      if (sg == 0) dstart[d + 1] = tot;
     }
     __syncthreads();
-    if (tid == 0) {
-      idstart[0] = 0;
-      for (int v = 0; v < kTinyVocab; ++v) idstart[v + 1] += idstart[v];
+    if (tid < kWave) {              // exclusive scan of the 128 digit totals by one wave (two digits a lane)
+      const int a0 = dstart[2 * tid + 1], a1 = dstart[2 * tid + 2];
+      int incl = a0 + a1;
+#pragma unroll
+      for (int o = 1; o < kWave; o <<= 1) {
+        const int t = __shfl_up(incl, o, kWave);
+        if (tid >= o) incl += t;
+      }
+      const int excl = incl - (a0 + a1);
+      dstart[2 * tid + 1] = excl + a0;
+      dstart[2 * tid + 2] = excl + a0 + a1;
+      if (tid == 0) dstart[0] = 0;
     }
-    __syncthreads();
-    const int total_valid = idstart[kTinyVocab];
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < PER_THREAD; ++r)
-      if (myid[r] >= 0) keys[CH + idstart[myid[r]] + wcnt[(r * kW + w) * kTinyVocab + myid[r]] + myrank[r]] = mykey[r];
+      if (mydig[r] >= 0) dst[dstart[mydig[r]] + wcnt[(r * kW + w) * kDigits + mydig[r]] + myrank[r]] = mykey[r];
+    const int total = dstart[kDigits];
     __syncthreads();
-    for (int i = tid; i < CH; i += SORT_THREADS) keys[i] = i < total_valid ? keys[CH + i] : SENTINEL;
+    return total;
+  };
+  // the whole sort: `passes` passes over the id bits, ping-pong keys <-> buf1, sentinels behind the valid keys
+  auto radix_sort = [&]() {
+    int bits = 1;
+    while ((1ll << bits) < vocab) ++bits;                     // ids < vocab
+    int nvalid = -1;
+    const KeyT* src = keys;
+    KeyT* dst = buf1;
+    for (int shift = 0; shift < bits; shift += 7) {
+      nvalid = radix_pass(src, dst, shift, nvalid);
+      const KeyT* t = src; src = dst; dst = const_cast<KeyT*>(t);
+    }
+    // src holds the sorted valid keys
+    if (src != keys)
+      for (int i = tid; i < CH; i += SORT_THREADS) keys[i] = i < nvalid ? src[i] : SENTINEL;
+    else
+      for (int i = tid; i < CH; i += SORT_THREADS) if (i >= nvalid) keys[i] = SENTINEL;
     __syncthreads();
+  };
+  if (vocab <= kDigits) {
+    radix_sort();
     sorted = true;
   }
   if (!sorted) {
@@ -219,46 +265,7 @@ __global__ __launch_bounds__(SORT_THREADS) void rowplan_sort(
     }
   }
 
-  // Bitonic sort, ascending.  Thread t holds keys [4t, 4t+4) in registers: compare-exchange partners
-  // at distance j < 4 are in the same thread, at 4 <= j <= 128 in the same wave (lane ^ j/4: one
-  // shuffle per key, no LDS traffic, no barrier), and only the 10 steps with j >= 256 (of 78) go
-  // through LDS with workgroup barriers.  (All-LDS: 36 us per chunk; this: see DESIGN.md.)
-  KeyT v[PER_THREAD];
-#pragma unroll
-  for (int r = 0; r < PER_THREAD; ++r) v[r] = keys[tid * PER_THREAD + r];
-  static_assert(PER_THREAD == 4, "the register steps below are written for 4 keys per thread");
-  for (int k = 2; k <= ((sorted || (ablate & 1)) ? 0 : CH); k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      KeyT other[PER_THREAD];
-      if (j >= 256) {
-        __syncthreads();                                   // readers of the previous LDS step are done
-#pragma unroll
-        for (int r = 0; r < PER_THREAD; ++r) keys[tid * PER_THREAD + r] = v[r];
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < PER_THREAD; ++r) other[r] = keys[(tid * PER_THREAD + r) ^ j];
-      } else if (j >= 4) {
-#pragma unroll
-        for (int r = 0; r < PER_THREAD; ++r) other[r] = __shfl_xor(v[r], j >> 2, kWave);
-      } else if (j == 2) {
-        other[0] = v[2]; other[1] = v[3]; other[2] = v[0]; other[3] = v[1];
-      } else {
-        other[0] = v[1]; other[1] = v[0]; other[2] = v[3]; other[3] = v[2];
-      }
-#pragma unroll
-      for (int r = 0; r < PER_THREAD; ++r) {
-        const int p = tid * PER_THREAD + r;
-        const bool lower = (p & j) == 0;                   // this element is the lower index of its pair
-        const bool up = (p & k) == 0;                      // ascending sub-sequence
-        const KeyT lo = v[r] < other[r] ? v[r] : other[r], hi = v[r] < other[r] ? other[r] : v[r];
-        v[r] = (lower == up) ? lo : hi;
-      }
-    }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int r = 0; r < PER_THREAD; ++r) keys[tid * PER_THREAD + r] = v[r];
-  __syncthreads();
+  if (!sorted && !(ablate & 1)) radix_sort();                  // overflowing buckets: skew-proof path
 
   if (ablate & 2) return;
   // run heads over the valid prefix; thread owns PER_THREAD consecutive entries

@@ -391,12 +391,14 @@ def test_run_from_record_equals_load_then_run(fused):
         assert np.array_equal(results[0][0][k], results[1][0][k]), k
 
 
-@pytest.mark.parametrize("vocab", [3, 64, 65, 200, 1000, (1 << 20) - 2, (1 << 20) - 1, 3_000_000])
-def test_rowplan_key_widths_vs_oracle(vocab):
+@pytest.mark.parametrize("hot", [False, True])
+@pytest.mark.parametrize("vocab", [3, 64, 65, 128, 129, 200, 1000, 20000, (1 << 20) - 2, (1 << 20) - 1, 3_000_000])
+def test_rowplan_key_widths_vs_oracle(vocab, hot):
     """dfm_rowplan_build sorts 32-bit keys (id << 12 | pos) when every vocabulary is below 2^20 - 1 and
     64-bit keys otherwise: both against the oracle's ordered reduction, with duplicates, padding ids, the
-    largest id and an odd tail (two chunks).  Vocabularies of <= 64 ids take the counting-by-ballot sort,
-    65 / 200 the bucket ranking with long buckets or the bitonic network.  Bit-exact for every row with at most 64 contributions (summed
+    largest id and an odd tail (two chunks).  Vocabularies of <= 128 ids take one pass of the ballot-counting
+    radix sort, larger ones the bucket ranking, and with `hot` (40 % of the batch on three ids, the largest id among
+    them) the buckets overflow and the multi-pass radix sort runs (2 ... 4 passes, both key widths).  Bit-exact for every row with at most 64 contributions (summed
     in sample order); longer runs (the 50-id field: ~80 per row) go through the workgroup-wide fixed tree of
     rowgrad_body and are held to rounding."""
     from deepfm_amd import _lib
@@ -405,6 +407,9 @@ def test_rowplan_key_widths_vs_oracle(vocab):
     B, D, S, F = 5000, 16, 2, 3
     rng = np.random.default_rng(vocab % 977)
     ids = [rng.integers(1, vocab, size=B).astype(np.int64), rng.integers(1, min(vocab, 50), size=B).astype(np.int64)]
+    if hot:
+        pick = np.array([vocab - 1, max(1, vocab // 2), min(5, vocab - 1)], dtype=np.int64)
+        ids[0] = np.where(rng.random(B) < 0.4, pick[rng.integers(0, 3, size=B)], ids[0])
     ids[0][:7] = [vocab - 1, vocab - 1, 0, 1, 0, vocab - 1, 1]
     d_ids = [torch.from_numpy(a).cuda() for a in ids]
     ch = _lib.ROWPLAN_CHUNK
