@@ -325,6 +325,25 @@ __global__ __launch_bounds__(SORT_THREADS) void rowplan_sort(
     o_seg[total_u] = total_valid;
     num_uniq[list] = total_u;
   }
+  // runs of more than kSplitRun ids, for the row gradients to split over workgroups: listed in the free tail of
+  // seg_start (layout and reasons: tail_bodies.h::rowgrad_body).  Run lengths from the run starts in LDS.
+  if (total_u > CH - tail::kSplitRun) return;               // (then no run can be that long)
+  int* hstart = reinterpret_cast<int*>(keys + 2 * CH);
+  __shared__ int s_nsplit, s_split[tail::kMaxSplitRuns];
+  if (tid == 0) { s_nsplit = 0; hstart[total_u] = total_valid; }
+  slot = wave_off + incl - cnt;
+#pragma unroll
+  for (int r = 0; r < PER_THREAD; ++r)
+    if (head[r]) hstart[slot++] = e0 + r;
+  __syncthreads();
+  for (int j = tid; j < total_u; j += SORT_THREADS)
+    if (hstart[j + 1] - hstart[j] > tail::kSplitRun) s_split[atomicAdd(&s_nsplit, 1)] = j;
+  __syncthreads();
+  if (tid < s_nsplit) o_seg[CH - 1 - tid] = s_split[tid];
+  if (tid == 0) {
+    o_seg[CH] = s_nsplit;
+    o_seg[CH - 1 - tail::kMaxSplitRuns] = 0;                // arrival counter of the list's workgroups
+  }
 }
 
 __global__ __launch_bounds__(256) void rowgrad_kernel(

@@ -160,7 +160,23 @@ struct SampleSegments {
 // row, and one lane group walking them took 0.9 ms — are summed by the whole workgroup: 256 / (D/4) lane
 // groups take every (256 / (D/4))-th contribution each, the partial sums are added in group order (fixed
 // tree: still bitwise reproducible, 64 x shorter chain at D = 16).
+//
+// Runs of more than kSplitRun contributions — half a batch on one id: a default / missing-value category — are
+// summed by SEVERAL workgroups of the list (one workgroup alone takes 3-5 us per 512 contributions, 42 us for a
+// run of 4096, while the list's other 63 workgroups have nothing to do).  The row plan lists those runs (at
+// most one of 4096 ids) in the unused tail of the list's seg_start:
+//     seg[CH] = number of split runs (valid when num_uniq <= CH - kSplitRun; otherwise there are none)
+//     seg[CH - 1 - e] = entry u of split run e,   seg[CH - 1 - kMaxSplitRuns] = arrival counter (0)
+// Workgroup bl < nsl of the list sums slice bl of every split run (contributions p0 + bl*per ... , same lane
+// group tree as above) into row CH - 1 - (e * nsl + bl) of the list's row_g2 / row_g1 — rows behind
+// num_uniq, free because a split run of > 2048 contributions leaves > 2047 rows unused; the last workgroup to
+// arrive adds the nsl partial rows of every split run in slice order (fixed association again) and writes
+// the row.  This hand-over between workgroups costs ~10 us (three dependent trips to memory: partial rows
+// out, arrival counter, partial rows in), paid only by lists that have such a run.
 constexpr int kLongRun = 64;
+constexpr int kSplitRun = 2048;        // below this the hand-over costs more than it saves
+constexpr int kMaxSplitRuns = 2;        // > 4096 / 2049
+constexpr int kMaxSlices = 64;
 constexpr int kRowgradLds = 2048;       // floats: groups x (D + 4) = 1024 + 1024 / (D/4) <= 2048
 
 __device__ __forceinline__ void rowgrad_load(const float* __restrict__ g_field, const float* __restrict__ g_first,
@@ -178,23 +194,36 @@ __device__ __forceinline__ void rowgrad_load(const float* __restrict__ g_field, 
 // contributions pos[p], p = p0, p0 + step, ... < p1, added in that order; eight positions, then their eight
 // rows in flight at a time (the loads do not depend on each other — only the additions are ordered)
 constexpr int kRunBatch = 8;
+// agent-scope accesses for data handed from one workgroup to another inside a launch (tail of rowgrad_body)
+__device__ __forceinline__ void st_agent(float* p, float v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float ld_agent(const float* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ __forceinline__ void rowgrad_run(const float* __restrict__ g_field, const float* __restrict__ g_first,
                                             const int32_t* __restrict__ pos, int p0, int p1, int step, int F, int f,
                                             int D, int q, const SampleSegments& segs, float4& acc, float& acc1) {
   // every batch is predicated, the last one included: a tail walked one contribution at a time pays two
-  // dependent memory latencies per contribution (7 of a 31-long strided run cost more than its 3 batches)
+  // dependent memory latencies per contribution (7 of a 31-long strided run cost more than its 3 batches).
+  // The positions of the NEXT batch are requested before the rows of this one are waited for: a long run
+  // then pays one memory latency per batch instead of two (positions and rows both come from another XCD's
+  // kernel, i.e. from memory: ~2.5 us each).
+  int32_t b[kRunBatch];
+#pragma unroll
+  for (int u = 0; u < kRunBatch; ++u) b[u] = p0 + u * step < p1 ? pos[p0 + u * step] : 0;
   for (int p = p0; p < p1; p += kRunBatch * step) {
     float4 g[kRunBatch];
     float g1[kRunBatch];
-    int32_t b[kRunBatch];
-#pragma unroll
-    for (int u = 0; u < kRunBatch; ++u) b[u] = p + u * step < p1 ? pos[p + u * step] : 0;
 #pragma unroll
     for (int u = 0; u < kRunBatch; ++u) {
       g[u] = make_float4(0.f, 0.f, 0.f, 0.f);
       g1[u] = 0.f;
       if (p + u * step < p1) rowgrad_load(g_field, g_first, b[u], F, f, D, q, segs, g[u], g1[u]);
     }
+    const int pn = p + kRunBatch * step;
+#pragma unroll
+    for (int u = 0; u < kRunBatch; ++u) b[u] = pn + u * step < p1 ? pos[pn + u * step] : 0;
 #pragma unroll
     for (int u = 0; u < kRunBatch; ++u) {
       if (p + u * step < p1) {                   // (no "+ 0.f": -0.f + 0.f would turn into +0.f)
@@ -207,9 +236,10 @@ __device__ __forceinline__ void rowgrad_run(const float* __restrict__ g_field, c
 
 __device__ __forceinline__ void rowgrad_body(int blk, FieldMap fmap, int S, int F, int D, int lists, const float* __restrict__ g_first,
     const float* __restrict__ g_field, const int32_t* __restrict__ sorted_pos,
-    const int32_t* __restrict__ seg_start, const int32_t* __restrict__ num_uniq,
-    float* __restrict__ row_g2, float* __restrict__ row_g1, SampleSegments segs = SampleSegments{0, 0}) {
+    const int32_t* seg_start, const int32_t* __restrict__ num_uniq,
+    float* row_g2, float* row_g1, SampleSegments segs = SampleSegments{0, 0}) {
   __shared__ float red[kRowgradLds];
+  __shared__ int s_last;
   __shared__ int s_long, s_ent[kTailThreads], s_p0[kTailThreads], s_p1[kTailThreads];   // the workgroup's long runs
   const int lpr = D / 4, groups = kTailThreads / lpr;       // lane groups (= list entries) per workgroup
   // (lane groups that do not tile the workgroup — D/4 not a power of two — keep the linear mapping and the
@@ -231,20 +261,23 @@ __device__ __forceinline__ void rowgrad_body(int blk, FieldMap fmap, int S, int 
     list = entry / CH;
     u = static_cast<int>(entry % CH);
   }
-  const bool valid = threadIdx.x < groups * lpr && list < lists && u < num_uniq[list];
+  const int nu = list < lists ? num_uniq[list] : 0;
+  const bool valid = threadIdx.x < groups * lpr && u < nu;
+  const int32_t* seg = seg_start + (list < lists ? list : 0) * (CH + 1);
+  const int n_split = coop && nu > 0 && nu <= CH - kSplitRun ? seg[CH] : 0;     // uniform over the workgroup
   int p0 = 0, p1 = 0;
   if (valid) {
-    const int32_t* seg = seg_start + list * (CH + 1);
     p0 = seg[u]; p1 = seg[u + 1];
   }
   if (threadIdx.x == 0) s_long = 0;
   __syncthreads();
-  const bool is_long = coop && valid && p1 - p0 > kLongRun;
+  const bool is_split = coop && valid && p1 - p0 > kSplitRun;
+  const bool is_long = coop && valid && !is_split && p1 - p0 > kLongRun;
   if (is_long && q == 0) {                 // (the order of this list does not matter: the runs are independent)
     const int i = atomicAdd(&s_long, 1);
     s_ent[i] = u; s_p0[i] = p0; s_p1[i] = p1;
   }
-  if (valid && !is_long) {
+  if (valid && !is_long && !is_split) {
     const int f = fmap.f[static_cast<int>(list % S)];
     const int32_t* pos = sorted_pos + list * CH;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -254,7 +287,7 @@ __device__ __forceinline__ void rowgrad_body(int blk, FieldMap fmap, int S, int 
     if (q == 0) row_g1[list * CH + u] = acc1;
   }
   __syncthreads();
-  if (!s_long) return;                                      // uniform: the usual case ends here
+  if (!s_long && !n_split) return;                          // uniform: the usual case ends here
   // ---- long runs of this workgroup's entries, one after the other, by all lane groups ----
   // (found in LDS: asking global memory for every entry's run length again was 64 dependent loads, ~40 us)
   const int n_long = s_long;
@@ -284,6 +317,84 @@ __device__ __forceinline__ void rowgrad_body(int blk, FieldMap fmap, int S, int 
     }
     __syncthreads();
   }
+  if (!n_split) return;
+  // ---- split runs of the list: this workgroup's slice of each ----
+  const int nsl = nbl < kMaxSlices ? nbl : kMaxSlices, bl = blk % nbl;
+  if (bl >= nsl) return;
+  const int f = fmap.f[static_cast<int>(list % S)];
+  const int32_t* pos = sorted_pos + list * CH;
+  for (int e = 0; e < n_split; ++e) {
+    const int ue = seg[CH - 1 - e];
+    const int q0 = seg[ue], q1 = seg[ue + 1];
+    const int per = (q1 - q0 + nsl - 1) / nsl;
+    const int s0 = q0 + bl * per, s1 = s0 + per < q1 ? s0 + per : q1;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float acc1 = 0.f;
+    if (grp < groups) {
+      rowgrad_run(g_field, g_first, pos, s0 + grp, s1, groups, F, f, D, q, segs, acc, acc1);
+      st4(red + grp * (D + 4) + q * 4, acc);
+      if (q == 0) red[grp * (D + 4) + D] = acc1;
+    }
+    __syncthreads();
+    if (grp == 0) {
+      float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
+      float tot1 = 0.f;
+      for (int gi = 0; gi < groups; ++gi) {
+        const float4 v = ld4(red + gi * (D + 4) + q * 4);
+        tot.x += v.x; tot.y += v.y; tot.z += v.z; tot.w += v.w;
+        if (q == 0) tot1 += red[gi * (D + 4) + D];
+      }
+      const int64_t prow = list * CH + CH - 1 - (e * nsl + bl);
+      st_agent(row_g2 + prow * D + q * 4 + 0, tot.x);
+      st_agent(row_g2 + prow * D + q * 4 + 1, tot.y);
+      st_agent(row_g2 + prow * D + q * 4 + 2, tot.z);
+      st_agent(row_g2 + prow * D + q * 4 + 3, tot.w);
+      if (q == 0) st_agent(row_g1 + prow, tot1);
+    }
+    __syncthreads();
+  }
+  // hand-over: the list's workgroups sit on different XCDs = different, non-coherent L2s.  The partial rows
+  // are written and read with agent-scope accesses (write-through / L2-bypassing: a handful of floats), the
+  // barrier waits for the stores, then the arrival is counted.  (__threadfence() instead makes every
+  // workgroup write back and invalidate its XCD's whole L2: 133 us for this kernel.)
+  int* counter = const_cast<int*>(seg) + (CH - 1 - kMaxSplitRuns);
+  __syncthreads();
+  if (threadIdx.x == 0)
+    s_last = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nsl - 1 ? 1 : 0;
+  __syncthreads();
+  if (!s_last) return;
+  // the nsl partial rows of every split run: one row per lane group (all loads of a run in flight together —
+  // they come from memory, ~2 us each), then the same LDS tree as above
+  const int nred = groups < nsl ? groups : nsl;
+  for (int e = 0; e < n_split; ++e) {
+    const int ue = seg[CH - 1 - e];
+    if (grp < nred) {
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      float acc1 = 0.f;
+      for (int r = grp; r < nsl; r += groups) {
+        const int64_t prow = list * CH + CH - 1 - (e * nsl + r);
+        const float* pr = row_g2 + prow * D + q * 4;
+        acc.x += ld_agent(pr); acc.y += ld_agent(pr + 1); acc.z += ld_agent(pr + 2); acc.w += ld_agent(pr + 3);
+        if (q == 0) acc1 += ld_agent(row_g1 + prow);
+      }
+      st4(red + grp * (D + 4) + q * 4, acc);
+      if (q == 0) red[grp * (D + 4) + D] = acc1;
+    }
+    __syncthreads();
+    if (grp == 0) {
+      float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
+      float tot1 = 0.f;
+      for (int gi = 0; gi < nred; ++gi) {
+        const float4 v = ld4(red + gi * (D + 4) + q * 4);
+        tot.x += v.x; tot.y += v.y; tot.z += v.z; tot.w += v.w;
+        if (q == 0) tot1 += red[gi * (D + 4) + D];
+      }
+      st4(row_g2 + (list * CH + ue) * D + q * 4, tot);
+      if (q == 0) row_g1[list * CH + ue] = tot1;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (the row plan zeroes it too: this is for a plan used twice)
 }
 
 __device__ __forceinline__ int find_row(const int32_t* __restrict__ rows, int n, int32_t row) {

@@ -176,13 +176,18 @@ int dfm_embedding_backward_dense_fields(const dfm_embedding_plan* plan, const vo
  *   d_uniq_rows  (C, S, chunk) int32  distinct ids, ascending
  *   d_seg_start  (C, S, chunk+1) int32  first sorted entry of every distinct id
  *   d_num_uniq   (C, S) int32
+ * Entries of a list behind its num_uniq (+ 1 for d_seg_start) are working space of the library: the tail of
+ * d_seg_start carries the list's runs of more than half a chunk and an arrival counter for
+ * dfm_rowgrad_build, which sums such a run with several workgroups.
  * Depends on the ids only, so it can run ahead of the forward pass. */
 int dfm_rowplan_build(const int64_t* const* ids, const int32_t* vocab, int num_sparse, int64_t n,
                       int32_t* d_sorted_pos, int32_t* d_uniq_rows, int32_t* d_seg_start,
                       int32_t* d_num_uniq, int32_t* d_error_flag, dfm_stream_t stream);
 
-/* Row gradients of the distinct ids, contributions added in increasing sample order:
- *   d_row_g2 (C, S, chunk, dim)   d_row_g1 (C, S, chunk)
+/* Row gradients of the distinct ids, contributions added in increasing sample order (runs of more than 64
+ * contributions: by a fixed tree — reproducible run to run, equal to the sequential sum up to rounding):
+ *   d_row_g2 (C, S, chunk, dim)   d_row_g1 (C, S, chunk)      rows behind num_uniq: working space
+ * d_seg_start must come from dfm_rowplan_build (its tail is read, and its counter written).
  * `field_of_sparse[s]` is the schema position of sparse field s inside d_g_field
  * (B, F, dim); d_g_first is (B,1).  Uniform plans only (dim == fm_dim). */
 int dfm_rowgrad_build(const int32_t* field_of_sparse, int num_sparse, int num_fields, int dim,
