@@ -128,9 +128,10 @@ __device__ __forceinline__ void put_image(float* img, const f32x4 (&m)[NT][NT], 
 }
 // X^T[d][key] = sum_query Y[query][d] M[query][key] for M in the image (Y rows past the end count as 0);
 // X[key][:] goes to out[key * ldo + col0 + d].
+// frag[tk] = the row fragment X[key 16tk + c][4g ..] that was stored (keys past the end: 0).
 template <int NT>
-__device__ __forceinline__ void contract_queries(const float* img, const float (&ya)[NT][4],
-                                                 float* __restrict__ out, int64_t ldo, int col0, int F, int c, int g) {
+__device__ __forceinline__ void contract_queries(const float* img, const float (&ya)[NT][4], float* __restrict__ out,
+                                                 int64_t ldo, int col0, int F, int c, int g, float4 (&frag)[NT]) {
 #pragma unroll
   for (int tk = 0; tk < NT; ++tk) {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -139,8 +140,15 @@ __device__ __forceinline__ void contract_queries(const float* img, const float (
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc = mfma4(ya[tq][r], img[(16 * tq + 4 * g + r) * kTS + 16 * tk + c], acc);
     const int key = 16 * tk + c;
-    if (key < F) st4(out + static_cast<int64_t>(key) * ldo + col0 + 4 * g, make_float4(acc[0], acc[1], acc[2], acc[3]));
+    frag[tk] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    if (key < F) st4(out + static_cast<int64_t>(key) * ldo + col0 + 4 * g, frag[tk]);
   }
+}
+template <int NT>
+__device__ __forceinline__ void contract_queries(const float* img, const float (&ya)[NT][4], float* __restrict__ out,
+                                                 int64_t ldo, int col0, int F, int c, int g) {
+  float4 frag[NT];
+  contract_queries<NT>(img, ya, out, ldo, col0, F, c, g, frag);
 }
 
 template <int NT>
@@ -296,7 +304,7 @@ struct Proj {
   // row fragments of (x W^T + b)[:, r0 : r0 + 16], times `scale`
   __device__ __forceinline__ void transposed(const float4 (&wf)[KD], const float* __restrict__ bias, int r0, float scale,
                                              float4 (&out)[NT]) const {
-    const float4 b4 = ld4(bias + r0 + 4 * g);
+    const float4 b4 = bias ? ld4(bias + r0 + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);      // (no bias: uniform)
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       f32x4 acc = {b4.x, b4.y, b4.z, b4.w};
@@ -308,7 +316,7 @@ struct Proj {
   // out[t][r] = (x W^T + b)[token 16t + 4g + r][r0 + c]; tokens past the end: the bias alone, or 0 (zero_pad)
   __device__ __forceinline__ void direct(const float4 (&wf)[KD], const float* __restrict__ bias, int r0, int F,
                                          bool zero_pad, float (&out)[NT][4]) const {
-    const float bc = bias[r0 + c];
+    const float bc = bias ? bias[r0 + c] : 0.f;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       f32x4 acc = {bc, bc, bc, bc};
@@ -523,6 +531,148 @@ __global__ __launch_bounds__(kUnitsPerBlock * 64) void attn_qkv_mfma_bwd(
   contract_queries<NT>(img, ya, dbase, rs, A, F, c, g);         // dK^T = Q^T dS
 }
 
+// The backward of an _AttentionBlock from d y (the gradient of the output projection's result; with the residual
+// it is also the gradient that reaches x directly) to d x, in ONE launch for num_heads == 4 (workgroup = sample,
+// wave = head, as in attn_block_mfma_fwd): the head's d O = d y W_out[:, head] is formed in-kernel in both operand
+// forms (no (B*F, A) d_o tensor, no GEMM launch), the core backward runs as in attn_qkv_mfma_bwd, and d Q, d K,
+// d V — row fragments in the accumulators — are multiplied by the head's 16 rows of W_q, W_k, W_v on the spot:
+// the four heads' partial (F, D) results meet in LDS and d x = sum (+ d y) is written once.  d_qkv is still
+// written: the weight gradient d W_qkv = d_qkv^T x is a GEMM over the whole batch.
+template <int NT, int KD, bool RES>
+__global__ __launch_bounds__(kUnitsPerBlock * 64) void attn_block_mfma_bwd(
+    const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+    const float* __restrict__ wo, const float* __restrict__ g_y, int64_t B, int F, int A,
+    float* __restrict__ d_qkv, float* __restrict__ d_x) {
+  constexpr int D = 16 * KD, YS = D + 4, IS = kTS > YS ? kTS : YS;
+  extern __shared__ __attribute__((aligned(16))) float lds[];      // [4 heads][16 NT][IS]: transpose image, then d x part
+  const int lane = lane_id(), wave = wave_id_uniform();
+  const int64_t b = blockIdx.x;
+  const int h = wave;
+  const int c = lane & 15, g = lane >> 4;
+  const int64_t rs = 3 * static_cast<int64_t>(A);
+  float* dbase = d_qkv + b * F * rs + h * kHd;
+  float* img = lds + static_cast<size_t>(wave) * (16 * NT) * IS;
+  Proj<NT, KD> pj;
+  pj.load_x(x, b * F, F, D, c, g);
+  float4 wq[KD], wk[KD];
+  pj.load_w(w, h * kHd, D, wq);
+  pj.load_w(w, A + h * kHd, D, wk);
+  f32x4 pt[NT][NT], ds[NT][NT];
+  float gcol[NT][4];                                        // d O[token 16t + 4g + r][c]
+  {
+    float4 gf[NT];                                          // d O[token 16t + c][4g ..]
+    {
+      Proj<NT, KD> pg;
+      pg.load_x(g_y, b * F, F, D, c, g);
+      float4 wot[KD];                                       // W_out^T[h*16 + c][16kd + 4g ..]
+#pragma unroll
+      for (int kd = 0; kd < KD; ++kd) {
+        const float* p = wo + static_cast<int64_t>(16 * kd + 4 * g) * A + h * kHd + c;
+        wot[kd] = make_float4(p[0], p[A], p[2 * A], p[3 * static_cast<int64_t>(A)]);
+      }
+      pg.transposed(wot, nullptr, 0, 1.f, gf);
+      pg.direct(wot, nullptr, 0, F, true, gcol);
+    }
+    float4 qf[NT], kf[NT], vf[NT], wv[KD];
+    pj.load_w(w, 2 * A + h * kHd, D, wv);
+    pj.transposed(wq, bias, h * kHd, 0.25f, qf);
+    pj.transposed(wk, bias, A + h * kHd, 1.f, kf);
+    pj.transposed(wv, bias, 2 * A + h * kHd, 1.f, vf);
+    scores_softmax<NT>(kf, qf, F, g, pt);
+#pragma unroll
+    for (int tk = 0; tk < NT; ++tk)
+#pragma unroll
+      for (int tq = 0; tq < NT; ++tq) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        ds[tk][tq] = mfma_frag(vf[tk], gf[tq], acc);
+      }
+  }
+#pragma unroll
+  for (int tq = 0; tq < NT; ++tq) {
+    float dot = 0.f;
+#pragma unroll
+    for (int tk = 0; tk < NT; ++tk)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dot = fmaf(ds[tk][tq][r], pt[tk][tq][r], dot);
+    dot = rows4_sum(dot);
+#pragma unroll
+    for (int tk = 0; tk < NT; ++tk)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ds[tk][tq][r] = pt[tk][tq][r] * (ds[tk][tq][r] - dot) * 0.25f;
+  }
+  // d x part of this head: yp[t][et][r] = part[token 16t + 4g + r][16et + c], accumulated over Q, K, V
+  f32x4 yp[NT][KD];
+  // rows [r0, r0 + 16) of the stacked weight as the B operand of (tokens x 16) . (16 x D): W[r0 + 4g + kc][16et + c]
+  auto weight_cols = [&](int r0, float4 (&wc)[KD]) {
+#pragma unroll
+    for (int et = 0; et < KD; ++et) {
+      const float* p = w + static_cast<int64_t>(r0 + 4 * g) * D + 16 * et + c;
+      wc[et] = make_float4(p[0], p[D], p[2 * D], p[3 * D]);
+    }
+  };
+  float ya[NT][4];
+  {
+    float4 wc[KD];
+    weight_cols(h * kHd, wc);
+    pj.direct(wk, bias, A + h * kHd, F, false, ya);             // K, token on the contraction index (dS^T is 0 past the end)
+#pragma unroll
+    for (int tq = 0; tq < NT; ++tq) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int tk = 0; tk < NT; ++tk)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc = mfma4(ya[tk][r], ds[tk][tq][r], acc);
+      const int query = 16 * tq + c;
+      const float4 dq = make_float4(acc[0], acc[1], acc[2], acc[3]);
+      if (query < F) st4(dbase + static_cast<int64_t>(query) * rs + 4 * g, dq);
+#pragma unroll
+      for (int et = 0; et < KD; ++et) {
+        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        yp[tq][et] = mfma_frag(dq, wc[et], z);
+      }
+    }
+  }
+  {
+    float4 wc[KD], frag[NT];
+    weight_cols(2 * A + h * kHd, wc);
+    put_image<NT>(img, pt, c, g);
+    contract_queries<NT>(img, gcol, dbase, rs, 2 * A, F, c, g, frag);       // dV^T = dO^T P
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int et = 0; et < KD; ++et) yp[t][et] = mfma_frag(frag[t], wc[et], yp[t][et]);
+    weight_cols(A + h * kHd, wc);
+    pj.direct(wq, bias, h * kHd, F, true, ya);                  // unscaled Q, 0 past the end
+    put_image<NT>(img, ds, c, g);
+    contract_queries<NT>(img, ya, dbase, rs, A, F, c, g, frag);             // dK^T = Q^T dS
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int et = 0; et < KD; ++et) yp[t][et] = mfma_frag(frag[t], wc[et], yp[t][et]);
+  }
+  // (the image is this wave's own: its reads above are done before these writes in program order)
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int et = 0; et < KD; ++et)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) img[(16 * t + 4 * g + r) * IS + 16 * et + c] = yp[t][et][r];
+  __syncthreads();
+  constexpr int LPT = D <= 32 ? 32 : 64, RPP = 64 / LPT;
+  const int e = lane % LPT, sub = lane / LPT;
+  const bool elive = e < D;
+  for (int t0 = wave * RPP; t0 < F; t0 += kUnitsPerBlock * RPP) {
+    const int t = t0 + sub;
+    const bool live = elive && t < F;
+    const int tc = t < F ? t : F - 1;
+    const int64_t row = b * F + tc;
+    float v = (RES && elive) ? g_y[row * D + e] : 0.f;
+#pragma unroll
+    for (int hh = 0; hh < kUnitsPerBlock; ++hh) v += elive ? lds[(static_cast<size_t>(hh) * 16 * NT + tc) * IS + e] : 0.f;
+    if (live) d_x[row * D + e] = v;
+  }
+}
+
 }  // namespace
 
 namespace dfm {
@@ -632,6 +782,32 @@ int attn_block_mfma_forward(const float* x, const float* w, const float* bias, c
   if (D == 16 * K_)                                                                                                 \
     return res ? launch_block_fwd<K_, true>(x, w, bias, wo, bo, gamma, beta, eps, B, F, A, o, y, out, stats, out_group_stride, st) \
                : launch_block_fwd<K_, false>(x, w, bias, wo, bo, gamma, beta, eps, B, F, A, o, y, out, stats, out_group_stride, st)
+  DFM_KD(1); DFM_KD(2); DFM_KD(3); DFM_KD(4);
+#undef DFM_KD
+  return fail(DFM_ERR_UNSUPPORTED, "attention block kernel: embed_dim %d", D);
+}
+
+template <int KD, bool RES>
+static int launch_block_bwd(const float* x, const float* w, const float* bias, const float* wo, const float* g_y,
+                            int64_t B, int F, int A, float* d_qkv, float* d_x, hipStream_t st) {
+  const int nt = (F + 15) / 16;
+  constexpr int IS = kTS > 16 * KD + 4 ? kTS : 16 * KD + 4;
+  const size_t lds = sizeof(float) * kUnitsPerBlock * (16 * nt) * IS;
+  const dim3 grid(static_cast<unsigned>(B)), block(kUnitsPerBlock * 64);
+#define DFM_BLK(NT_)                                                                                              \
+  hipLaunchKernelGGL((attn_block_mfma_bwd<NT_, KD, RES>), grid, block, lds, st, x, w, bias, wo, g_y, B, F, A, d_qkv, d_x)
+  if (nt == 1) DFM_BLK(1); else if (nt == 2) DFM_BLK(2); else DFM_BLK(3);
+#undef DFM_BLK
+  DFM_LAUNCH_CHECK();
+  return DFM_OK;
+}
+
+int attn_block_mfma_backward(const float* x, const float* w, const float* bias, const float* wo, const float* g_y,
+                             bool residual, int64_t B, int F, int D, int A, float* d_qkv, float* d_x, hipStream_t st) {
+#define DFM_KD(K_)                                                                                     \
+  if (D == 16 * K_)                                                                                    \
+    return residual ? launch_block_bwd<K_, true>(x, w, bias, wo, g_y, B, F, A, d_qkv, d_x, st)         \
+                    : launch_block_bwd<K_, false>(x, w, bias, wo, g_y, B, F, A, d_qkv, d_x, st)
   DFM_KD(1); DFM_KD(2); DFM_KD(3); DFM_KD(4);
 #undef DFM_KD
   return fail(DFM_ERR_UNSUPPORTED, "attention block kernel: embed_dim %d", D);

@@ -235,22 +235,33 @@ class _AttnGemmFn(torch.autograd.Function):
         if not _weight_grad(g_y, o, M, D, A, d_wo, d_bo):
             _gemm(g_y, D, False, o, A, False, d_wo, D, A, M)                     # dWo = g_y^T O
             _gemm(g_y, D, False, ones_column(M, dev), 1, False, d_bo, D, 1, M)
-        d_o = torch.empty(M, A, dtype=torch.float32, device=dev)
-        _gemm(g_y, D, True, wo, A, False, d_o, M, A, D)                          # dO = g_y Wo
         d_qkv = torch.empty(M, 3 * A, dtype=torch.float32, device=dev)
-        if qkv is None:                                                          # Q, K, V recomputed from X in-kernel
-            _lib.check(lib.dfm_attention_qkv_core_backward(X.data_ptr(), w_qkv.data_ptr(), b_qkv.data_ptr(),
-                                                           d_o.data_ptr(), B, F, D, A, H, d_qkv.data_ptr(),
-                                                           _lib.stream_handle()))
-        else:
-            _lib.check(lib.dfm_attention_core_backward(qkv.data_ptr(), d_o.data_ptr(), B, F, A, H, d_qkv.data_ptr(),
-                                                       _lib.stream_handle()))
         d_wqkv = gq if direct else torch.empty(3 * A, D, dtype=torch.float32, device=dev)
         d_bqkv = gb.view(3 * A, 1) if direct else torch.empty(3 * A, 1, dtype=torch.float32, device=dev)
+        whole = (qkv is None and block.whole_block_kernel
+                 and lib.dfm_attention_block_supported(F, D, A, H) == 1)
+        if whole:                                                                # dO, the core and dX in one launch
+            d_x = torch.empty(M, D, dtype=torch.float32, device=dev)
+            _lib.check(lib.dfm_attention_block_backward(X.data_ptr(), w_qkv.data_ptr(), b_qkv.data_ptr(),
+                                                        wo.data_ptr(), g_y.data_ptr(), int(block.use_residual),
+                                                        B, F, D, A, H, d_qkv.data_ptr(), d_x.data_ptr(),
+                                                        _lib.stream_handle()))
+        else:
+            d_o = torch.empty(M, A, dtype=torch.float32, device=dev)
+            _gemm(g_y, D, True, wo, A, False, d_o, M, A, D)                      # dO = g_y Wo
+            if qkv is None:                                                      # Q, K, V recomputed from X in-kernel
+                _lib.check(lib.dfm_attention_qkv_core_backward(X.data_ptr(), w_qkv.data_ptr(), b_qkv.data_ptr(),
+                                                               d_o.data_ptr(), B, F, D, A, H, d_qkv.data_ptr(),
+                                                               _lib.stream_handle()))
+            else:
+                _lib.check(lib.dfm_attention_core_backward(qkv.data_ptr(), d_o.data_ptr(), B, F, A, H,
+                                                           d_qkv.data_ptr(), _lib.stream_handle()))
         if not _weight_grad(d_qkv, X, M, 3 * A, D, d_wqkv, d_bqkv):
             _gemm(d_qkv, 3 * A, False, X, D, False, d_wqkv, 3 * A, D, M)         # dWqkv = dQKV^T X
             _gemm(d_qkv, 3 * A, False, ones_column(M, dev), 1, False, d_bqkv, 3 * A, 1, M)
-        if block.use_residual:
+        if whole:
+            pass
+        elif block.use_residual:
             d_x = g_y                                                            # residual branch, then +=
             _gemm(d_qkv, 3 * A, True, w_qkv, D, False, d_x, M, D, 3 * A, accumulate=True)
         else:
