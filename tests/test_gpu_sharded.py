@@ -94,21 +94,34 @@ def _run(kind, sharded, use_graph, steps=4, B=512, V=300, D=16, spg=1):
     return _state(model, opt), losses
 
 
-def _close(a, b, what, rtol=2e-4):
+def _close(a, b, what, rtol=2e-4, max_bad=1e-3):
     a, b = a.double().cpu().numpy(), b.double().cpu().numpy()
     scale = max(np.abs(b).max(), 1e-30)
     err = np.abs(a - b)
     bad = err > rtol * np.abs(b) + 2e-6 * scale
-    assert bad.mean() <= 1e-3, f"{what}: {bad.sum()} / {bad.size} out of tolerance (max err {err.max():.3e}, scale {scale:.3e})"
+    assert bad.mean() <= max_bad, f"{what}: {bad.sum()} / {bad.size} out of tolerance (max err {err.max():.3e}, scale {scale:.3e})"
 
 
 @pytest.mark.parametrize("kind", ["deepfm", "xdeepfm", "attention_deepfm"])
 def test_one_rank_sharded_step_trains_like_the_fused_step(kind):
+    """Two steps: every parameter and moment within 2e-4 (measured: the first step is bit-identical, the second
+    differs by 1e-7 — the sharded step adds the tower's d-weight slabs in another order).  Four steps: the losses
+    agree to 1e-5 and all but a small fraction of the elements still do.  That fraction is Adam at lr = 1e-2
+    on parameters whose gradient is mathematically zero — the attention's K bias (softmax does not see a
+    shift of every key's score) and the last LayerNorm's bias (the tower's first BatchNorm removes a constant
+    input shift): their "gradient" is rounding noise, Adam turns its sign into a full step, and any two summation
+    orders drift apart by +-lr per step on those 16 + 64 values (and, through them, on ~0.2 % of the first
+    Linear's weights).  The reference's own Adam does the same."""
+    want, wl = _run(kind, sharded=False, use_graph=False, steps=2)
+    got, gl = _run(kind, sharded=True, use_graph=False, steps=2)
+    assert np.allclose(wl, gl, rtol=1e-6, atol=1e-7), (wl, gl)
+    for k in want:
+        _close(got[k], want[k], f"{kind} {k} after 2 steps", max_bad=0.0)
     want, wl = _run(kind, sharded=False, use_graph=False)
     got, gl = _run(kind, sharded=True, use_graph=False)
     assert np.allclose(wl, gl, rtol=1e-5, atol=1e-7), (wl, gl)
     for k in want:
-        _close(got[k], want[k], f"{kind} {k}")
+        _close(got[k], want[k], f"{kind} {k}", max_bad=5e-3 if kind == "attention_deepfm" else 1e-3)
     assert float((got["tables"] != 0).float().mean()) > 0.5
 
 
