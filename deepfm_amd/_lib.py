@@ -128,8 +128,9 @@ SIGNATURES = {
     "dfm_attention_qkv_core_forward": (_I, [_P, _P, _P, _L, _I, _I, _I, _I, _P, _P]),
     "dfm_attention_qkv_core_backward": (_I, [_P, _P, _P, _P, _L, _I, _I, _I, _I, _P, _P]),
     "dfm_attention_block_supported": (_I, [_I, _I, _I, _I]),
-    "dfm_attention_block_forward": (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _L, _I, _I, _I, _I, _P, _P, _P, _P, _L, _P]),
-    "dfm_attention_block_backward": (_I, [_P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _I, _P, _P, _P]),
+    "dfm_attention_block_forward": (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _L, _I, _I, _I, _I, _P, _P, _P, _P, _L, _P, _L,
+                                         _P]),
+    "dfm_attention_block_backward": (_I, [_P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _I, _P, _P, _P, _L, _P, _P, _P]),
     "dfm_layernorm_workspace_bytes": (_SZ, [_L, _I]),
     "dfm_layernorm_forward": (_I, [_P, _P, _L, _I, _P, _P, _F, _P, _P, _L, _L, _P]),
     "dfm_layernorm_backward": (_I, [_P, _P, _P, _P, _L, _I, _P, _P, _P, _P, _P, _L, _L, _P]),

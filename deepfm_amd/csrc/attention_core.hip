@@ -473,9 +473,11 @@ int attn_qkv_mfma_backward(const float* x, const float* w, const float* bias, co
 bool attn_block_mfma_supported(int F, int D, int A, int heads);
 int attn_block_mfma_forward(const float* x, const float* w, const float* bias, const float* wo, const float* bo,
                             const float* gamma, const float* beta, float eps, int64_t B, int F, int D, int A, float* o,
-                            float* y, float* out, float* stats, int64_t out_group_stride, hipStream_t st);
+                            float* y, float* out, float* stats, int64_t out_group_stride, float* x_copy,
+                            int64_t x_copy_stride, hipStream_t st);
 int attn_block_mfma_backward(const float* x, const float* w, const float* bias, const float* wo, const float* g_y,
-                             bool residual, int64_t B, int F, int D, int A, float* d_qkv, float* d_x, hipStream_t st);
+                             bool residual, int64_t B, int F, int D, int A, float* d_qkv, float* d_x,
+                             const AttnGradTail& tail, hipStream_t st);
 }  // namespace dfm
 
 // Attention core with the Q | K | V projection inside (attention_mfma.hip): x (B*F, D), stacked weight
@@ -508,7 +510,7 @@ extern "C" int dfm_attention_block_forward(const float* d_x, const float* d_w_qk
                                            const float* d_beta, float eps, int64_t batch, int num_fields,
                                            int embed_dim, int attention_dim, int num_heads, float* d_o, float* d_y,
                                            float* d_out, float* d_stats, int64_t out_group_stride,
-                                           dfm_stream_t stream) {
+                                           float* d_x_copy, int64_t x_copy_group_stride, dfm_stream_t stream) {
   DFM_REQUIRE(d_x && d_w_qkv && d_b_qkv && d_w_out && d_b_out && d_o && d_y && d_out, "null argument");
   DFM_REQUIRE((d_gamma == nullptr) == (d_beta == nullptr) && (d_gamma == nullptr || d_stats != nullptr),
               "residual LayerNorm needs gamma, beta and the statistics buffer together");
@@ -516,18 +518,22 @@ extern "C" int dfm_attention_block_forward(const float* d_x, const float* d_w_qk
               "unsupported shape (dfm_attention_block_supported)");
   DFM_REQUIRE(al16(d_x) && al16(d_w_qkv) && al16(d_b_qkv) && al16(d_w_out) && al16(d_o), "16-byte aligned buffers only");
   DFM_REQUIRE(out_group_stride == 0 || out_group_stride >= static_cast<int64_t>(num_fields) * embed_dim, "bad output grouping");
+  DFM_REQUIRE(!d_x_copy || x_copy_group_stride >= static_cast<int64_t>(num_fields) * embed_dim, "bad grouping of the input copy");
   DFM_REQUIRE(batch >= 0 && batch < (int64_t(1) << 31), "batch out of range");
   if (batch == 0) return DFM_OK;
   return attn_block_mfma_forward(d_x, d_w_qkv, d_b_qkv, d_w_out, d_b_out, d_gamma, d_beta, eps, batch, num_fields,
-                                 embed_dim, attention_dim, d_o, d_y, d_out, d_stats, out_group_stride,
-                                 as_stream(stream));
+                                 embed_dim, attention_dim, d_o, d_y, d_out, d_stats, out_group_stride, d_x_copy,
+                                 x_copy_group_stride, as_stream(stream));
 }
 
 extern "C" int dfm_attention_block_backward(const float* d_x, const float* d_w_qkv, const float* d_b_qkv,
                                             const float* d_w_out, const float* d_g_y, int residual, int64_t batch,
                                             int num_fields, int embed_dim, int attention_dim, int num_heads,
-                                            float* d_g_qkv, float* d_g_x, dfm_stream_t stream) {
+                                            float* d_g_qkv, float* d_g_x, const float* d_g_flat, int64_t ld_flat,
+                                            const float* d_g_fm, const float* d_fm_sum, dfm_stream_t stream) {
   DFM_REQUIRE(d_x && d_w_qkv && d_b_qkv && d_w_out && d_g_y && d_g_qkv && d_g_x, "null argument");
+  DFM_REQUIRE(!d_g_flat || ld_flat >= static_cast<int64_t>(num_fields) * embed_dim, "bad row stride of d_g_flat");
+  DFM_REQUIRE((d_g_fm == nullptr) == (d_fm_sum == nullptr), "the FM term needs d_g_fm and d_fm_sum together");
   DFM_REQUIRE(attn_block_mfma_supported(num_fields, embed_dim, attention_dim, num_heads),
               "unsupported shape (dfm_attention_block_supported)");
   DFM_REQUIRE(al16(d_x) && al16(d_w_qkv) && al16(d_b_qkv) && al16(d_g_y) && al16(d_g_qkv), "16-byte aligned buffers only");
@@ -535,7 +541,8 @@ extern "C" int dfm_attention_block_backward(const float* d_x, const float* d_w_q
   DFM_REQUIRE(batch >= 0 && batch < (int64_t(1) << 31), "batch out of range");
   if (batch == 0) return DFM_OK;
   return attn_block_mfma_backward(d_x, d_w_qkv, d_b_qkv, d_w_out, d_g_y, residual != 0, batch, num_fields, embed_dim,
-                                  attention_dim, d_g_qkv, d_g_x, as_stream(stream));
+                                  attention_dim, d_g_qkv, d_g_x, AttnGradTail{d_g_flat, ld_flat, d_g_fm, d_fm_sum},
+                                  as_stream(stream));
 }
 
 extern "C" int dfm_attention_qkv_core_backward(const float* d_x, const float* d_w_qkv, const float* d_b_qkv,

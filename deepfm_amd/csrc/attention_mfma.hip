@@ -375,13 +375,31 @@ __global__ __launch_bounds__(kUnitsPerBlock * 64) void attn_block_mfma_fwd(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
     const float* __restrict__ wo, const float* __restrict__ bo, const float* __restrict__ gamma,
     const float* __restrict__ beta, float eps, int64_t B, int F, int A, float* __restrict__ o, float* __restrict__ y,
-    float* __restrict__ out, float* __restrict__ stats, int64_t out_group_stride) {
+    float* __restrict__ out, float* __restrict__ stats, int64_t out_group_stride, float* __restrict__ x_copy,
+    int64_t x_copy_stride) {
   constexpr int D = 16 * KD, YS = D + 4;                  // row stride of the partial images
   extern __shared__ __attribute__((aligned(16))) float lds[];      // [4 heads][16 NT tokens][YS]
   const int lane = lane_id(), wave = wave_id_uniform();
   const int64_t b = blockIdx.x;                            // heads == kUnitsPerBlock: one sample per workgroup
   const int h = wave;
   const int c = lane & 15, g = lane >> 4;
+  // the last phase's operands (row t = (wave + 4 it) * RPP + sub, element e for this lane), requested now: at
+  // the end of a workgroup's life nothing hides their latency (see attn_block_mfma_bwd)
+  constexpr int LPT = D <= 32 ? 32 : 64, RPP = 64 / LPT;
+  constexpr int NIT = (16 * NT + kUnitsPerBlock * RPP - 1) / (kUnitsPerBlock * RPP);
+  constexpr bool kEarly = NIT <= 6;
+  const int e = lane % LPT, sub = lane / LPT;
+  const bool elive = e < D;
+  const float bo_e = elive ? bo[e] : 0.f;
+  const float ga = (RES && elive) ? gamma[e] : 0.f, be = (RES && elive) ? beta[e] : 0.f;
+  float xe[kEarly ? NIT : 1];
+  if (kEarly) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int t = (wave + kUnitsPerBlock * it) * RPP + sub;
+      xe[it] = ((RES || x_copy) && elive) ? x[(b * F + (t < F ? t : F - 1)) * D + e] : 0.f;
+    }
+  }
   {
     Proj<NT, KD> pj;
     pj.load_x(x, b * F, F, D, c, g);
@@ -421,13 +439,10 @@ __global__ __launch_bounds__(kUnitsPerBlock * 64) void attn_block_mfma_fwd(
   }
   __syncthreads();
   // rows of the sample, round-robin over the waves; LPT lanes per row (32 for D <= 32: two rows per pass)
-  constexpr int LPT = D <= 32 ? 32 : 64, RPP = 64 / LPT;
-  const int e = lane % LPT, sub = lane / LPT;
-  const bool elive = e < D;
-  const float bo_e = elive ? bo[e] : 0.f;
-  const float ga = (RES && elive) ? gamma[e] : 0.f, be = (RES && elive) ? beta[e] : 0.f;
-  for (int t0 = wave * RPP; t0 < F; t0 += kUnitsPerBlock * RPP) {
-    const int t = t0 + sub;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    if ((wave + kUnitsPerBlock * it) * RPP >= F) break;
+    const int t = (wave + kUnitsPerBlock * it) * RPP + sub;
     const bool live = elive && t < F;
     const int tc = t < F ? t : F - 1;
     float v = bo_e;
@@ -435,11 +450,15 @@ __global__ __launch_bounds__(kUnitsPerBlock * 64) void attn_block_mfma_fwd(
     for (int hh = 0; hh < kUnitsPerBlock; ++hh) v += elive ? lds[(static_cast<size_t>(hh) * 16 * NT + tc) * YS + e] : 0.f;
     const int64_t row = b * F + tc;
     if (live) y[row * D + e] = v;
+    // x_copy: the block's input rows again, sample b at x_copy + b * x_copy_stride (the DNN of AttentionDeepFM
+    // takes cat([attention(e), e]): the second half is written here instead of by a copy kernel)
+    const float xv = kEarly ? xe[it] : (((RES || x_copy) && elive) ? x[row * D + e] : 0.f);
+    if (x_copy && live) x_copy[b * x_copy_stride + static_cast<int64_t>(tc) * D + e] = xv;
     if (!RES) {
       if (live) out[out_group_stride ? b * out_group_stride + static_cast<int64_t>(tc) * D + e : row * D + e] = v;
       continue;
     }
-    const float s = elive ? v + x[row * D + e] : 0.f;
+    const float s = elive ? v + xv : 0.f;
     float mu = group_sum<16>(s);
     mu += __shfl_xor(mu, 16, kWave);
     if (LPT == 64) mu += __shfl_xor(mu, 32, kWave);
@@ -538,11 +557,15 @@ __global__ __launch_bounds__(kUnitsPerBlock * 64) void attn_qkv_mfma_bwd(
 // d V — row fragments in the accumulators — are multiplied by the head's 16 rows of W_q, W_k, W_v on the spot:
 // the four heads' partial (F, D) results meet in LDS and d x = sum (+ d y) is written once.  d_qkv is still
 // written: the weight gradient d W_qkv = d_qkv^T x is a GEMM over the whole batch.
+//
+// `tail` (optional, for the block that reads the field embeddings themselves): what else flows back into them in
+// AttentionDeepFM (attention_deepfm.py:48-66) — the flat half of the DNN's d input and the FM backward
+// g_fm * (S - e) (fm.py:18-23; this block's x IS e) — added before the one store, instead of a separate pass.
 template <int NT, int KD, bool RES>
 __global__ __launch_bounds__(kUnitsPerBlock * 64) void attn_block_mfma_bwd(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
     const float* __restrict__ wo, const float* __restrict__ g_y, int64_t B, int F, int A,
-    float* __restrict__ d_qkv, float* __restrict__ d_x) {
+    float* __restrict__ d_qkv, float* __restrict__ d_x, AttnGradTail tail) {
   constexpr int D = 16 * KD, YS = D + 4, IS = kTS > YS ? kTS : YS;
   extern __shared__ __attribute__((aligned(16))) float lds[];      // [4 heads][16 NT][IS]: transpose image, then d x part
   const int lane = lane_id(), wave = wave_id_uniform();
@@ -557,6 +580,27 @@ __global__ __launch_bounds__(kUnitsPerBlock * 64) void attn_block_mfma_bwd(
   float4 wq[KD], wk[KD];
   pj.load_w(w, h * kHd, D, wq);
   pj.load_w(w, A + h * kHd, D, wk);
+  // What the last phase adds to the heads' sum, requested NOW: with two workgroups per CU nothing hides a
+  // memory latency at the end of a workgroup's life (loaded there, these terms cost 20 us of the launch).
+  // The last phase gives row t = (wave + 4 it) * RPP + sub, element e to this lane.
+  constexpr int LPT = D <= 32 ? 32 : 64, RPP = 64 / LPT;
+  constexpr int NIT = (16 * NT + kUnitsPerBlock * RPP - 1) / (kUnitsPerBlock * RPP);
+  constexpr bool kEarly = NIT <= 6;                         // (embed_dim 64: 12 rows per lane — too many registers)
+  const int e = lane % LPT, sub = lane / LPT;
+  const bool elive = e < D;
+  float tl_gy[kEarly ? NIT : 1], tl_gf[kEarly ? NIT : 1], tl_x[kEarly ? NIT : 1];
+  const float tl_gfm = (tail.g_fm && elive) ? tail.g_fm[b] : 0.f;
+  const float tl_s = (tail.g_fm && elive) ? tail.fm_sum[b * D + e] : 0.f;
+  if (kEarly) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int t = (wave + kUnitsPerBlock * it) * RPP + sub;
+      const int64_t row = b * F + (t < F ? t : F - 1);
+      tl_gy[it] = (RES && elive) ? g_y[row * D + e] : 0.f;
+      tl_gf[it] = (tail.g_flat && elive) ? tail.g_flat[b * tail.ld_flat + (row - b * F) * D + e] : 0.f;
+      tl_x[it] = (tail.g_fm && elive) ? x[row * D + e] : 0.f;
+    }
+  }
   f32x4 pt[NT][NT], ds[NT][NT];
   float gcol[NT][4];                                        // d O[token 16t + 4g + r][c]
   {
@@ -658,17 +702,25 @@ __global__ __launch_bounds__(kUnitsPerBlock * 64) void attn_block_mfma_bwd(
 #pragma unroll
       for (int r = 0; r < 4; ++r) img[(16 * t + 4 * g + r) * IS + 16 * et + c] = yp[t][et][r];
   __syncthreads();
-  constexpr int LPT = D <= 32 ? 32 : 64, RPP = 64 / LPT;
-  const int e = lane % LPT, sub = lane / LPT;
-  const bool elive = e < D;
-  for (int t0 = wave * RPP; t0 < F; t0 += kUnitsPerBlock * RPP) {
-    const int t = t0 + sub;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int t = (wave + kUnitsPerBlock * it) * RPP + sub;
+    if ((wave + kUnitsPerBlock * it) * RPP >= F) break;
     const bool live = elive && t < F;
     const int tc = t < F ? t : F - 1;
     const int64_t row = b * F + tc;
-    float v = (RES && elive) ? g_y[row * D + e] : 0.f;
+    float v, gf, xv;
+    if (kEarly) {
+      v = tl_gy[it]; gf = tl_gf[it]; xv = tl_x[it];
+    } else {
+      v = (RES && elive) ? g_y[row * D + e] : 0.f;
+      gf = (tail.g_flat && elive) ? tail.g_flat[b * tail.ld_flat + static_cast<int64_t>(tc) * D + e] : 0.f;
+      xv = (tail.g_fm && elive) ? x[row * D + e] : 0.f;
+    }
 #pragma unroll
     for (int hh = 0; hh < kUnitsPerBlock; ++hh) v += elive ? lds[(static_cast<size_t>(hh) * 16 * NT + tc) * IS + e] : 0.f;
+    v += gf;
+    v += tl_gfm * (tl_s - xv);
     if (live) d_x[row * D + e] = v;
   }
 }
@@ -761,13 +813,14 @@ bool attn_block_mfma_supported(int F, int D, int A, int heads) {
 template <int KD, bool RES>
 static int launch_block_fwd(const float* x, const float* w, const float* bias, const float* wo, const float* bo,
                             const float* gamma, const float* beta, float eps, int64_t B, int F, int A, float* o,
-                            float* y, float* out, float* stats, int64_t out_group_stride, hipStream_t st) {
+                            float* y, float* out, float* stats, int64_t out_group_stride, float* x_copy,
+                            int64_t x_copy_stride, hipStream_t st) {
   const int nt = (F + 15) / 16;
   const size_t lds = sizeof(float) * kUnitsPerBlock * (16 * nt) * (16 * KD + 4);
   const dim3 grid(static_cast<unsigned>(B)), block(kUnitsPerBlock * 64);
 #define DFM_BLK(NT_)                                                                                              \
   hipLaunchKernelGGL((attn_block_mfma_fwd<NT_, KD, RES>), grid, block, lds, st, x, w, bias, wo, bo, gamma, beta, eps, \
-                     B, F, A, o, y, out, stats, out_group_stride)
+                     B, F, A, o, y, out, stats, out_group_stride, x_copy, x_copy_stride)
   if (nt == 1) DFM_BLK(1); else if (nt == 2) DFM_BLK(2); else DFM_BLK(3);
 #undef DFM_BLK
   DFM_LAUNCH_CHECK();
@@ -776,12 +829,13 @@ static int launch_block_fwd(const float* x, const float* w, const float* bias, c
 
 int attn_block_mfma_forward(const float* x, const float* w, const float* bias, const float* wo, const float* bo,
                             const float* gamma, const float* beta, float eps, int64_t B, int F, int D, int A, float* o,
-                            float* y, float* out, float* stats, int64_t out_group_stride, hipStream_t st) {
+                            float* y, float* out, float* stats, int64_t out_group_stride, float* x_copy,
+                            int64_t x_copy_stride, hipStream_t st) {
   const bool res = gamma != nullptr;
 #define DFM_KD(K_)                                                                                                  \
   if (D == 16 * K_)                                                                                                 \
-    return res ? launch_block_fwd<K_, true>(x, w, bias, wo, bo, gamma, beta, eps, B, F, A, o, y, out, stats, out_group_stride, st) \
-               : launch_block_fwd<K_, false>(x, w, bias, wo, bo, gamma, beta, eps, B, F, A, o, y, out, stats, out_group_stride, st)
+    return res ? launch_block_fwd<K_, true>(x, w, bias, wo, bo, gamma, beta, eps, B, F, A, o, y, out, stats, out_group_stride, x_copy, x_copy_stride, st) \
+               : launch_block_fwd<K_, false>(x, w, bias, wo, bo, gamma, beta, eps, B, F, A, o, y, out, stats, out_group_stride, x_copy, x_copy_stride, st)
   DFM_KD(1); DFM_KD(2); DFM_KD(3); DFM_KD(4);
 #undef DFM_KD
   return fail(DFM_ERR_UNSUPPORTED, "attention block kernel: embed_dim %d", D);
@@ -789,13 +843,14 @@ int attn_block_mfma_forward(const float* x, const float* w, const float* bias, c
 
 template <int KD, bool RES>
 static int launch_block_bwd(const float* x, const float* w, const float* bias, const float* wo, const float* g_y,
-                            int64_t B, int F, int A, float* d_qkv, float* d_x, hipStream_t st) {
+                            int64_t B, int F, int A, float* d_qkv, float* d_x, const AttnGradTail& tail,
+                            hipStream_t st) {
   const int nt = (F + 15) / 16;
   constexpr int IS = kTS > 16 * KD + 4 ? kTS : 16 * KD + 4;
   const size_t lds = sizeof(float) * kUnitsPerBlock * (16 * nt) * IS;
   const dim3 grid(static_cast<unsigned>(B)), block(kUnitsPerBlock * 64);
 #define DFM_BLK(NT_)                                                                                              \
-  hipLaunchKernelGGL((attn_block_mfma_bwd<NT_, KD, RES>), grid, block, lds, st, x, w, bias, wo, g_y, B, F, A, d_qkv, d_x)
+  hipLaunchKernelGGL((attn_block_mfma_bwd<NT_, KD, RES>), grid, block, lds, st, x, w, bias, wo, g_y, B, F, A, d_qkv, d_x, tail)
   if (nt == 1) DFM_BLK(1); else if (nt == 2) DFM_BLK(2); else DFM_BLK(3);
 #undef DFM_BLK
   DFM_LAUNCH_CHECK();
@@ -803,11 +858,12 @@ static int launch_block_bwd(const float* x, const float* w, const float* bias, c
 }
 
 int attn_block_mfma_backward(const float* x, const float* w, const float* bias, const float* wo, const float* g_y,
-                             bool residual, int64_t B, int F, int D, int A, float* d_qkv, float* d_x, hipStream_t st) {
+                             bool residual, int64_t B, int F, int D, int A, float* d_qkv, float* d_x,
+                             const AttnGradTail& tail, hipStream_t st) {
 #define DFM_KD(K_)                                                                                     \
   if (D == 16 * K_)                                                                                    \
-    return residual ? launch_block_bwd<K_, true>(x, w, bias, wo, g_y, B, F, A, d_qkv, d_x, st)         \
-                    : launch_block_bwd<K_, false>(x, w, bias, wo, g_y, B, F, A, d_qkv, d_x, st)
+    return residual ? launch_block_bwd<K_, true>(x, w, bias, wo, g_y, B, F, A, d_qkv, d_x, tail, st)   \
+                    : launch_block_bwd<K_, false>(x, w, bias, wo, g_y, B, F, A, d_qkv, d_x, tail, st)
   DFM_KD(1); DFM_KD(2); DFM_KD(3); DFM_KD(4);
 #undef DFM_KD
   return fail(DFM_ERR_UNSUPPORTED, "attention block kernel: embed_dim %d", D);

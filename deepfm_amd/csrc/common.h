@@ -81,4 +81,12 @@ __device__ __forceinline__ int64_t checked_id(int64_t id, int vocab, int32_t* er
   return id;
 }
 
+// Optional extra terms of attn_block_mfma_bwd's d x (attention_mfma.hip); all null: none.
+struct AttnGradTail {
+  const float* g_flat;         // (B, >= F*D) rows at stride ld_flat
+  int64_t ld_flat;
+  const float* g_fm;           // (B)
+  const float* fm_sum;         // (B, D)
+};
+
 }  // namespace dfm

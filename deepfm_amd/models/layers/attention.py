@@ -153,10 +153,14 @@ class _AttnGemmFn(torch.autograd.Function):
                 out = into[0] if into is not None else torch.empty(M, D, dtype=torch.float32, device=x.device)
             else:
                 out = y
+            # x_copy_into (fused training step): (data_ptr, row stride) of a second home of the block's input rows
+            xc = getattr(ctx, "x_copy_into", None)
             _lib.check(lib.dfm_attention_block_forward(
                 X.data_ptr(), w_qkv.data_ptr(), b_qkv.data_ptr(), wo.data_ptr(), bo.data_ptr(), _lib.ptr(gamma),
                 _lib.ptr(beta), float(block.layer_norm.eps) if block.use_residual else 0.0, B, F, D, A, H, o.data_ptr(),
-                y.data_ptr(), out.data_ptr(), _lib.ptr(stats), into[1] if into is not None else 0, _lib.stream_handle()))
+                y.data_ptr(), out.data_ptr(), _lib.ptr(stats), into[1] if into is not None else 0,
+                xc[0] if xc else None, xc[1] if xc else 0, _lib.stream_handle()))
+            ctx.x_copied = xc is not None
             ctx.block, ctx.dims = block, (B, F, D, A, H)
             ctx.save_for_backward(X, None, o, y, stats, w_qkv, wo, gamma, b_qkv)
             return out if into is not None else out.view(B, F, D)
@@ -241,11 +245,16 @@ class _AttnGemmFn(torch.autograd.Function):
         whole = (qkv is None and block.whole_block_kernel
                  and lib.dfm_attention_block_supported(F, D, A, H) == 1)
         if whole:                                                                # dO, the core and dX in one launch
-            d_x = torch.empty(M, D, dtype=torch.float32, device=dev)
-            _lib.check(lib.dfm_attention_block_backward(X.data_ptr(), w_qkv.data_ptr(), b_qkv.data_ptr(),
-                                                        wo.data_ptr(), g_y.data_ptr(), int(block.use_residual),
-                                                        B, F, D, A, H, d_qkv.data_ptr(), d_x.data_ptr(),
-                                                        _lib.stream_handle()))
+            # grad_tail (fused training step, first block): dict(out, g_flat, ld_flat, g_fm, fm_sum) — the other
+            # gradients of the field embeddings, added in the kernel's one store of d x (-> ctx.tail_done)
+            tail = getattr(ctx, "grad_tail", None)
+            d_x = tail["out"].view(M, D) if tail else torch.empty(M, D, dtype=torch.float32, device=dev)
+            _lib.check(lib.dfm_attention_block_backward(
+                X.data_ptr(), w_qkv.data_ptr(), b_qkv.data_ptr(), wo.data_ptr(), g_y.data_ptr(),
+                int(block.use_residual), B, F, D, A, H, d_qkv.data_ptr(), d_x.data_ptr(),
+                tail["g_flat"] if tail else None, tail["ld_flat"] if tail else 0,
+                tail["g_fm"] if tail else None, tail["fm_sum"] if tail else None, _lib.stream_handle()))
+            ctx.tail_done = tail is not None
         else:
             d_o = torch.empty(M, A, dtype=torch.float32, device=dev)
             _gemm(g_y, D, True, wo, A, False, d_o, M, A, D)                      # dO = g_y Wo

@@ -405,11 +405,14 @@ class FusedAttentionDeepFMStep(_FusedTowerStep):
             ctx.direct = True          # parameter gradients straight into the flat buffer's .grad views
             if block is last and block.use_residual:
                 ctx.out_into = (self.xcat, 2 * FD)
+            if block is self.blocks[0]:    # its input IS fe: the whole-block kernel writes the flat half of xcat too
+                ctx.x_copy_into = (self.xcat.data_ptr() + FD * 4, 2 * FD)
             x = _AttnGemmFn.forward(ctx, block, x, *block._param_list())
             self._ctxs.append(ctx)
         if not last.use_residual:
             _lib.check(lib.dfm_copy_2d(x.data_ptr(), FD, self.xcat.data_ptr(), 2 * FD, self.B, FD, st))
-        _lib.check(lib.dfm_copy_2d(self.fe.data_ptr(), FD, self.xcat.data_ptr() + FD * 4, 2 * FD, self.B, FD, st))
+        if not getattr(self._ctxs[0], "x_copied", False):
+            _lib.check(lib.dfm_copy_2d(self.fe.data_ptr(), FD, self.xcat.data_ptr() + FD * 4, 2 * FD, self.B, FD, st))
         return self.fm
 
     def _interaction_backward(self):
@@ -426,12 +429,18 @@ class FusedAttentionDeepFMStep(_FusedTowerStep):
         else:
             g = self.g_att.view(B, F, D)
             _lib.check(_lib.load().dfm_copy_2d(self.g_xcat.data_ptr(), 2 * FD, g.data_ptr(), FD, B, FD, _lib.stream_handle()))
+        # the first block's d x is d fe once the DNN's flat half and the FM backward are added: its whole-block
+        # kernel does that in its one store (else: dfm_embedding_grad_combine below)
+        self._ctxs[0].grad_tail = dict(out=self.g_fe, g_flat=self.g_xcat.data_ptr() + FD * 4, ld_flat=2 * FD,
+                                       g_fm=self.g_logits.data_ptr(), fm_sum=self.fm_sum.data_ptr())
         for block, ctx in zip(reversed(self.blocks), reversed(self._ctxs)):
             out = _AttnGemmFn.backward(ctx, g)
             g = out[1]
             if len(out) > 2:           # the flat buffer is not laid out for direct writes: add the temporaries
                 ps = block._param_list()
                 torch._foreach_add_([p.grad for p in ps], [t.view_as(p) for t, p in zip(out[2:], ps)])
+        if getattr(self._ctxs[0], "tail_done", False):
+            return
         _lib.check(_lib.load().dfm_embedding_grad_combine(
             self.g_xcat.data_ptr() + FD * 4, 2 * FD, g.data_ptr(), self.g_logits.data_ptr(), self.fm_sum.data_ptr(),
             self.fe.data_ptr(), B, F, D, self.g_fe.data_ptr(), _lib.stream_handle()))

@@ -361,15 +361,22 @@ int dfm_attention_block_forward(const float* d_x, const float* d_w_qkv, const fl
                                 const float* d_b_out, const float* d_gamma, const float* d_beta, float eps,
                                 int64_t batch, int num_fields, int embed_dim, int attention_dim, int num_heads,
                                 float* d_o, float* d_y, float* d_out, float* d_stats, int64_t out_group_stride,
-                                dfm_stream_t stream);
-/* The backward of the same block from d_g_y (gradient of the output projection's result y; residual != 0: also
+                                float* d_x_copy, int64_t x_copy_group_stride, dfm_stream_t stream);
+/* (d_x_copy, optional: the block's input rows once more, sample b at d_x_copy + b * x_copy_group_stride — the
+ * second half of AttentionDeepFM's cat([attention(e), e]), attention_deepfm.py:57-61, without a copy pass.)
+ * The backward of the same block from d_g_y (gradient of the output projection's result y; residual != 0: also
  * the gradient reaching x through the residual) to d_g_x (batch * num_fields, embed_dim), in ONE launch: the
  * head's d O = d y W_out[:, head], the core backward, and d x = d Q W_q + d K W_k + d V W_v (+ d y) all stay in
  * the kernel.  d_g_qkv (batch * num_fields, 3 * attention_dim) is written for the weight-gradient GEMM
- * d W_qkv = d_g_qkv^T x; d W_out = d_g_y^T o is a GEMM on the forward's d_o.  d_g_x must not alias an input. */
+ * d W_qkv = d_g_qkv^T x; d W_out = d_g_y^T o is a GEMM on the forward's d_o.  d_g_x must not alias an input.
+ * Optional further terms of d_g_x for the block that reads the field embeddings themselves (what
+ * dfm_embedding_grad_combine adds in a pass of its own): d_g_flat (rows of num_fields * embed_dim floats at
+ * stride ld_flat: the flat half of the DNN's d input) and the FM backward d_g_fm[b] * (d_fm_sum[b, :] - x). */
 int dfm_attention_block_backward(const float* d_x, const float* d_w_qkv, const float* d_b_qkv, const float* d_w_out,
                                  const float* d_g_y, int residual, int64_t batch, int num_fields, int embed_dim,
-                                 int attention_dim, int num_heads, float* d_g_qkv, float* d_g_x, dfm_stream_t stream);
+                                 int attention_dim, int num_heads, float* d_g_qkv, float* d_g_x,
+                                 const float* d_g_flat, int64_t ld_flat, const float* d_g_fm, const float* d_fm_sum,
+                                 dfm_stream_t stream);
 size_t dfm_layernorm_workspace_bytes(int64_t rows, int dim);
 /* out_group_rows > 0: output row r is written at d_out + (r / out_group_rows) * out_group_stride +
  * (r % out_group_rows) * dim (the attention output as the first half of the DNN's concatenated input,
