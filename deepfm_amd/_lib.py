@@ -140,6 +140,7 @@ SIGNATURES = {
     "dfm_bn_bwd_workspace_bytes": (_SZ, [_L, _I]),
     "dfm_bn_backward_apply": (_I, [C.POINTER(BnBwd), _L, _I, C.POINTER(HeadTail), _P, _P]),
     "dfm_head_bce": (_I, [_P, _L, _I, _P, _P, _P, _P, _P, _P, _P, C.POINTER(BnBwd), _P]),
+    "dfm_head_bn_bce": (_I, [_P, _P, _P, _P, _P, _F, _F, _L, _I, _P, _P, _P, _P, _P, _P, _P, C.POINTER(BnBwd), _P]),
     "dfm_linear_backward_workspace_bytes": (_SZ, [_L, _I, _I]),
     "dfm_linear_backward": (_I, [_P, _L, _I, _P, _I, _P, _P, C.POINTER(BnBwd), C.POINTER(FmBwd), _I, _P, _P]),
     "dfm_linear_backward_finish": (_I, [C.POINTER(SlabRef), _I, _P]),

@@ -118,6 +118,36 @@ __device__ __forceinline__ void row_lane_totals(float4& a, float4& b, float (*re
   a = ta; b = tb;
 }
 
+// Batch statistics of four columns from the merged sums (s1 = sum cnt * (tile mean - shift), s2 = sum of the
+// tiles' M2 about the shift), and the running statistics' update.  Shared by bn_relu_dropout_apply_kernel and the
+// head kernel that does the same work in its prologue; contraction is OFF here so that both get the same bits
+// whatever the surrounding code lets the compiler fuse.
+__device__ __forceinline__ void finish_column_stats(const float4& s1, const float4& s2, const float4& shift, int M,
+                                                    float eps, float (&mu)[4], float (&rs)[4], float (&var)[4]) {
+#pragma clang fp contract(off)
+  const float invM = 1.f / static_cast<float>(M);
+  const float s1a[4] = {s1.x, s1.y, s1.z, s1.w}, s2a[4] = {s2.x, s2.y, s2.z, s2.w};
+  const float sh[4] = {shift.x, shift.y, shift.z, shift.w};
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const float d = s1a[u] * invM;               // mean - shift
+    mu[u] = sh[u] + d;
+    var[u] = fmaxf(s2a[u] * invM - d * d, 0.f);  // biased, as BN normalises
+    rs[u] = rsqrtf(var[u] + eps);
+  }
+}
+__device__ __forceinline__ void update_running_stats(float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                     int c, const float (&mu)[4], const float (&var)[4], int M,
+                                                     float momentum) {
+#pragma clang fp contract(off)
+  const float unb = M > 1 ? static_cast<float>(M) / static_cast<float>(M - 1) : 1.f;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    running_mean[c + u] = (1.f - momentum) * running_mean[c + u] + momentum * mu[u];
+    running_var[c + u] = (1.f - momentum) * running_var[c + u] + momentum * var[u] * unb;
+  }
+}
+
 }  // namespace
 
 // =====================================================================================
@@ -193,28 +223,12 @@ __global__ __launch_bounds__(kApThreads) void bn_relu_dropout_apply_kernel(
     s2.z += fmaf(cnt * dz, dz, qt.z); s2.w += fmaf(cnt * dw, dw, qt.w);
   }
   row_lane_totals(s1, s2, red);
-  const float invM = 1.f / static_cast<float>(M);
   float mu[4], rs[4], var[4];
-  const float s1a[4] = {s1.x, s1.y, s1.z, s1.w}, s2a[4] = {s2.x, s2.y, s2.z, s2.w};
-  const float sh[4] = {m0v.x, m0v.y, m0v.z, m0v.w};
-#pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const float d = s1a[u] * invM;               // mean - shift
-    mu[u] = sh[u] + d;
-    var[u] = fmaxf(s2a[u] * invM - d * d, 0.f);  // biased, as BN normalises
-    rs[u] = rsqrtf(var[u] + eps);
-  }
+  finish_column_stats(s1, s2, m0v, M, eps, mu, rs, var);
   if (blockIdx.y == 0 && rl == 0 && okc) {
     st4(mean_rstd + c, make_float4(mu[0], mu[1], mu[2], mu[3]));
     st4(mean_rstd + N + c, make_float4(rs[0], rs[1], rs[2], rs[3]));
-    if (running_mean) {
-      const float unb = M > 1 ? static_cast<float>(M) / static_cast<float>(M - 1) : 1.f;
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        running_mean[c + u] = (1.f - momentum) * running_mean[c + u] + momentum * mu[u];
-        running_var[c + u] = (1.f - momentum) * running_var[c + u] + momentum * var[u] * unb;
-      }
-    }
+    if (running_mean) update_running_stats(running_mean, running_var, c, mu, var, M, momentum);
     if (blockIdx.x == 0 && cl == 0 && num_batches) num_batches[0] += 1;
   }
   if (!okc) return;
@@ -331,25 +345,89 @@ constexpr int kHeadMaxChunks = 8;                        // K <= 256
 
 // partials per workgroup (merged by bn_bwd_apply): [3][K] column sums (dy, dy*xhat, dlogit*a),
 // then loss and dlogit sums, padded to 3K + 4 floats
-template <int CH>   // CH = K / 32 float4 chunks per lane
+// What bn_relu_dropout_apply_kernel needs beyond a BnBwd when the head does its work (FUSE).
+struct BnFwdTail {
+  const float* partial;     // per-tile column statistics of linear_bn_fwd
+  float* mean_rstd;         // written by workgroup 0
+  float* running_mean;
+  float* running_var;
+  int64_t* num_batches;
+  float momentum, eps;
+};
+
+// FUSE: the last BatchNorm -> ReLU -> Dropout of the tower happens HERE instead of in a
+// bn_relu_dropout_apply launch of its own: every workgroup merges the tile statistics of all K columns (what
+// each workgroup of that launch did for its 64 columns: the same loads, the same order, the same numbers),
+// a = dropout(relu(gamma * (z - mean) * rstd + beta)) is formed in registers from z and never stored — the
+// backward wants z, the statistics and the mask, not a.  One launch (~5 us) less per step.
+template <int CH, bool FUSE>   // CH = K / 32 float4 chunks per lane
 __global__ __launch_bounds__(kHeadThreads) void head_bce_kernel(
     const float* __restrict__ a, int M, const float* __restrict__ w, const float* __restrict__ b,
     const float* __restrict__ fo, const float* __restrict__ fm, const float* __restrict__ labels,
     float* __restrict__ logits, float* __restrict__ dlogit, float* __restrict__ g_a, BnBwd bn, int has_bn,
-    float* __restrict__ hpart) {
+    float* __restrict__ hpart, BnFwdTail ft) {
   constexpr int K = CH * 32;
   constexpr int P = 3 * K + 4;
   __shared__ float red[kHeadThreads / kWave][P];
+  __shared__ __attribute__((aligned(16))) float s_mu[FUSE ? K : 4], s_rs[FUSE ? K : 4];
   const int tid = threadIdx.x, l8 = tid & (kHeadLPR - 1), rl = tid / kHeadLPR;
   const int m = blockIdx.x * kHeadRows + rl;
   const bool live = m < M;
   const int mc = live ? m : M - 1;
+  if (FUSE) {
+    static_assert(kHeadThreads == kApThreads, "the statistics merge uses the apply kernel's thread layout");
+    __shared__ float mred[2][kApRowLanes][kApCols];
+    const int cl = tid & 15, ml = tid >> 4;
+    const int T = (M + 31) / 32;
+    for (int c0 = 0; c0 < K; c0 += kApCols) {
+      const int c = c0 + cl * 4;
+      const bool okc = c < K;
+      const int cc = okc ? c : 0;
+      const float4 m0v = ld4(ft.partial + cc);
+      float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+#pragma unroll 4
+      for (int t = ml; t < T; t += kApRowLanes) {
+        const float cnt = static_cast<float>(M - 32 * t < 32 ? M - 32 * t : 32);
+        const float4 mt = ld4(ft.partial + (static_cast<int64_t>(t) * 2 + 0) * K + cc);
+        const float4 qt = ld4(ft.partial + (static_cast<int64_t>(t) * 2 + 1) * K + cc);
+        const float dx = mt.x - m0v.x, dy = mt.y - m0v.y, dz = mt.z - m0v.z, dw = mt.w - m0v.w;
+        s1.x = fmaf(cnt, dx, s1.x); s1.y = fmaf(cnt, dy, s1.y); s1.z = fmaf(cnt, dz, s1.z); s1.w = fmaf(cnt, dw, s1.w);
+        s2.x += fmaf(cnt * dx, dx, qt.x); s2.y += fmaf(cnt * dy, dy, qt.y);
+        s2.z += fmaf(cnt * dz, dz, qt.z); s2.w += fmaf(cnt * dw, dw, qt.w);
+      }
+      row_lane_totals(s1, s2, mred);
+      float mu[4], rs[4], var[4];
+      finish_column_stats(s1, s2, m0v, M, ft.eps, mu, rs, var);
+      if (ml == 0 && okc) {
+        st4(s_mu + c, make_float4(mu[0], mu[1], mu[2], mu[3]));
+        st4(s_rs + c, make_float4(rs[0], rs[1], rs[2], rs[3]));
+        if (blockIdx.x == 0) {
+          st4(ft.mean_rstd + c, make_float4(mu[0], mu[1], mu[2], mu[3]));
+          st4(ft.mean_rstd + K + c, make_float4(rs[0], rs[1], rs[2], rs[3]));
+          if (ft.running_mean) update_running_stats(ft.running_mean, ft.running_var, c, mu, var, M, ft.momentum);
+          if (c == 0 && ft.num_batches) ft.num_batches[0] += 1;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  const int64_t seed = (has_bn && bn.seed) ? bn.seed[0] : 0;
   float4 av[CH], wv[CH];
   float dot = 0.f;
 #pragma unroll
   for (int i = 0; i < CH; ++i) {
     const int j = i * 32 + l8 * 4;
-    av[i] = ld4(a + static_cast<int64_t>(mc) * K + j);
+    if (FUSE) {
+      const float4 zv = ld4(bn.z + static_cast<int64_t>(mc) * K + j), mu = ld4(s_mu + j), rs = ld4(s_rs + j),
+                   ga = ld4(bn.gamma + j), be = ld4(bn.beta + j);
+      const int64_t idx = static_cast<int64_t>(mc) * K + j;
+      av[i].x = fmaxf(fmaf(ga.x, (zv.x - mu.x) * rs.x, be.x), 0.f) * drop_scale(seed, bn.salt, idx + 0, bn.thresh, bn.inv_keep);
+      av[i].y = fmaxf(fmaf(ga.y, (zv.y - mu.y) * rs.y, be.y), 0.f) * drop_scale(seed, bn.salt, idx + 1, bn.thresh, bn.inv_keep);
+      av[i].z = fmaxf(fmaf(ga.z, (zv.z - mu.z) * rs.z, be.z), 0.f) * drop_scale(seed, bn.salt, idx + 2, bn.thresh, bn.inv_keep);
+      av[i].w = fmaxf(fmaf(ga.w, (zv.w - mu.w) * rs.w, be.w), 0.f) * drop_scale(seed, bn.salt, idx + 3, bn.thresh, bn.inv_keep);
+    } else {
+      av[i] = ld4(a + static_cast<int64_t>(mc) * K + j);
+    }
     wv[i] = ld4(w + j);
     dot = fmaf(av[i].x, wv[i].x, dot); dot = fmaf(av[i].y, wv[i].y, dot);
     dot = fmaf(av[i].z, wv[i].z, dot); dot = fmaf(av[i].w, wv[i].w, dot);
@@ -369,7 +447,6 @@ __global__ __launch_bounds__(kHeadThreads) void head_bce_kernel(
     dlogit[m] = dl;
   }
   float cs[3][CH][4];            // this lane's contributions to the column sums
-  const int64_t seed = (has_bn && bn.seed) ? bn.seed[0] : 0;
 #pragma unroll
   for (int i = 0; i < CH; ++i) {
     const int j = i * 32 + l8 * 4;
@@ -377,8 +454,8 @@ __global__ __launch_bounds__(kHeadThreads) void head_bce_kernel(
     const float aa[4] = {av[i].x, av[i].y, av[i].z, av[i].w};
     float dyv[4] = {0.f, 0.f, 0.f, 0.f};
     if (has_bn) {
-      const float4 zv = ld4(bn.z + static_cast<int64_t>(mc) * K + j), mu = ld4(bn.mean_rstd + j),
-                   rs = ld4(bn.mean_rstd + K + j), ga = ld4(bn.gamma + j), be = ld4(bn.beta + j);
+      const float4 zv = ld4(bn.z + static_cast<int64_t>(mc) * K + j), mu = ld4(FUSE ? s_mu + j : bn.mean_rstd + j),
+                   rs = ld4(FUSE ? s_rs + j : bn.mean_rstd + K + j), ga = ld4(bn.gamma + j), be = ld4(bn.beta + j);
       const float zz[4] = {zv.x, zv.y, zv.z, zv.w}, mm[4] = {mu.x, mu.y, mu.z, mu.w}, rr[4] = {rs.x, rs.y, rs.z, rs.w},
                   gg[4] = {ga.x, ga.y, ga.z, ga.w}, bb[4] = {be.x, be.y, be.z, be.w};
 #pragma unroll
@@ -654,22 +731,17 @@ extern "C" int dfm_bn_backward_apply(const dfm_bn_bwd* bn, int64_t batch, int fe
   return DFM_OK;
 }
 
-extern "C" int dfm_head_bce(const float* d_a, int64_t batch, int features, const float* d_w, const float* d_b,
-                            const float* d_first_order, const float* d_fm, const float* d_labels, float* d_logits,
-                            float* d_g_logits, const dfm_bn_bwd* bn, dfm_stream_t stream) {
-  DFM_REQUIRE(d_a && d_w && d_labels && d_logits && d_g_logits && bn, "null argument");
-  DFM_REQUIRE(batch > 0 && batch < (1 << 30), "bad batch");
-  DFM_REQUIRE(features > 0 && features % 32 == 0 && features <= 32 * kHeadMaxChunks,
-              "head features must be a multiple of 32, at most 256");
-  DFM_REQUIRE(aligned16(d_a) && aligned16(d_w), "pointers must be 16-byte aligned");
-  BnBwd dbn = {};
-  DFM_REQUIRE(fill_bn(bn, &dbn), "incomplete dfm_bn_bwd");
+namespace {
+template <bool FUSE>
+int launch_head(const float* d_a, int64_t batch, int features, const float* d_w, const float* d_b,
+                const float* d_first_order, const float* d_fm, const float* d_labels, float* d_logits,
+                float* d_g_logits, const BnBwd& dbn, const BnFwdTail& ft, hipStream_t st) {
   const int M = static_cast<int>(batch);
   const unsigned blocks = static_cast<unsigned>((batch + kHeadRows - 1) / kHeadRows);
-#define DFM_HEAD(CH)                                                                                              \
-  hipLaunchKernelGGL(head_bce_kernel<CH>, dim3(blocks), dim3(kHeadThreads), 0, as_stream(stream), d_a, M, d_w, d_b, \
-                     d_first_order, d_fm, d_labels, d_logits, d_g_logits, static_cast<float*>(nullptr), dbn, 1,     \
-                     dbn.partial)
+#define DFM_HEAD(CH)                                                                                             \
+  hipLaunchKernelGGL((head_bce_kernel<CH, FUSE>), dim3(blocks), dim3(kHeadThreads), 0, st, d_a, M, d_w, d_b,     \
+                     d_first_order, d_fm, d_labels, d_logits, d_g_logits, static_cast<float*>(nullptr), dbn, 1,  \
+                     dbn.partial, ft)
   switch (features / 32) {
     case 1: DFM_HEAD(1); break;
     case 2: DFM_HEAD(2); break;
@@ -683,6 +755,41 @@ extern "C" int dfm_head_bce(const float* d_a, int64_t batch, int features, const
 #undef DFM_HEAD
   DFM_LAUNCH_CHECK();
   return DFM_OK;
+}
+}  // namespace
+
+extern "C" int dfm_head_bce(const float* d_a, int64_t batch, int features, const float* d_w, const float* d_b,
+                            const float* d_first_order, const float* d_fm, const float* d_labels, float* d_logits,
+                            float* d_g_logits, const dfm_bn_bwd* bn, dfm_stream_t stream) {
+  DFM_REQUIRE(d_a && d_w && d_labels && d_logits && d_g_logits && bn, "null argument");
+  DFM_REQUIRE(batch > 0 && batch < (1 << 30), "bad batch");
+  DFM_REQUIRE(features > 0 && features % 32 == 0 && features <= 32 * kHeadMaxChunks,
+              "head features must be a multiple of 32, at most 256");
+  DFM_REQUIRE(aligned16(d_a) && aligned16(d_w), "pointers must be 16-byte aligned");
+  BnBwd dbn = {};
+  DFM_REQUIRE(fill_bn(bn, &dbn), "incomplete dfm_bn_bwd");
+  return launch_head<false>(d_a, batch, features, d_w, d_b, d_first_order, d_fm, d_labels, d_logits, d_g_logits, dbn,
+                            BnFwdTail{}, as_stream(stream));
+}
+
+extern "C" int dfm_head_bn_bce(const void* d_fwd_workspace, float* d_mean_rstd, float* d_running_mean,
+                               float* d_running_var, int64_t* d_num_batches, float momentum, float eps,
+                               int64_t batch, int features, const float* d_w, const float* d_b,
+                               const float* d_first_order, const float* d_fm, const float* d_labels,
+                               float* d_logits, float* d_g_logits, const dfm_bn_bwd* bn, dfm_stream_t stream) {
+  DFM_REQUIRE(d_fwd_workspace && d_mean_rstd && d_w && d_labels && d_logits && d_g_logits && bn, "null argument");
+  DFM_REQUIRE(batch > 0 && batch < (1 << 30), "bad batch");
+  DFM_REQUIRE(features > 0 && features % 32 == 0 && features <= 32 * kHeadMaxChunks,
+              "head features must be a multiple of 32, at most 256");
+  BnBwd dbn = {};
+  DFM_REQUIRE(fill_bn(bn, &dbn), "incomplete dfm_bn_bwd");
+  DFM_REQUIRE(dbn.mean_rstd == d_mean_rstd, "bn->mean_rstd must be the buffer the statistics are written to");
+  DFM_REQUIRE(aligned16(d_fwd_workspace) && aligned16(d_mean_rstd) && aligned16(d_w) && aligned16(dbn.z) &&
+                  aligned16(dbn.gamma) && aligned16(dbn.beta), "pointers must be 16-byte aligned");
+  BnFwdTail ft = {static_cast<const float*>(d_fwd_workspace), d_mean_rstd, d_running_mean, d_running_var,
+                  d_num_batches, momentum, eps};
+  return launch_head<true>(nullptr, batch, features, d_w, d_b, d_first_order, d_fm, d_labels, d_logits, d_g_logits,
+                           dbn, ft, as_stream(stream));
 }
 
 namespace {

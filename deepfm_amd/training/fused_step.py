@@ -160,6 +160,7 @@ class _FusedTowerStep(RowSparseTrainStep):
         # ---- forward ----
         extra = self._interaction_forward()
         x = self.x0
+        head = self.head
         for i in range(self.L):
             lin, bn = self.lin[i], self.bn[i]
             n, k = lin.out_features, lin.in_features
@@ -167,19 +168,22 @@ class _FusedTowerStep(RowSparseTrainStep):
             _lib.check(lib.dfm_linear_bn_forward(
                 x.data_ptr(), k, lin.weight.data_ptr(), _lib.ptr(lin.bias), B, n, k, self.z[i].data_ptr(),
                 self.ws_fwd[i].data_ptr(), st))
+            stats = (self.stats[i].data_ptr(), bn.running_mean.data_ptr() if track else None,
+                     bn.running_var.data_ptr() if track else None,
+                     bn.num_batches_tracked.data_ptr() if track else None, float(bn.momentum), float(bn.eps))
+            if i == self.L - 1:
+                # ---- last block + head in one launch: logits, d logits, the BatchNorm's statistics and mask
+                # (its output a is never stored; loss + head gradients: next launch) ----
+                ctx = self._bn_ctx(i)
+                _lib.check(lib.dfm_head_bn_bce(
+                    self.ws_fwd[i].data_ptr(), *stats, B, head.in_features, head.weight.data_ptr(),
+                    _lib.ptr(head.bias), self.fo.data_ptr(), _lib.ptr(extra), self.labels.data_ptr(),
+                    self.logits.data_ptr(), self.g_logits.data_ptr(), C.byref(ctx), st))
+                break
             _lib.check(lib.dfm_bn_relu_dropout_apply(
                 self.z[i].data_ptr(), B, n, self.ws_fwd[i].data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(),
-                self.stats[i].data_ptr(), bn.running_mean.data_ptr() if track else None,
-                bn.running_var.data_ptr() if track else None, bn.num_batches_tracked.data_ptr() if track else None,
-                float(bn.momentum), float(bn.eps), self.drop_p[i], self.seed.data_ptr(), i, self.a[i].data_ptr(), st))
+                *stats, self.drop_p[i], self.seed.data_ptr(), i, self.a[i].data_ptr(), st))
             x = self.a[i]
-        # ---- head: logits, d logits, mask of the last BatchNorm (loss + head gradients: next launch) ----
-        head = self.head
-        ctx = self._bn_ctx(self.L - 1)
-        _lib.check(lib.dfm_head_bce(
-            x.data_ptr(), B, head.in_features, head.weight.data_ptr(), _lib.ptr(head.bias), self.fo.data_ptr(),
-            _lib.ptr(extra), self.labels.data_ptr(), self.logits.data_ptr(), self.g_logits.data_ptr(),
-            C.byref(ctx), st))
         tail = _lib.HeadTail()
         tail.g_w = head.weight.grad.data_ptr()
         tail.g_b = head.bias.grad.data_ptr() if head.bias is not None else None

@@ -426,7 +426,8 @@ int dfm_bce_with_logits(const float* d_logits, const float* d_labels, int64_t n,
  * BCEWithLogitsLoss).  Few launches, none with a serial tail (csrc/tower.hip):
  *   forward, per layer : dfm_linear_bn_forward (GEMM + per-tile column statistics),
  *                        dfm_bn_relu_dropout_apply (merges the statistics, then normalises)
- *   head               : dfm_head_bce (logits, d logits, the last BN's mask, partial sums)
+ *   head               : dfm_head_bce (logits, d logits, the last BN's mask, partial sums), or
+ *                        dfm_head_bn_bce = the last block's dfm_bn_relu_dropout_apply + dfm_head_bce
  *   backward, per layer: dfm_bn_backward_apply (merges the partial sums, then dz),
  *                        dfm_linear_backward (dW and dx in one launch; the dx epilogue is the lower
  *                        layer's BatchNorm mask or the FM backward)
@@ -493,6 +494,16 @@ size_t dfm_bn_bwd_workspace_bytes(int64_t batch, int features);
 int dfm_head_bce(const float* d_a, int64_t batch, int features, const float* d_w, const float* d_b,
                  const float* d_first_order, const float* d_fm, const float* d_labels, float* d_logits,
                  float* d_g_logits, const dfm_bn_bwd* bn, dfm_stream_t stream);
+/* dfm_bn_relu_dropout_apply of the tower's LAST block and dfm_head_bce in one launch: every workgroup merges
+ * the column statistics in d_fwd_workspace (dfm_linear_bn_forward's) exactly as dfm_bn_relu_dropout_apply does,
+ * workgroup 0 writes d_mean_rstd (= bn->mean_rstd) and the running statistics, and
+ * a = dropout(relu(gamma * (bn->z - mean) * rstd + beta)) is formed in registers and never stored (the backward
+ * needs z, the statistics and the mask).  Results are bit-identical to the two calls it replaces. */
+int dfm_head_bn_bce(const void* d_fwd_workspace, float* d_mean_rstd, float* d_running_mean, float* d_running_var,
+                    int64_t* d_num_batches, float momentum, float eps, int64_t batch, int features,
+                    const float* d_w, const float* d_b, const float* d_first_order, const float* d_fm,
+                    const float* d_labels, float* d_logits, float* d_g_logits, const dfm_bn_bwd* bn,
+                    dfm_stream_t stream);
 /* dz = gamma * rstd * (dy - mean(dy) - xhat * mean(dy * xhat)), d gamma / d beta ADDED; d_dz may be
  * bn->dy.  `head` non-NULL iff bn was filled by dfm_head_bce (it then also receives the loss and
  * the head gradients). */

@@ -246,6 +246,60 @@ def test_apply_and_mask_share_the_dropout_pattern():
     assert torch.equal(dy != 0, kept)        # d logits > 0 everywhere (labels 0), so dy != 0 exactly where kept
 
 
+@pytest.mark.parametrize("M,K,p", [(2048, 64, 0.3), (4096, 64, 0.0), (1000, 32, 0.2), (777, 128, 0.5), (4096, 256, 0.1)])
+def test_head_with_the_last_batchnorm_inside_is_bitwise_the_two_launches(M, K, p):
+    """dfm_head_bn_bce = dfm_bn_relu_dropout_apply (last block) + dfm_head_bce: same statistics (mean, rstd,
+    running mean / variance, batch counter), logits, d logits, masked gradient and workgroup partials, bit for
+    bit — every workgroup of the fused launch merges the tile statistics in the order the apply kernel uses."""
+    from deepfm_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator(device="cuda").manual_seed(M + K)
+    x = torch.randn(M, 48, device="cuda", generator=g)
+    w = torch.randn(K, 48, device="cuda", generator=g)
+    bias = torch.randn(K, device="cuda", generator=g)
+    gamma = torch.rand(K, device="cuda", generator=g) + 0.5
+    beta = torch.randn(K, device="cuda", generator=g) * 0.1
+    hw, hb = torch.randn(1, K, device="cuda", generator=g) * 0.1, torch.randn(1, device="cuda", generator=g)
+    fo, fm = torch.randn(M, device="cuda", generator=g), torch.randn(M, device="cuda", generator=g)
+    y = (torch.rand(M, device="cuda", generator=g) < 0.3).float()
+    seed = torch.tensor([987654321], dtype=torch.int64, device="cuda")
+    z = torch.empty(M, K, device="cuda")
+    wsf = _ws(lib.dfm_linear_bn_workspace_bytes(M, K))
+    _lib.check(lib.dfm_linear_bn_forward(x.data_ptr(), 48, w.data_ptr(), bias.data_ptr(), M, K, 48, z.data_ptr(),
+                                         wsf.data_ptr(), _lib.stream_handle()))
+    nws = lib.dfm_bn_bwd_workspace_bytes(M, K) // 4
+
+    def run(fused):
+        stats = torch.zeros(2, K, device="cuda")
+        rm, rv = torch.full((K,), 0.25, device="cuda"), torch.full((K,), 2.0, device="cuda")
+        nb = torch.tensor([7], dtype=torch.int64, device="cuda")
+        logits, dl = torch.zeros(M, device="cuda"), torch.zeros(M, device="cuda")
+        dy, gg, gb = torch.zeros(M, K, device="cuda"), torch.zeros(K, device="cuda"), torch.zeros(K, device="cuda")
+        wsb = torch.zeros(nws, device="cuda")
+        ctx = _bn_ctx(z, stats, gamma, beta, dy, gg, gb, wsb, p=p, seed=seed, salt=2)
+        if fused:
+            _lib.check(lib.dfm_head_bn_bce(wsf.data_ptr(), stats.data_ptr(), rm.data_ptr(), rv.data_ptr(), nb.data_ptr(),
+                                           0.1, 1e-5, M, K, hw.data_ptr(), hb.data_ptr(), fo.data_ptr(), fm.data_ptr(),
+                                           y.data_ptr(), logits.data_ptr(), dl.data_ptr(), C.byref(ctx),
+                                           _lib.stream_handle()))
+        else:
+            a = torch.empty(M, K, device="cuda")
+            _lib.check(lib.dfm_bn_relu_dropout_apply(z.data_ptr(), M, K, wsf.data_ptr(), gamma.data_ptr(),
+                                                     beta.data_ptr(), stats.data_ptr(), rm.data_ptr(), rv.data_ptr(),
+                                                     nb.data_ptr(), 0.1, 1e-5, p, seed.data_ptr(), 2, a.data_ptr(),
+                                                     _lib.stream_handle()))
+            _lib.check(lib.dfm_head_bce(a.data_ptr(), M, K, hw.data_ptr(), hb.data_ptr(), fo.data_ptr(), fm.data_ptr(),
+                                        y.data_ptr(), logits.data_ptr(), dl.data_ptr(), C.byref(ctx),
+                                        _lib.stream_handle()))
+        torch.cuda.synchronize()
+        return dict(stats=stats, rm=rm, rv=rv, nb=nb, logits=logits, dl=dl, dy=dy, partials=wsb)
+
+    two, one = run(False), run(True)
+    assert int(one["nb"]) == 8
+    for k in two:
+        assert torch.equal(two[k], one[k]), k
+
+
 def _fused_pair(B, seed=0):
     from deepfm_amd.training.fused_step import FusedDeepFMStep
     from deepfm_amd.training.rowsparse import RowSparseAdam
