@@ -63,7 +63,11 @@ size_t cin_mfma_wgrad_workspace_bytes(int64_t B, int C, int H, int F);
 bool cin_mfma_wgrad_has_bias(int F);
 bool cin_mfma_wgrad_supported(int64_t B, int D);
 int cin_mfma_wgrad(const float* dY, const float* x0, const float* hidden, int64_t hidden_stride, int64_t B,
-                   int F, int H, int C, int D, float* dW, float* db, void* workspace, bool split, hipStream_t st);
+                   int F, int H, int C, int D, float* dW, float* db, void* workspace, bool split, bool reduce_now,
+                   hipStream_t st);
+int cin_mfma_wgrad_max_layers_per_reduce();
+int cin_mfma_wgrad_reduce_layers(int count, void* const* workspaces, float* const* dW, float* const* db, int64_t B,
+                                 int F, const int* H, const int* C, hipStream_t st);
 size_t cin_bias_grad_workspace_bytes(int C);
 int cin_bias_grad_launch(const float* dY, int64_t B, int C, int D, float* db, float* partial, hipStream_t st);
 bool cin_mfma_supported(int F, int D, const int* C, const int* H, int L);
@@ -164,6 +168,9 @@ static size_t packed_wt_total(const Layout& lo) {
   for (int i = 0; i < lo.L; ++i) total += ((cin_bwd_packed_wt_elems(lo.H[i], lo.F, lo.C[i]) + 63) / 64) * 64;
   return total;
 }
+static size_t wgrad_region_bytes(int64_t batch, int C, int H, int F) {
+  return (cin_mfma_wgrad_workspace_bytes(batch, C, H, F) + 255) / 256 * 256;
+}
 static bool mfma_bwd_ok(const Layout& lo, int64_t batch) {
   return cin_mode() != 2 && cin_mfma_wgrad_supported(batch, lo.D) &&
          cin_mfma_supported(lo.F, lo.D, lo.C.data(), lo.H.data(), lo.L);
@@ -179,12 +186,10 @@ extern "C" size_t dfm_cin_backward_workspace_bytes(const int32_t* layer_sizes, i
   int64_t part = kWgradSlices * lo.max_CK;             // weight-gradient partials (reused for bias partials)
   if (part < 256 * static_cast<int64_t>(lo.max_C)) part = 256 * static_cast<int64_t>(lo.max_C);
   size_t simple = sizeof(float) * static_cast<size_t>(dy + 2 * dh + part);
-  // matrix-core path: dY of every layer + W^T fragments (hi, lo) + the largest wgrad workspace
+  // matrix-core path: dY of every layer + W^T fragments (hi, lo) + every layer's wgrad workspace (the partial
+  // products of all layers are added by one launch at the end)
   size_t wg = 0;
-  for (int i = 0; i < lo.L; ++i) {
-    const size_t w = cin_mfma_wgrad_workspace_bytes(batch, lo.C[i], lo.H[i], num_fields);
-    wg = w > wg ? w : wg;
-  }
+  for (int i = 0; i < lo.L; ++i) wg += wgrad_region_bytes(batch, lo.C[i], lo.H[i], num_fields);
   size_t mfma = sizeof(float) * static_cast<size_t>(lo.saved_floats) + 2 * sizeof(bf16_t) * packed_wt_total(lo) + wg + 1024;
   return simple > mfma ? simple : mfma;
 }
@@ -289,17 +294,25 @@ extern "C" int dfm_cin_backward(const float* d_x0, int64_t batch, int num_fields
     const int fg8 = ((num_fields + 7) / 8) * 8;
     args.dh_rows = dh_rows > fg8 ? dh_rows : fg8;
     if (int rc = cin_mfma_dgrad(args, dim, split, st)) return rc;
+    // every layer's batch-sliced partial products into its own region, then ONE launch adds them all
+    const bool fused_bias = cin_mfma_wgrad_has_bias(num_fields);   // the bias gradient rides in a padding column
+    const bool together = fused_bias && lo.L <= cin_mfma_wgrad_max_layers_per_reduce();
+    void* regions[kCinMaxLayers];
+    int Hs[kCinMaxLayers], Cs[kCinMaxLayers];
     for (int i = 0; i < lo.L; ++i) {
       const CinBwdLayer& ly = args.layer[i];
-      // the bias gradient rides in a padding column of the weight-gradient GEMM when there is one
-      const bool fused_bias = cin_mfma_wgrad_has_bias(num_fields);
+      regions[i] = wg_ws;
+      Hs[i] = lo.H[i]; Cs[i] = lo.C[i];
       if (int rc = cin_mfma_wgrad(ly.dY, d_x0, ly.hidden, ly.hidden_stride, batch, num_fields, lo.H[i], lo.C[i], dim,
-                                  g_weights[i], fused_bias ? g_biases[i] : nullptr, wg_ws, split, st))
+                                  g_weights[i], fused_bias ? g_biases[i] : nullptr, wg_ws, split, !together, st))
         return rc;
       // else: wgrad's slabs are consumed (stream order), its workspace doubles as the bias partials
       if (!fused_bias)
         if (int rc = cin_bias_grad_launch(ly.dY, batch, lo.C[i], dim, g_biases[i], reinterpret_cast<float*>(wg_ws), st)) return rc;
+      if (together) wg_ws += wgrad_region_bytes(batch, lo.C[i], lo.H[i], num_fields);
     }
+    if (together)
+      if (int rc = cin_mfma_wgrad_reduce_layers(lo.L, regions, g_weights, g_biases, batch, num_fields, Hs, Cs, st)) return rc;
     return DFM_OK;
   }
   float* ws = static_cast<float*>(d_workspace);

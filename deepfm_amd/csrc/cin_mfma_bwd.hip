@@ -526,21 +526,50 @@ __global__ __launch_bounds__(256, kWgBound) void cin_wgrad_mfma(CinWgradArgs a) 
 }
 
 // dW[c][h*F+f] += sum_s slabs[s][c][h*FP+f]  (fixed order); with db: db[c] += sum_s slabs[s][c][F]
-__global__ __launch_bounds__(256) void cin_wgrad_reduce_mfma(const float* __restrict__ slabs, int slices,
-                                                             int rows_pad, int cols_pad, int C, int H, int F,
-                                                             int FP, float* __restrict__ dW, float* __restrict__ db) {
-  const int64_t o = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
-  const int64_t K = static_cast<int64_t>(H) * F;
-  const int64_t n = C * K;
-  if (o >= n + (db ? C : 0)) return;
+struct CinWgradReduceJob {
+  const float* slabs;
+  float* dW;
+  float* db;
+  int slices, rows_pad, cols_pad, C, H, F, FP;
+};
+__device__ __forceinline__ void cin_wgrad_reduce_body(int blk, const CinWgradReduceJob& j) {
+  const int64_t o = static_cast<int64_t>(blk) * 256 + threadIdx.x;
+  const int64_t K = static_cast<int64_t>(j.H) * j.F;
+  const int64_t n = j.C * K;
+  if (o >= n + (j.db ? j.C : 0)) return;
   const int c = o < n ? static_cast<int>(o / K) : static_cast<int>(o - n);
   const int k = static_cast<int>(o % K);
-  const int kp = o < n ? (k / F) * FP + k % F : F;
+  const int kp = o < n ? (k / j.F) * j.FP + k % j.F : j.F;
+  // 25 ... 39 slices: eight loads in flight at a time, added in slice order
+  const float* p = j.slabs + static_cast<int64_t>(c) * j.cols_pad + kp;
+  const int64_t stride = static_cast<int64_t>(j.rows_pad) * j.cols_pad;
   float acc = 0.f;
-  for (int s = 0; s < slices; ++s)
-    acc += slabs[(static_cast<int64_t>(s) * rows_pad + c) * cols_pad + kp];
-  if (o < n) dW[o] += acc;
-  else db[c] += acc;
+  int s = 0;
+  for (; s + 8 <= j.slices; s += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = p[(s + u) * stride];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += v[u];
+  }
+  for (; s < j.slices; ++s) acc += p[s * stride];
+  if (o < n) j.dW[o] += acc;
+  else j.db[c] += acc;
+}
+__global__ __launch_bounds__(256) void cin_wgrad_reduce_mfma(CinWgradReduceJob j) {
+  cin_wgrad_reduce_body(blockIdx.x, j);
+}
+// every layer's slabs in ONE launch (each layer has its own slab region): three 12 us launches -> one
+constexpr int kCinReduceMaxJobs = 8;
+struct CinWgradReduceJobs {
+  CinWgradReduceJob job[kCinReduceMaxJobs];
+  int first_block[kCinReduceMaxJobs + 1];
+  int count;
+};
+__global__ __launch_bounds__(256) void cin_wgrad_reduce_all(CinWgradReduceJobs jobs) {
+  int i = 0;
+  while (i + 1 < jobs.count && static_cast<int>(blockIdx.x) >= jobs.first_block[i + 1]) ++i;
+  cin_wgrad_reduce_body(blockIdx.x - jobs.first_block[i], jobs.job[i]);
 }
 
 // ---- host side ---------------------------------------------------------------------------
@@ -636,9 +665,21 @@ bool cin_mfma_wgrad_has_bias(int F) { return F % 8 != 0; }
 // D == 8 pairs samples in a k-step: the batch must be even
 bool cin_mfma_wgrad_supported(int64_t B, int D) { return D == 16 || D == 32 || (D == 8 && B % 2 == 0); }
 
-// dW += dY^T (hidden (x) x0); db += sum_{b,d} dY when `db` is given (cin_mfma_wgrad_has_bias)
+static CinWgradReduceJob wgrad_reduce_job(void* workspace, float* dW, float* db, int64_t B, int F, int H, int C,
+                                          int* blocks) {
+  const int MB = (C + 31) / 32, FP = ((F + 7) / 8) * 8;
+  const int KT = (H * FP + 31) / 32;
+  const int64_t n = static_cast<int64_t>(C) * H * F + (db ? C : 0);
+  *blocks = static_cast<int>((n + 255) / 256);
+  return CinWgradReduceJob{static_cast<const float*>(workspace), dW, db, wgrad_slices(B, KT), MB * 32, KT * 32, C, H, F, FP};
+}
+
+// dW += dY^T (hidden (x) x0); db += sum_{b,d} dY when `db` is given (cin_mfma_wgrad_has_bias).
+// reduce_now false: the batch slices' partial products stay in `workspace` — the caller gives every layer its own
+// and adds them all with ONE cin_mfma_wgrad_reduce_layers launch.
 int cin_mfma_wgrad(const float* dY, const float* x0, const float* hidden, int64_t hidden_stride, int64_t B,
-                   int F, int H, int C, int D, float* dW, float* db, void* workspace, bool split, hipStream_t st) {
+                   int F, int H, int C, int D, float* dW, float* db, void* workspace, bool split, bool reduce_now,
+                   hipStream_t st) {
   DFM_REQUIRE(!db || cin_mfma_wgrad_has_bias(F), "no padding column for the bias gradient (F = %d)", F);
   DFM_REQUIRE(cin_mfma_wgrad_supported(B, D), "no MFMA weight-gradient kernel for D = %d, B = %lld", D, (long long)B);
   const int MB = (C + 31) / 32, FP = ((F + 7) / 8) * 8;
@@ -661,9 +702,30 @@ int cin_mfma_wgrad(const float* dY, const float* x0, const float* hidden, int64_
   DFM_WG(8) DFM_WG(16) DFM_WG(32)
 #undef DFM_WG
   DFM_LAUNCH_CHECK();
-  const int64_t n = static_cast<int64_t>(C) * H * F + (db ? C : 0);
-  hipLaunchKernelGGL(cin_wgrad_reduce_mfma, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, st, slabs,
-                     slices, MB * 32, KT * 32, C, H, F, FP, dW, db);
+  if (!reduce_now) return DFM_OK;
+  int blocks;
+  const CinWgradReduceJob job = wgrad_reduce_job(workspace, dW, db, B, F, H, C, &blocks);
+  hipLaunchKernelGGL(cin_wgrad_reduce_mfma, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, st, job);
+  DFM_LAUNCH_CHECK();
+  return DFM_OK;
+}
+
+int cin_mfma_wgrad_max_layers_per_reduce() { return kCinReduceMaxJobs; }
+
+// the reductions cin_mfma_wgrad(..., reduce_now = false) left open, layer i in workspaces[i]
+int cin_mfma_wgrad_reduce_layers(int count, void* const* workspaces, float* const* dW, float* const* db, int64_t B,
+                                 int F, const int* H, const int* C, hipStream_t st) {
+  DFM_REQUIRE(count >= 0 && count <= kCinReduceMaxJobs, "at most %d layers per reduction launch", kCinReduceMaxJobs);
+  if (count == 0) return DFM_OK;
+  CinWgradReduceJobs js;
+  js.count = count;
+  js.first_block[0] = 0;
+  for (int i = 0; i < count; ++i) {
+    int blocks;
+    js.job[i] = wgrad_reduce_job(workspaces[i], dW[i], db[i], B, F, H[i], C[i], &blocks);
+    js.first_block[i + 1] = js.first_block[i] + blocks;
+  }
+  hipLaunchKernelGGL(cin_wgrad_reduce_all, dim3(static_cast<unsigned>(js.first_block[count])), dim3(256), 0, st, js);
   DFM_LAUNCH_CHECK();
   return DFM_OK;
 }

@@ -28,7 +28,7 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&dW, nw * 4)); CK(hipMalloc(&db, C * 4));
     CK(hipMalloc(&ws, dfm::cin_mfma_wgrad_workspace_bytes(B, C, H, F)));
     auto run = [&]() {
-      if (dfm::cin_mfma_wgrad(dY, x0, hid, (int64_t)H * D, B, F, H, C, D, dW, db, ws, true, st)) { fprintf(stderr, "%s\n", dfm::last_error_buf()); exit(1); }
+      if (dfm::cin_mfma_wgrad(dY, x0, hid, (int64_t)H * D, B, F, H, C, D, dW, db, ws, true, true, st)) { fprintf(stderr, "%s\n", dfm::last_error_buf()); exit(1); }
     };
     CK(hipMemsetAsync(dW, 0, nw * 4, st)); CK(hipMemsetAsync(db, 0, C * 4, st));
     run();
