@@ -68,7 +68,7 @@ class SlabRef(C.Structure):
 
 class HeadTail(C.Structure):
     """struct dfm_head_tail"""
-    _fields_ = [("g_w", C.c_void_p), ("g_b", C.c_void_p), ("loss", C.c_void_p)]
+    _fields_ = [("g_w", C.c_void_p), ("g_b", C.c_void_p), ("loss", C.c_void_p), ("g_b2", C.c_void_p)]
 
 
 # name -> (restype, argtypes); must list every symbol of include/deepfm_hip.h
@@ -139,6 +139,10 @@ SIGNATURES = {
     "dfm_bn_relu_dropout_apply": (_I, [_P, _L, _I, _P, _P, _P, _P, _P, _P, _P, _F, _F, _F, _P, _I, _P, _P]),
     "dfm_bn_bwd_workspace_bytes": (_SZ, [_L, _I]),
     "dfm_bn_backward_apply": (_I, [C.POINTER(BnBwd), _L, _I, C.POINTER(HeadTail), _P, _P]),
+    "dfm_linear1_supported": (_I, [_I]),
+    "dfm_linear1_forward": (_I, [_P, _L, _I, _P, _P, _P, _P]),
+    "dfm_linear1_backward_splits": (_I, [_L]),
+    "dfm_linear1_backward": (_I, [_P, _P, _L, _I, _P, _P, _P, _P]),
     "dfm_head_bce": (_I, [_P, _L, _I, _P, _P, _P, _P, _P, _P, _P, C.POINTER(BnBwd), _P]),
     "dfm_head_bn_bce": (_I, [_P, _P, _P, _P, _P, _F, _F, _L, _I, _P, _P, _P, _P, _P, _P, _P, C.POINTER(BnBwd), _P]),
     "dfm_linear_backward_workspace_bytes": (_SZ, [_L, _I, _I]),

@@ -257,6 +257,7 @@ struct HeadTail {
   float* g_w;       // (K) += sum_b dlogit_b * a[b, :]
   float* g_b;       // (1) += sum_b dlogit_b     (may be NULL)
   float* loss;      // (1)  = mean BCE
+  float* g_b2;      // (1) += the same sum: the bias of another 1-wide Linear added to the logit (may be NULL)
   int enabled;
 };
 
@@ -307,6 +308,7 @@ __global__ __launch_bounds__(kApThreads) void bn_bwd_apply_kernel(
       if (blockIdx.x == 0 && threadIdx.x == 0) {
         head.loss[0] = s4.x / static_cast<float>(M);
         if (head.g_b) head.g_b[0] += s4.y;
+        if (head.g_b2) head.g_b2[0] += s4.y;
       }
     }
   }
@@ -720,7 +722,7 @@ extern "C" int dfm_bn_backward_apply(const dfm_bn_bwd* bn, int64_t batch, int fe
   int T = (M + 31) / 32, stride = 2 * features, off1 = features;
   if (head) {       // the mask came from dfm_head_bce: its workgroup partials, not the dx epilogue's
     DFM_REQUIRE(head->g_w && head->loss && aligned16(head->g_w), "incomplete dfm_head_tail");
-    ht.g_w = head->g_w; ht.g_b = head->g_b; ht.loss = head->loss; ht.enabled = 1;
+    ht.g_w = head->g_w; ht.g_b = head->g_b; ht.loss = head->loss; ht.g_b2 = head->g_b2; ht.enabled = 1;
     T = (M + kHeadRows - 1) / kHeadRows;
     stride = 3 * features + 4;
   }
@@ -790,6 +792,104 @@ extern "C" int dfm_head_bn_bce(const void* d_fwd_workspace, float* d_mean_rstd, 
                   d_num_batches, momentum, eps};
   return launch_head<true>(nullptr, batch, features, d_w, d_b, d_first_order, d_fm, d_labels, d_logits, d_g_logits,
                            dbn, ft, as_stream(stream));
+}
+
+// =====================================================================================
+// A Linear with ONE output added to the logit (xDeepFM's cin_linear, xdeepfm.py:41-47): forward a row dot
+// product, backward an outer product and a column sum — a few microseconds of memory traffic that cost six
+// generic GEMM / reduce launches (43 us) before.
+// =====================================================================================
+namespace {
+constexpr int kL1Threads = 256;
+constexpr int kL1Rows = 64;          // rows per workgroup (= per slab) of the backward
+}  // namespace
+
+// out[b] = x[b, :] . w (+ bias): one wave per row
+__global__ __launch_bounds__(kL1Threads) void linear1_fwd_kernel(const float* __restrict__ x, int64_t M, int K,
+                                                                 const float* __restrict__ w,
+                                                                 const float* __restrict__ bias,
+                                                                 float* __restrict__ out) {
+  const int lane = lane_id(), wave = wave_id_uniform();
+  const int64_t row = static_cast<int64_t>(blockIdx.x) * (kL1Threads / kWave) + wave;
+  if (row >= M) return;
+  float acc = 0.f;
+  for (int k = lane * 4; k < K; k += kWave * 4) {
+    const float4 xv = ld4(x + row * K + k), wv = ld4(w + k);
+    acc = fmaf(xv.x, wv.x, acc); acc = fmaf(xv.y, wv.y, acc); acc = fmaf(xv.z, wv.z, acc); acc = fmaf(xv.w, wv.w, acc);
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, kWave);
+  if (lane == 0) out[row] = acc + (bias ? bias[0] : 0.f);
+}
+
+// g_x[b, :] = g[b] * w;  slab[blockIdx][k] = sum over the workgroup's rows of g[b] * x[b, k] (fixed order),
+// added into the weight gradient by dfm_linear_backward_finish (a dfm_slab_ref with splits = gridDim.x)
+__global__ __launch_bounds__(kL1Threads) void linear1_bwd_kernel(const float* __restrict__ g,
+                                                                 const float* __restrict__ x, int64_t M, int K,
+                                                                 const float* __restrict__ w,
+                                                                 float* __restrict__ g_x, float* __restrict__ slabs) {
+  __shared__ __attribute__((aligned(16))) float red[kL1Threads * 4];
+  const int c4n = K / 4;                                   // <= kL1Threads (host)
+  const int rln = kL1Threads / c4n;                        // row lanes
+  const int cl = threadIdx.x % c4n, rl = threadIdx.x / c4n;
+  const bool active = rl < rln;
+  const int64_t r0 = static_cast<int64_t>(blockIdx.x) * kL1Rows;
+  const float4 wv = ld4(w + 4 * cl);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (active) {
+    for (int r = rl; r < kL1Rows; r += rln) {
+      const int64_t row = r0 + r;
+      if (row >= M) break;
+      const float gv = g[row];
+      const float4 xv = ld4(x + row * K + 4 * cl);
+      st4(g_x + row * K + 4 * cl, make_float4(gv * wv.x, gv * wv.y, gv * wv.z, gv * wv.w));
+      acc.x = fmaf(gv, xv.x, acc.x); acc.y = fmaf(gv, xv.y, acc.y);
+      acc.z = fmaf(gv, xv.z, acc.z); acc.w = fmaf(gv, xv.w, acc.w);
+    }
+    st4(red + (rl * c4n + cl) * 4, acc);
+  }
+  __syncthreads();
+  if (rl == 0) {
+    float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = 0; i < rln; ++i) {
+      const float4 v = ld4(red + (i * c4n + cl) * 4);
+      tot.x += v.x; tot.y += v.y; tot.z += v.z; tot.w += v.w;
+    }
+    st4(slabs + static_cast<int64_t>(blockIdx.x) * K + 4 * cl, tot);
+  }
+}
+
+extern "C" int dfm_linear1_supported(int features) {
+  return (features > 0 && features % 4 == 0 && features / 4 <= kL1Threads) ? 1 : 0;
+}
+extern "C" int dfm_linear1_forward(const float* d_x, int64_t batch, int features, const float* d_w, const float* d_b,
+                                   float* d_out, dfm_stream_t stream) {
+  DFM_REQUIRE(d_x && d_w && d_out, "null argument");
+  DFM_REQUIRE(dfm_linear1_supported(features), "features must be a multiple of 4, at most %d", 4 * kL1Threads);
+  DFM_REQUIRE(batch >= 0 && batch < (1 << 30), "bad batch");
+  DFM_REQUIRE(aligned16(d_x) && aligned16(d_w), "pointers must be 16-byte aligned");
+  if (batch == 0) return DFM_OK;
+  const int rows = kL1Threads / kWave;
+  hipLaunchKernelGGL(linear1_fwd_kernel, dim3(static_cast<unsigned>((batch + rows - 1) / rows)), dim3(kL1Threads), 0,
+                     as_stream(stream), d_x, batch, features, d_w, d_b, d_out);
+  DFM_LAUNCH_CHECK();
+  return DFM_OK;
+}
+extern "C" int dfm_linear1_backward_splits(int64_t batch) {
+  return static_cast<int>((batch + kL1Rows - 1) / kL1Rows);
+}
+extern "C" int dfm_linear1_backward(const float* d_g, const float* d_x, int64_t batch, int features,
+                                    const float* d_w, float* d_g_x, void* d_workspace, dfm_stream_t stream) {
+  DFM_REQUIRE(d_g && d_x && d_w && d_g_x && d_workspace, "null argument");
+  DFM_REQUIRE(dfm_linear1_supported(features), "features must be a multiple of 4, at most %d", 4 * kL1Threads);
+  DFM_REQUIRE(batch > 0 && batch < (1 << 30), "bad batch");
+  DFM_REQUIRE(aligned16(d_x) && aligned16(d_w) && aligned16(d_g_x) && aligned16(d_workspace),
+              "pointers must be 16-byte aligned");
+  hipLaunchKernelGGL(linear1_bwd_kernel, dim3(static_cast<unsigned>(dfm_linear1_backward_splits(batch))),
+                     dim3(kL1Threads), 0, as_stream(stream), d_g, d_x, batch, features, d_w, d_g_x,
+                     static_cast<float*>(d_workspace));
+  DFM_LAUNCH_CHECK();
+  return DFM_OK;
 }
 
 namespace {

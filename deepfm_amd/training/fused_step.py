@@ -188,6 +188,7 @@ class _FusedTowerStep(RowSparseTrainStep):
         tail.g_w = head.weight.grad.data_ptr()
         tail.g_b = head.bias.grad.data_ptr() if head.bias is not None else None
         tail.loss = self.loss.data_ptr()
+        tail.g_b2 = self._second_logit_bias_grad()
         # ---- backward: the interaction layer first (its d embeddings ride in layer 1's epilogue) ----
         fmb = self._interaction_backward()
         for i in range(self.L - 1, -1, -1):
@@ -207,8 +208,13 @@ class _FusedTowerStep(RowSparseTrainStep):
                     None, C.byref(fmb) if fmb is not None else None, 3, self.ws_lin[i].data_ptr(), st))
         self._finish_embedding_grad()
         # the batch-split d weight products of all layers -> the flat gradient buffer, one launch
-        n_refs = self.L + (1 if self._dense_parts else 0)
+        extra = self._extra_slab_refs()
+        n_refs = self.L + (1 if self._dense_parts else 0) + len(extra)
         refs = (_lib.SlabRef * n_refs)()
+        for j, (ws_ptr, g_ptr, elems, splits) in enumerate(extra):
+            r = refs[n_refs - len(extra) + j]
+            r.workspace, r.g_w = ws_ptr, g_ptr
+            r.batch, r.out_features, r.in_features, r.splits = 1, 1, elems, splits
         for i in range(self.L):
             r, lin = refs[i], self.lin[i]
             r.workspace, r.g_w = self.ws_lin[i].data_ptr(), lin.weight.grad.data_ptr()
@@ -232,6 +238,14 @@ class _FusedTowerStep(RowSparseTrainStep):
         if not self._dense_parts:
             return None
         return self._dense_partial, self._dense_parts, self.opt.flat_grad
+
+    def _second_logit_bias_grad(self):
+        """data_ptr of another bias added to the logit (its gradient is sum(d logits), like the head's), or None."""
+        return None
+
+    def _extra_slab_refs(self):
+        """(workspace ptr, gradient ptr, elements, slabs): further partial sums the step's slab reduction adds."""
+        return []
 
 
 class FusedDeepFMStep(_FusedTowerStep):
@@ -294,6 +308,12 @@ class FusedXDeepFMStep(_FusedTowerStep):
         self.cin_ws_b = torch.empty(max(lib.dfm_cin_backward_workspace_bytes(self.cin_sizes, self.cin_L, self.cin_split, B, F, D) // 4, 1),
                                     **f32)
         self.ones = torch.ones(B, 1, **f32)
+        head = model.cin_linear
+        # cin_linear (256 -> 1): a row-dot / outer-product kernel pair instead of six generic GEMM launches
+        self.head1 = bool(lib.dfm_linear1_supported(head.in_features)) and head.out_features == 1
+        if self.head1:
+            self.head1_splits = lib.dfm_linear1_backward_splits(B)
+            self.head1_ws = torch.empty(self.head1_splits, head.in_features, **f32)
         for p in list(cin.parameters()) + list(model.cin_linear.parameters()):
             if p.grad is None or not p.grad.is_contiguous() or not p.is_contiguous():
                 raise RuntimeError("fused steps need RowSparseAdam's flat gradient views on every dense parameter")
@@ -315,8 +335,22 @@ class FusedXDeepFMStep(_FusedTowerStep):
                                        self.cin_ws_f.data_ptr(), _lib.stream_handle()))
         head = self.model.cin_linear                       # explicit = cin_linear(cin(fe))   (xdeepfm.py:41-42)
         K = head.in_features
-        _gemm(self.cin_out, K, True, head.weight, K, True, self.cin_lin, B, 1, K, bias=head.bias)
+        if self.head1:
+            _lib.check(lib.dfm_linear1_forward(self.cin_out.data_ptr(), B, K, head.weight.data_ptr(), _lib.ptr(head.bias),
+                                               self.cin_lin.data_ptr(), _lib.stream_handle()))
+        else:
+            _gemm(self.cin_out, K, True, head.weight, K, True, self.cin_lin, B, 1, K, bias=head.bias)
         return self.cin_lin
+
+    def _second_logit_bias_grad(self):
+        head = self.model.cin_linear
+        return head.bias.grad.data_ptr() if self.head1 and head.bias is not None else None
+
+    def _extra_slab_refs(self):
+        if not self.head1:
+            return []
+        head = self.model.cin_linear
+        return [(self.head1_ws.data_ptr(), head.weight.grad.data_ptr(), head.in_features, self.head1_splits)]
 
     def _interaction_backward(self):
         from deepfm_amd.models.layers.dnn import _gemm
@@ -325,10 +359,15 @@ class FusedXDeepFMStep(_FusedTowerStep):
         head = self.model.cin_linear
         K = head.in_features
         g = self.g_logits                                                     # (B, 1) = d loss / d logit
-        _gemm(g, 1, True, head.weight, K, False, self.g_cin_out, B, K, 1)    # d cin_out = g w
-        _gemm(g, 1, False, self.cin_out, K, False, head.weight.grad, 1, K, B, accumulate=True)       # dW += g^T cin_out
-        if head.bias is not None:
-            _gemm(g, 1, False, self.ones, 1, False, head.bias.grad.view(1, 1), 1, 1, B, accumulate=True)
+        if self.head1:     # d cin_out = g w; dW as slabs for the step's slab reduction; d bias: the head's tail
+            _lib.check(lib.dfm_linear1_backward(g.data_ptr(), self.cin_out.data_ptr(), B, K, head.weight.data_ptr(),
+                                                self.g_cin_out.data_ptr(), self.head1_ws.data_ptr(),
+                                                _lib.stream_handle()))
+        else:
+            _gemm(g, 1, True, head.weight, K, False, self.g_cin_out, B, K, 1)    # d cin_out = g w
+            _gemm(g, 1, False, self.cin_out, K, False, head.weight.grad, 1, K, B, accumulate=True)   # dW += g^T cin_out
+            if head.bias is not None:
+                _gemm(g, 1, False, self.ones, 1, False, head.bias.grad.view(1, 1), 1, 1, B, accumulate=True)
         ws = [c.weight for c in self.cin.conv_layers]
         g_w = [c.weight.grad for c in self.cin.conv_layers]
         g_b = [c.bias.grad for c in self.cin.conv_layers]

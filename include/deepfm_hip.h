@@ -469,6 +469,8 @@ typedef struct dfm_head_tail {
   float* g_w;              /* (features) head weight gradient, ADDED */
   float* g_b;              /* (1) head bias gradient, ADDED (may be NULL) */
   float* loss;             /* (1) mean BCE-with-logits, written */
+  float* g_b2;             /* (1) ADDED the same sum as g_b: the bias of another 1-wide Linear that is added to the
+                            * logit (xDeepFM's cin_linear, xdeepfm.py:41-47), or NULL */
 } dfm_head_tail;
 
 size_t dfm_linear_bn_workspace_bytes(int64_t batch, int features);
@@ -523,6 +525,17 @@ int dfm_linear_backward(const float* d_dz, int64_t batch, int out_features, cons
                         int in_features, const float* d_w, float* d_g_x,
                         const dfm_bn_bwd* bn_below, const dfm_fm_bwd* fm, int parts, void* d_workspace,
                         dfm_stream_t stream);
+/* A Linear with ONE output that is added to the logit (xDeepFM's cin_linear, xdeepfm.py:41-47).
+ * forward: d_out[b] = d_x[b, :] . d_w (+ d_b[0]).  backward: d_g_x[b, :] = d_g[b] * d_w, and the weight
+ * gradient as dfm_linear1_backward_splits(batch) slabs of `features` floats in d_workspace — add them with a
+ * dfm_slab_ref {workspace, g_w, batch 1, out 1, in features, splits}; the bias gradient is sum(d_g) =
+ * dfm_head_tail.g_b2 when d_g is the head's d logits.  features % 4 == 0, <= 1024 (dfm_linear1_supported). */
+int dfm_linear1_supported(int features);
+int dfm_linear1_forward(const float* d_x, int64_t batch, int features, const float* d_w, const float* d_b,
+                        float* d_out, dfm_stream_t stream);
+int dfm_linear1_backward_splits(int64_t batch);
+int dfm_linear1_backward(const float* d_g, const float* d_x, int64_t batch, int features, const float* d_w,
+                         float* d_g_x, void* d_workspace, dfm_stream_t stream);
 /* d_g_w (out, in) += sum of the batch-split partial products of one dfm_linear_backward call. */
 typedef struct dfm_slab_ref {
   const void* workspace;   /* the d_workspace that call was given */

@@ -300,6 +300,37 @@ def test_head_with_the_last_batchnorm_inside_is_bitwise_the_two_launches(M, K, p
         assert torch.equal(two[k], one[k]), k
 
 
+@pytest.mark.parametrize("M,K", [(4096, 256), (1000, 64), (77, 200), (4099, 1024), (5, 4)])
+def test_one_output_linear_kernels_match_torch(M, K):
+    """dfm_linear1_forward / _backward (xDeepFM's cin_linear, xdeepfm.py:41-47) against torch in float64; the weight
+    gradient arrives as slabs and is added by dfm_linear_backward_finish."""
+    from deepfm_amd import _lib
+    lib = _lib.load()
+    assert lib.dfm_linear1_supported(K) == 1 and lib.dfm_linear1_supported(K + 1) == 0 and lib.dfm_linear1_supported(2048) == 0
+    g = torch.Generator(device="cuda").manual_seed(M * 7 + K)
+    x = torch.randn(M, K, device="cuda", generator=g)
+    w = torch.randn(1, K, device="cuda", generator=g)
+    b = torch.randn(1, device="cuda", generator=g)
+    go = torch.randn(M, device="cuda", generator=g)
+    out = torch.empty(M, device="cuda")
+    _lib.check(lib.dfm_linear1_forward(x.data_ptr(), M, K, w.data_ptr(), b.data_ptr(), out.data_ptr(), _lib.stream_handle()))
+    want = (x.double() @ w.double().t()).view(-1) + b.double()
+    assert_close(npy(out), npy(want), rtol=1e-5, atol_scale=2e-6, what="forward")
+    _lib.check(lib.dfm_linear1_forward(x.data_ptr(), M, K, w.data_ptr(), None, out.data_ptr(), _lib.stream_handle()))
+    assert_close(npy(out), npy(want - b.double()), rtol=1e-5, atol_scale=2e-6, what="forward without bias")
+    splits = lib.dfm_linear1_backward_splits(M)
+    ws = torch.full((splits, K), float("nan"), device="cuda")
+    gx = torch.empty(M, K, device="cuda")
+    _lib.check(lib.dfm_linear1_backward(go.data_ptr(), x.data_ptr(), M, K, w.data_ptr(), gx.data_ptr(), ws.data_ptr(),
+                                        _lib.stream_handle()))
+    assert torch.equal(gx, go.view(-1, 1) * w)
+    gw = torch.ones(1, K, device="cuda")
+    ref = _lib.SlabRef()
+    ref.workspace, ref.g_w, ref.batch, ref.out_features, ref.in_features, ref.splits = ws.data_ptr(), gw.data_ptr(), 1, 1, K, splits
+    _lib.check(lib.dfm_linear_backward_finish(C.byref(ref), 1, _lib.stream_handle()))
+    assert_close(npy(gw), npy(go.double().view(1, -1) @ x.double() + 1), rtol=1e-5, atol_scale=2e-6, what="dW (accumulated)")
+
+
 def _fused_pair(B, seed=0):
     from deepfm_amd.training.fused_step import FusedDeepFMStep
     from deepfm_amd.training.rowsparse import RowSparseAdam
