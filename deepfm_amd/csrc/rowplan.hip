@@ -349,7 +349,7 @@ __global__ __launch_bounds__(SORT_THREADS) void rowplan_sort(
 __global__ __launch_bounds__(256) void rowgrad_kernel(
     FieldMap fmap, int S, int F, int D, int lists, const float* __restrict__ g_first,
     const float* __restrict__ g_field, const int32_t* __restrict__ sorted_pos,
-    const int32_t* __restrict__ seg_start, const int32_t* __restrict__ num_uniq,
+    int32_t* seg_start, const int32_t* __restrict__ num_uniq,
     float* __restrict__ row_g2, float* __restrict__ row_g1) {
   tail::rowgrad_body(blockIdx.x, fmap, S, F, D, lists, g_first, g_field, sorted_pos, seg_start, num_uniq, row_g2, row_g1);
 }
@@ -404,7 +404,7 @@ int dfm_rowplan_build(const int64_t* const* ids, const int32_t* vocab, int num_s
 
 int dfm_rowgrad_build(const int32_t* field_of_sparse, int num_sparse, int num_fields, int dim,
                       int64_t n, const float* d_g_first, const float* d_g_field,
-                      const int32_t* d_sorted_pos, const int32_t* d_seg_start,
+                      const int32_t* d_sorted_pos, int32_t* d_seg_start,
                       const int32_t* d_num_uniq, float* d_row_g2, float* d_row_g1,
                       dfm_stream_t stream) {
   DFM_REQUIRE(field_of_sparse && d_g_first && d_g_field && d_sorted_pos && d_seg_start && d_num_uniq &&

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(kThreads) void shard_rowgrad_kernel(FieldMap fm, in
                                                                  const float* __restrict__ g_first,
                                                                  const float* __restrict__ g_field,
                                                                  const int32_t* __restrict__ sorted_pos,
-                                                                 const int32_t* __restrict__ seg_start,
+                                                                 int32_t* seg_start,
                                                                  const int32_t* __restrict__ num_uniq,
                                                                  float* __restrict__ row_g2, float* __restrict__ row_g1,
                                                                  SampleSegments segs) {
@@ -250,7 +250,7 @@ extern "C" int dfm_shard_pack(const int32_t* first_field, const int32_t* field_c
 }
 
 extern "C" int dfm_shard_rowgrad(int num_owned, int dim, int world, int64_t batch, const float* d_recv,
-                                 int64_t segment, const int32_t* d_sorted_pos, const int32_t* d_seg_start,
+                                 int64_t segment, const int32_t* d_sorted_pos, int32_t* d_seg_start,
                                  const int32_t* d_num_uniq, float* d_row_g2, float* d_row_g1, dfm_stream_t stream) {
   DFM_REQUIRE(d_recv && d_sorted_pos && d_seg_start && d_num_uniq && d_row_g2 && d_row_g1, "null argument");
   DFM_REQUIRE(num_owned > 0 && num_owned <= DFM_MAX_FIELDS && world > 0 && dim > 0 && dim % 4 == 0 && batch > 0,

@@ -77,7 +77,7 @@ __device__ __forceinline__ void dense_prepare_slabs_body(int blk, float* __restr
 __global__ __launch_bounds__(kTailThreads) void step_embedding_backward_kernel(
     int dense_blocks, const int32_t* __restrict__ dense_list, PtrTable in, GradTable gt, int64_t B, int F, int D,
     const float* __restrict__ g_first, const float* __restrict__ g_field, FieldMap fmap, int S, int lists,
-    const int32_t* __restrict__ sorted_pos, const int32_t* __restrict__ seg_start,
+    const int32_t* __restrict__ sorted_pos, int32_t* seg_start,
     const int32_t* __restrict__ num_uniq, float* __restrict__ row_g2, float* __restrict__ row_g1,
     DensePartials dp) {
   const int blk = blockIdx.x;
@@ -153,7 +153,7 @@ extern "C" int dfm_step_embedding_backward(const int32_t* d_dense_list, int num_
                                            const dfm_field_grad* dense_grads, const int32_t* field_of_sparse,
                                            int num_sparse, int num_fields, int dim, int64_t batch,
                                            const float* d_g_first, const float* d_g_field,
-                                           const int32_t* d_sorted_pos, const int32_t* d_seg_start,
+                                           const int32_t* d_sorted_pos, int32_t* d_seg_start,
                                            const int32_t* d_num_uniq, float* d_row_g2, float* d_row_g1,
                                            float* d_dense_partials, int dense_parts, const float* d_dense_grad_base,
                                            int64_t dense_grad_elems, dfm_stream_t stream) {

@@ -236,7 +236,7 @@ __device__ __forceinline__ void rowgrad_run(const float* __restrict__ g_field, c
 
 __device__ __forceinline__ void rowgrad_body(int blk, FieldMap fmap, int S, int F, int D, int lists, const float* __restrict__ g_first,
     const float* __restrict__ g_field, const int32_t* __restrict__ sorted_pos,
-    const int32_t* seg_start, const int32_t* __restrict__ num_uniq,
+    int32_t* seg_start, const int32_t* __restrict__ num_uniq,
     float* row_g2, float* row_g1, SampleSegments segs = SampleSegments{0, 0}) {
   __shared__ float red[kRowgradLds];
   __shared__ int s_last;
@@ -263,7 +263,7 @@ __device__ __forceinline__ void rowgrad_body(int blk, FieldMap fmap, int S, int 
   }
   const int nu = list < lists ? num_uniq[list] : 0;
   const bool valid = threadIdx.x < groups * lpr && u < nu;
-  const int32_t* seg = seg_start + (list < lists ? list : 0) * (CH + 1);
+  int32_t* seg = seg_start + (list < lists ? list : 0) * (CH + 1);       // (its tail holds the arrival counter)
   const int n_split = coop && nu > 0 && nu <= CH - kSplitRun ? seg[CH] : 0;     // uniform over the workgroup
   int p0 = 0, p1 = 0;
   if (valid) {
@@ -357,7 +357,7 @@ __device__ __forceinline__ void rowgrad_body(int blk, FieldMap fmap, int S, int 
   // are written and read with agent-scope accesses (write-through / L2-bypassing: a handful of floats), the
   // barrier waits for the stores, then the arrival is counted.  (__threadfence() instead makes every
   // workgroup write back and invalidate its XCD's whole L2: 133 us for this kernel.)
-  int* counter = const_cast<int*>(seg) + (CH - 1 - kMaxSplitRuns);
+  int* counter = seg + (CH - 1 - kMaxSplitRuns);
   __syncthreads();
   if (threadIdx.x == 0)
     s_last = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nsl - 1 ? 1 : 0;

@@ -192,7 +192,7 @@ int dfm_rowplan_build(const int64_t* const* ids, const int32_t* vocab, int num_s
  * (B, F, dim); d_g_first is (B,1).  Uniform plans only (dim == fm_dim). */
 int dfm_rowgrad_build(const int32_t* field_of_sparse, int num_sparse, int num_fields, int dim,
                       int64_t n, const float* d_g_first, const float* d_g_field,
-                      const int32_t* d_sorted_pos, const int32_t* d_seg_start,
+                      const int32_t* d_sorted_pos, int32_t* d_seg_start,
                       const int32_t* d_num_uniq, float* d_row_g2, float* d_row_g1,
                       dfm_stream_t stream);
 
@@ -565,7 +565,7 @@ int dfm_step_embedding_backward(const int32_t* d_dense_list, int num_dense, cons
                                 const dfm_field_grad* dense_grads, const int32_t* field_of_sparse,
                                 int num_sparse, int num_fields, int dim, int64_t batch,
                                 const float* d_g_first, const float* d_g_field,
-                                const int32_t* d_sorted_pos, const int32_t* d_seg_start,
+                                const int32_t* d_sorted_pos, int32_t* d_seg_start,
                                 const int32_t* d_num_uniq, float* d_row_g2, float* d_row_g1,
                                 float* d_dense_partials, int dense_parts, const float* d_dense_grad_base,
                                 int64_t dense_grad_elems, dfm_stream_t stream);
@@ -664,7 +664,7 @@ int dfm_shard_pack(const int32_t* first_field, const int32_t* field_count, int w
  * of `segment` floats each, source-rank major; sample p * batch + b of the row plan is sample b of
  * segment p). */
 int dfm_shard_rowgrad(int num_owned, int dim, int world, int64_t batch, const float* d_recv, int64_t segment,
-                      const int32_t* d_sorted_pos, const int32_t* d_seg_start, const int32_t* d_num_uniq,
+                      const int32_t* d_sorted_pos, int32_t* d_seg_start, const int32_t* d_num_uniq,
                       float* d_row_g2, float* d_row_g1, dfm_stream_t stream);
 /* *d_out = x[0] + ... + x[n-1] in a fixed order (one workgroup): a rank's share of |g|^2. */
 int dfm_sum_floats(const float* d_x, int64_t n, float* d_out, dfm_stream_t stream);
