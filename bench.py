@@ -142,6 +142,9 @@ def cpu_baseline(model, fields, cfg, hp, ids, dense, labels, seconds):
     except Exception:
         threads = os.cpu_count() or 1
     return {"value": done * B / el, "unit": "samples/s", "cores": int(threads), "kind": "port",
+            "formulation": "row-sparse numpy port of this package's step (NOT the reference's dense step: dense V x d "
+                           "gradients + full-table L2 + dense Adam over 442 M parameters; reference-here: 1.6 K samples/s "
+                           "on 8 cores, BASELINE.md section 2)",
             "sample": f"{done} steps of batch {B} (numpy oracle, row-sparse step, {el:.1f} s)",
             "host_cpus": os.cpu_count()}
 
@@ -153,8 +156,7 @@ def build_step(name, V, D, B, dev, args, cin_sizes=None):
     from deepfm_amd.training.fused_step import fused_step_class
     from deepfm_amd.training.rowsparse import RowSparseAdam
     from deepfm_amd.training.step import RowSparseTrainStep
-    from tests.helpers import schema_from_fields
-    from tools_shared import CRITEO_KAGGLE_CARDINALITIES, criteo_fields
+    from deepfm_amd.data.synthetic import CRITEO_KAGGLE_CARDINALITIES, criteo_fields, schema_from_fields
     fields = criteo_fields([c + 1 for c in CRITEO_KAGGLE_CARDINALITIES] if args.vocab_profile == "criteo" else V, D)
     cfg = ExperimentConfig()
     cfg.feature.fm_embed_dim = D

@@ -636,29 +636,63 @@ def rowsparse_reduce_fast(ids: Array, g_rows: Array, g_first: Array):
             np.add.reduceat(g_first[order], starts).astype(F32))
 
 
-def deepfm_train_step_rowsparse(fields, params: Dict[str, Array], state: Dict[str, Array],
-                                batch, labels: Array, cfg: dict, hp: dict, step: int,
-                                exact_order: bool = False, info: Optional[dict] = None) -> F32:
-    """One DeepFM training step in the build's row-sparse mode, in place on ``params`` /
-    ``state`` (``m/<key>``, ``v/<key>`` Adam moments): forward (embedding.py:76-126,
-    fm.py:18-23, dnn.py:45-59, deepfm.py:30-42), BCE + L2 on the non-table embedding
-    parameters (trainer.py:221-225), backward, lazy L2 on touched rows, global-norm clip
-    (trainer.py:232-235), Adam (trainer.py:237).  hp: lr, l2, max_grad_norm, betas, eps.
+def train_step_rowsparse(model: str, fields, params: Dict[str, Array], state: Dict[str, Array],
+                         batch, labels: Array, cfg: dict, hp: dict, step: int,
+                         exact_order: bool = False, info: Optional[dict] = None) -> F32:
+    """One training step of ``model`` in {"deepfm", "xdeepfm", "attention_deepfm"} in the build's
+    row-sparse mode, in place on ``params`` / ``state`` (``m/<key>``, ``v/<key>`` Adam moments): forward
+    (embedding.py:76-126 + the model's ``_forward_components``: deepfm.py:30-42, xdeepfm.py:36-48,
+    attention_deepfm.py:48-66), BCE + L2 on the non-table embedding parameters (trainer.py:221-225),
+    backward, lazy L2 on touched rows, global-norm clip (trainer.py:232-235), Adam (trainer.py:237).
+    hp: lr, l2, max_grad_norm, betas, eps.  ``cfg`` as for ``model_logits``.
     ``info`` (optional) receives logits, the squared global gradient norm, the clip coefficient, the
     per-field row gradients (ids, rows incl. the L2 term, first-order) and the dense gradients."""
     emb_p = _sub(params, "embedding.")
     fo, fe, fl = embedding_forward(fields, emb_p, batch, cfg["fm_dim"])
+    B = fe.shape[0]
     n_hidden = len(cfg["hidden_units"])
     dnn_p = _sub(params, "dnn.")
-    h = dnn_forward(fl, dnn_p, n_hidden, training=True)
-    logits = fo + fm_forward(fe) + linear_forward(h, params, "output_linear.")
-    loss, dz = bce_with_logits(logits, labels)
+    act, bn = cfg.get("activation", "relu"), cfg.get("use_batch_norm", True)
     grads: Dict[str, Array] = {}
-    grads["output_linear.weight"] = (dz.T @ h).astype(F32)
-    grads["output_linear.bias"] = dz.sum(axis=0, dtype=F32)
-    d_fl, dnn_g = dnn_backward(fl, dnn_p, n_hidden, dz @ params["output_linear.weight"], training=True)
+
+    def head_backward(prefix, x_in, dz):
+        grads[prefix + "weight"] = (dz.T @ x_in).astype(F32)
+        grads[prefix + "bias"] = dz.sum(axis=0, dtype=F32)
+        return (dz @ params[prefix + "weight"]).astype(F32)
+
+    if model == "deepfm":
+        h = dnn_forward(fl, dnn_p, n_hidden, act, bn, training=True)
+        logits = fo + fm_forward(fe) + linear_forward(h, params, "output_linear.")
+        loss, dz = bce_with_logits(logits, labels)
+        d_fl, dnn_g = dnn_backward(fl, dnn_p, n_hidden, head_backward("output_linear.", h, dz), act, bn, training=True)
+        d_fe = fm_backward(fe, dz) + d_fl.reshape(fe.shape)  # uniform schema: flat == fe reshaped
+    elif model == "xdeepfm":
+        cin_p = _sub(params, "cin.")
+        sizes, split = cfg["cin_layer_sizes"], cfg["cin_split_half"]
+        cin_out = cin_forward(fe, cin_p, sizes, split)
+        h = dnn_forward(fl, dnn_p, n_hidden, act, bn, training=True)
+        logits = fo + linear_forward(cin_out, params, "cin_linear.") + linear_forward(h, params, "dnn_linear.")
+        loss, dz = bce_with_logits(logits, labels)
+        d_cin, cin_g = cin_backward(fe, cin_p, sizes, split, head_backward("cin_linear.", cin_out, dz))
+        grads.update({"cin." + k: v for k, v in cin_g.items()})
+        d_fl, dnn_g = dnn_backward(fl, dnn_p, n_hidden, head_backward("dnn_linear.", h, dz), act, bn, training=True)
+        d_fe = d_cin + d_fl.reshape(fe.shape)                # no FM term in xDeepFM (xdeepfm.py:36-48)
+    elif model == "attention_deepfm":
+        att_p = _sub(params, "attention.")
+        heads, layers, res = cfg["num_heads"], cfg["num_layers"], cfg["use_residual"]
+        att = attention_forward(fe, att_p, heads, layers, res)
+        dnn_in = np.concatenate([att.reshape(B, -1), fl], axis=1)
+        h = dnn_forward(dnn_in, dnn_p, n_hidden, act, bn, training=True)
+        logits = fo + fm_forward(fe) + linear_forward(h, params, "output_linear.")
+        loss, dz = bce_with_logits(logits, labels)
+        d_in, dnn_g = dnn_backward(dnn_in, dnn_p, n_hidden, head_backward("output_linear.", h, dz), act, bn, training=True)
+        n_att = att.shape[1] * att.shape[2]
+        d_att, att_g = attention_backward(fe, att_p, heads, layers, res, d_in[:, :n_att].reshape(att.shape))
+        grads.update({"attention." + k: v for k, v in att_g.items()})
+        d_fe = fm_backward(fe, dz) + d_in[:, n_att:].reshape(fe.shape) + d_att   # FM uses the un-attended fe
+    else:
+        raise ValueError(f"Unknown model: {model}")
     grads.update({"dnn." + k: v for k, v in dnn_g.items()})
-    d_fe = fm_backward(fe, dz) + d_fl.reshape(fe.shape)      # uniform schema: flat == fe reshaped
     l2 = F32(hp["l2"])
     rows = {}
     sq = 0.0
@@ -684,7 +718,7 @@ def deepfm_train_step_rowsparse(fields, params: Dict[str, Array], state: Dict[st
         sq += float((g.astype(np.float64) ** 2).sum())
     coef = clip_coef(sq, hp["max_grad_norm"]) if hp.get("max_grad_norm") else F32(1.0)
     if info is not None:
-        info.update(logits=logits, sq_norm=sq, coef=coef, rows=rows, grads=grads)
+        info.update(logits=logits, sq_norm=sq, coef=coef, rows=rows, grads=grads, d_fe=d_fe)
     b1, b2 = hp.get("betas", (0.9, 0.999))
     eps = hp.get("eps", 1e-8)
     for k, g in grads.items():
@@ -696,3 +730,9 @@ def deepfm_train_step_rowsparse(fields, params: Dict[str, Array], state: Dict[st
             adam_update(w, m, v, g * coef, step, hp["lr"], b1, b2, eps)
             params[key][uniq], state["m/" + key][uniq], state["v/" + key][uniq] = w, m, v
     return loss
+
+
+def deepfm_train_step_rowsparse(fields, params, state, batch, labels, cfg, hp, step,
+                                exact_order: bool = False, info: Optional[dict] = None) -> F32:
+    """``train_step_rowsparse("deepfm", ...)`` (the name the round-1/2 tests and bench.py use)."""
+    return train_step_rowsparse("deepfm", fields, params, state, batch, labels, cfg, hp, step, exact_order, info)

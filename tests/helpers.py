@@ -74,13 +74,7 @@ def cin_full_params(F=39, layer_sizes=(128, 128, 128), split_half=True):
 
 # ---- glue between the golden "fields" description and the package's schema objects ----
 
-def schema_from_fields(fields):
-    from deepfm_amd.data.schema import DatasetSchema, FeatureType, FieldSchema
-    kind = {"sparse": FeatureType.SPARSE, "dense": FeatureType.DENSE, "sequence": FeatureType.SEQUENCE}
-    return DatasetSchema(fields={
-        f["name"]: FieldSchema(name=f["name"], feature_type=kind[f["type"]], vocabulary_size=f["vocab"],
-                               embedding_dim=f["dim"], max_length=f["max_len"], combiner=f["combiner"])
-        for f in fields})
+from deepfm_amd.data.synthetic import random_fields_batch, schema_from_fields  # noqa: E402,F401  (package helpers)
 
 
 def load_params(module, params: Dict[str, np.ndarray], device="cuda"):
@@ -98,20 +92,6 @@ def to_device_batch(batch: Dict[str, np.ndarray], device="cuda"):
 
 def npy(t):
     return t.detach().cpu().numpy()
-
-
-def random_fields_batch(fields, B, rng, zero_frac=0.01):
-    batch = {}
-    for f in fields:
-        if f["type"] == "sparse":
-            x = rng.integers(1, f["vocab"], size=B, dtype=np.int64)
-            x[rng.random(B) < zero_frac] = 0
-        elif f["type"] == "sequence":
-            x = rng.integers(0, f["vocab"], size=(B, f["max_len"]), dtype=np.int64)
-        else:
-            x = rng.random(B).astype(np.float32)
-        batch[f["name"]] = x
-    return batch
 
 
 def assert_close_mostly(got, want, max_bad_frac: float, rtol: float = RTOL, atol_scale: float = 1e-5, what: str = ""):

@@ -54,13 +54,13 @@ def test_cin_reference_shape_tests():
 
 
 def test_cin_cfg3_batch_vs_oracle():
-    """BASELINE.json config 3 layer sizes at a batch the oracle finishes in seconds."""
+    """BASELINE.json config 3: layer sizes [128,128,128] at the FULL batch of 4096 (cin.py:66-105)."""
     rng = np.random.default_rng(7)
     params = cin_full_params()
     g = load("cin_criteo_full")
     cin = _module(g, params)
-    x = (rng.standard_normal((192, 39, 16)) * 0.7).astype(np.float32)
-    up = rng.standard_normal((192, 256)).astype(np.float32)
+    x = (rng.standard_normal((4096, 39, 16)) * 0.7).astype(np.float32)
+    up = rng.standard_normal((4096, 256)).astype(np.float32)
     t = torch.from_numpy(x).cuda().requires_grad_()
     out = cin(t)
     (out * torch.from_numpy(up).cuda()).sum().backward()

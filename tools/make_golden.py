@@ -340,7 +340,7 @@ def covering_batch(fields, B: int, rng: np.random.Generator):
     return batch
 
 
-def case_train_steps(name, fields, hidden, B, steps, seed, lr, l2, clip, scale=0.25):
+def case_train_steps(name, fields, hidden, B, steps, seed, lr, l2, clip, scale=0.25, kind="deepfm", fm_dim=16, **kw):
     """The body of the reference's ``Trainer._train_epoch`` (trainer.py:212-240) run for ``steps``
     batches on the reference's own layer classes: BCEWithLogitsLoss (trainer.py:59) + the L2 term of
     ``BaseCTRModel.get_l2_reg_loss`` (base.py:78-83: lambda * sum ||p||_2^2 over embedding.parameters()),
@@ -348,13 +348,13 @@ def case_train_steps(name, fields, hidden, B, steps, seed, lr, l2, clip, scale=0
     (trainer.py:228-235) / ``torch.optim.Adam(model.parameters(), lr)`` (trainer.py:67-70, 237)."""
     rng = np.random.default_rng(seed)
     torch.manual_seed(seed)
-    model = _RefComposite("deepfm", to_schema(fields), 16, hidden)
+    model = _RefComposite(kind, to_schema(fields), fm_dim, hidden, **kw)
     randomize_(model, rng, scale=scale)
     model.train()
     criterion = nn.BCEWithLogitsLoss()
     optimizer = torch.optim.Adam(model.parameters(), lr=lr)
     import json
-    cfg = dict(kind="deepfm", fm_dim=16, hidden_units=hidden)
+    cfg = dict(kind=kind, fm_dim=fm_dim, hidden_units=hidden, **kw)
     arrays = dict(fields=fields_meta(fields), cfg=np.array(json.dumps(cfg)), steps=np.int64(steps),
                   lr=np.float64(lr), l2=np.float64(l2), clip=np.float64(clip))
     arrays.update(sd_np(model, "init/"))
@@ -396,6 +396,19 @@ def main():
                      lr=1e-3, l2=1e-5, clip=1.0)                       # reference defaults (config.py:30,64,70)
     case_train_steps("train_steps_deepfm_l2clip", criteo_fields(9, 16), [64, 32], 48, 3, 502,
                      lr=1e-2, l2=1e-2, clip=0.25)                      # L2 and clipping both bite
+    # the same trainer body over the other two compositions (xdeepfm.py:36-48: CIN with split-half, three
+    # layers; attention_deepfm.py:48-66: embed_dim 32, attention_dim 64, 4 heads, residual LayerNorm) —
+    # what bench.py's extra_configs time as FusedXDeepFMStep / FusedAttentionDeepFMStep
+    case_train_steps("train_steps_xdeepfm", criteo_fields(12, 16), [64, 32], 64, 3, 503,
+                     lr=1e-3, l2=1e-5, clip=1.0, kind="xdeepfm", cin_sizes=[16, 16, 8], cin_split=True)
+    case_train_steps("train_steps_xdeepfm_l2clip", criteo_fields(9, 16), [64, 32], 48, 3, 504,
+                     lr=1e-2, l2=1e-2, clip=0.25, kind="xdeepfm", cin_sizes=[24, 12], cin_split=True)
+    case_train_steps("train_steps_attention_deepfm", criteo_fields(10, 32), [32, 32], 64, 3, 505,
+                     lr=1e-3, l2=1e-5, clip=1.0, kind="attention_deepfm", fm_dim=32,
+                     heads=4, A=64, layers=1, residual=True)
+    case_train_steps("train_steps_attention_deepfm_l2clip", criteo_fields(9, 32), [32, 32], 48, 3, 506,
+                     lr=1e-2, l2=1e-2, clip=0.25, kind="attention_deepfm", fm_dim=32,
+                     heads=4, A=64, layers=2, residual=True)
     if os.environ.get("GOLDEN_ONLY") == "train":
         return
     # FeatureEmbedding

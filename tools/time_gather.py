@@ -15,7 +15,7 @@ sys.path.insert(0, ROOT)
 from deepfm_amd import _lib  # noqa: E402
 from deepfm_amd.config import ExperimentConfig  # noqa: E402
 from deepfm_amd.models import create_model  # noqa: E402
-from tests.helpers import schema_from_fields  # noqa: E402
+from deepfm_amd.data.synthetic import schema_from_fields  # noqa: E402
 from tools_shared import criteo_fields  # noqa: E402
 
 

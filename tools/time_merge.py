@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from deepfm_amd.config import ExperimentConfig  # noqa: E402
 from deepfm_amd.models import create_model  # noqa: E402
 from deepfm_amd.training.rowsparse import RowSparseAdam  # noqa: E402
-from tests.helpers import schema_from_fields  # noqa: E402
+from deepfm_amd.data.synthetic import schema_from_fields  # noqa: E402
 from tools_shared import criteo_fields  # noqa: E402
 
 

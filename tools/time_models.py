@@ -15,7 +15,7 @@ from deepfm_amd.models import create_model  # noqa: E402
 from deepfm_amd.training.fused_step import fused_step_class  # noqa: E402
 from deepfm_amd.training.rowsparse import RowSparseAdam  # noqa: E402
 from deepfm_amd.training.step import RowSparseTrainStep  # noqa: E402
-from tests.helpers import schema_from_fields  # noqa: E402
+from deepfm_amd.data.synthetic import schema_from_fields  # noqa: E402
 from tools_shared import criteo_fields  # noqa: E402
 
 

@@ -23,7 +23,7 @@ from deepfm_amd.config import ExperimentConfig  # noqa: E402
 from deepfm_amd.models import create_model  # noqa: E402
 from deepfm_amd.training import exchange  # noqa: E402
 from deepfm_amd.training.sharded import ShardedRowAdam, TableShard, sharded_step_class  # noqa: E402
-from tests.helpers import schema_from_fields  # noqa: E402
+from deepfm_amd.data.synthetic import schema_from_fields  # noqa: E402
 from tools_shared import criteo_fields  # noqa: E402
 
 
