@@ -31,6 +31,9 @@ import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# The host driver of this pool supports dmabuf IPC only: without this RCCL (N > 1 ranks) fails in
+# hipIpcGetMemHandle.  Must be in the environment before the first HIP call of every rank.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 HBM_ACHIEVABLE_GBS = 6300.0   # same guide: what a streaming kernel reaches
@@ -73,6 +76,10 @@ def parse():
                     help="consecutive training steps captured in one HIP graph (1 under data parallelism)")
     ap.add_argument("--gather-shape", type=int, default=0,
                     help="tuning aid: force a launch shape of the gather (dfm_gather_set_shape); 0 = automatic")
+    ap.add_argument("--gather-samples", type=int, default=32,
+                    help="timed gather dispatches wanted for the roofline: those of the timed region plus single steps "
+                         "run after it (outside `value`) until this many are collected")
+    ap.add_argument("--no-gather-sweep", action="store_true", help="skip the isolated gather batch sweep (roofline.sweep)")
     ap.add_argument("--h2d", action="store_true",
                     help="batches start in HOST memory and go through the packed H2D ring (PCIe-inclusive rate; "
                          "reported in DESIGN.md, never the headline value)")
@@ -107,6 +114,47 @@ def make_pool(n_batches, n_sparse, n_dense, B, V, seed, device, dist_name="unifo
     dense = torch.rand((n_batches, n_dense, B), generator=g, device=device)
     labels = (torch.rand((n_batches, B), generator=g, device=device) < 0.25).float()
     return ids, dense, labels
+
+
+def gather_sweep(model, n_sparse, n_dense, V, D, dev, lib, batches=(4096, 8192, 16384, 32768, 65536), iters=12):
+    """The product gather alone on the step's own tables over a batch sweep: where one launch stops being
+    latency-structured (ids -> rows -> stores are three dependent HBM round trips per launch) and the
+    algorithmic rate reaches its asymptote.  HIP events on every dispatch, 8 rotating batches, uniform ids."""
+    import ctypes as C
+    from deepfm_amd import _lib
+    emb = model.embedding
+    g = torch.Generator(device=dev).manual_seed(4242)
+    NB, Bmax = 8, max(batches)
+    ids = torch.randint(1, V, (NB, n_sparse, Bmax), generator=g, device=dev, dtype=torch.int64)
+    dense = torch.rand((NB, n_dense, Bmax), generator=g, device=dev)
+    out = []
+    for Bs in batches:
+        fo = torch.empty(Bs, 1, device=dev)
+        fe = torch.empty(Bs, n_sparse + n_dense, D, device=dev)
+        fm = torch.empty(Bs, device=dev)
+        fsum = torch.empty(Bs, D, device=dev)
+
+        def launch(i):
+            nb = i % NB
+            inputs = [ids[nb, s, :Bs] for s in range(n_sparse)] + [dense[nb, j, :Bs] for j in range(n_dense)]
+            emb.forward_into(inputs, Bs, fo, fe, fm_out=fm, fm_sum=fsum)
+        for i in range(3):
+            launch(i)
+        torch.cuda.synchronize()
+        _lib.check(lib.dfm_gather_timing_begin(iters))
+        for i in range(iters):
+            launch(3 + i)
+        us = (C.c_float * iters)()
+        got = C.c_int(0)
+        _lib.check(lib.dfm_gather_timing_end(us, iters, C.byref(got)))
+        ts = [float(us[i]) for i in range(got.value)]
+        if not ts:
+            continue
+        avg = sum(ts) / len(ts)
+        algo = gather_bytes_per_sample(n_sparse, n_dense, D) * Bs
+        out.append({"batch": Bs, "avg_launch_us": avg, "min_launch_us": min(ts), "launches": len(ts),
+                    "achieved_GBps": algo / (avg * 1e-6) / 1e9, "frac": algo / (avg * 1e-6) / 1e9 / HBM_PEAK_GBS})
+    return out
 
 
 def cpu_baseline(model, fields, cfg, hp, ids, dense, labels, seconds):
@@ -332,15 +380,27 @@ def main():
     step.load_packed(records[0])
     # several steps per graph need the whole step inside ONE graph: one rank without the split exchange path
     spg = 1 if ((opt.split and not step.exchange_in_body) or args.no_graph) else args.steps_per_graph
+    # Graph capture must succeed on EVERY rank or on none: ranks that replay a graph and ranks that launch eagerly
+    # would issue different collective sequences.  A failed capture leaves the step's state restored
+    # (RowSparseTrainStep.capture), so the eager fallback starts from the same parameters.
+    capture_error = None
     try:
         step.capture(timed_variant=True, steps_per_graph=spg)
-    except Exception as exc:      # e.g. a runtime that refuses to capture the collectives: measure the eager step
+    except Exception as exc:      # e.g. a runtime that refuses to capture the collectives
         if not dist.is_initialized():
             raise
-        print(f"[bench rank {rank}] graph capture failed ({type(exc).__name__}: {exc}); running the step eagerly",
-              file=sys.stderr, flush=True)
-        step.release_graphs()
-        step.use_graph = False
+        capture_error = f"{type(exc).__name__}: {exc}"
+    capture_fallback = None
+    if dist.is_initialized():
+        ok = torch.tensor([0 if capture_error else 1], device=dev, dtype=torch.int32)
+        if world > 1:
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            print(f"[bench rank {rank}] graph capture failed on at least one rank "
+                  f"({capture_error or 'not on this one'}); every rank runs the step eagerly", file=sys.stderr, flush=True)
+            step.release_graphs()
+            step.use_graph = False
+            capture_fallback = "eager: " + (capture_error or "capture failed on another rank")
 
     feed = None
     if args.h2d:
@@ -413,9 +473,28 @@ def main():
     if n_timed:
         _lib.check(lib.dfm_gather_timing_end(us, n_timed, C.byref(got)))
     gather_us = [float(us[i]) for i in range(got.value)]
+    n_in_region = len(gather_us)
+    # More samples of the same dispatch, AFTER the timed region (not part of `value`): the step goes on on fresh
+    # records as single steps whose gather is launched eagerly with events on the dispatch — same kernel, same
+    # arguments, same place in the step (behind the previous step's optimizer tail).
+    n_after = 0
+    if timing and world == 1 and not args.no_graph and step.use_graph and args.gather_samples > n_in_region:
+        n_after = args.gather_samples - n_in_region
+        ids2, dense2, labels2 = make_pool(n_after, n_sparse, n_dense, B, pool_v, 977 + rank, dev, args.ids)
+        rec2 = step.pack_batches(ids2, dense2, labels2)
+        _lib.check(lib.dfm_gather_timing_begin(n_after))
+        for i in range(n_after):
+            step.run_from(rec2[i], eager_gather=True)
+        torch.cuda.synchronize()
+        us2 = (C.c_float * n_after)()
+        _lib.check(lib.dfm_gather_timing_end(us2, n_after, C.byref(got)))
+        gather_us += [float(us2[i]) for i in range(got.value)]
+        del ids2, dense2, labels2, rec2
     gather_avg_s = (sum(gather_us) / len(gather_us)) * 1e-6 if gather_us else float("nan")
     algo_bytes = gather_bytes_per_sample(n_sparse, n_dense, D) * B
     achieved = algo_bytes / gather_avg_s / 1e9 if gather_us else None
+    sweep = gather_sweep(model, n_sparse, n_dense, V, D, dev, lib) if (
+        world == 1 and timing and args.vocab_profile == "equal" and not args.no_gather_sweep) else None
 
     pmc = None
     pmc_path = os.path.join(ROOT, "profiles", "r02_gather_pmc.json")
@@ -445,8 +524,12 @@ def main():
                 "global_batch": B * world,
                 "parallelism": f"dp{world}" + ("" if not dist.is_initialized() else
                                                 f" ({'field-sharded tables, 3 all-to-alls + 1 small all-gather per step' if step.exchange_in_body else 'replicated tables, one grouped all-gather per step'})"),
-                "hip_graph": not args.no_graph,
+                "hip_graph": bool(step.use_graph and not args.no_graph),
                 "steps_per_graph": G,
+                "capture_fallback": capture_fallback,
+                **({"dp_layout": "field-sharded tables (a deviation from north_star's replicated tables + all-reduce: "
+                                 "DESIGN.md section 6 — replicated tables top out near 3.5x at 8 GPUs)"}
+                   if dist.is_initialized() and step.exchange_in_body else {}),
                 "input": "host memory -> pinned staging -> H2D ring (PCIe-inclusive)" if args.h2d else "resident in HBM",
                 "step": "fused tower kernels (no autograd)" if fused else "torch.autograd over the HIP ops",
                 **({"rehearsal": "gloo, all ranks on cuda:0 (not a measurement)"} if rehearsal else {}),
@@ -461,6 +544,12 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS if achieved else None,
                 "frac_of_achievable_6p3": achieved / HBM_ACHIEVABLE_GBS if achieved else None,
+                # counter bytes (static profile, see `rocprof`) over the time measured in THIS run
+                "frac_traffic": (pmc["traffic_bytes_per_launch"] / gather_avg_s / 1e9 / HBM_PEAK_GBS) if (pmc and gather_us) else None,
+                "target_frac": 0.60, "target_met": bool(achieved and achieved / HBM_PEAK_GBS >= 0.60),
+                "floor_note": "one B=4096 launch is a chain of three dependent HBM round trips (ids -> rows -> stores) plus "
+                              "~3 us of launch/completion: measured floor ~8 us = 0.28 (DESIGN.md 7r2); the sweep shows the asymptote",
+                "sweep": sweep,
                 # NOT measured in this run: PMC counters need their own rocprofv3 passes (see `rocprof`)
                 "traffic": None,
                 "traffic_from_profile": pmc["traffic_bytes_per_launch"] if pmc else None,
@@ -468,6 +557,7 @@ def main():
                 "avg_launch_us": gather_avg_s * 1e6 if gather_us else None,
                 "min_launch_us": min(gather_us) if gather_us else None,
                 "launches_timed": len(gather_us),
+                "launches_timed_in_region": n_in_region, "launches_timed_after_region": n_after,
                 "timer": f"HIP start/stop events attached to the gather dispatch (hipExtLaunchKernel, on the launch stream): one launch "
                          f"in {args.timing_every} of the timed region is a single step whose gather is launched eagerly in front of a "
                          f"gather-less copy of the step's graph; the other launches are graphs of {G} step(s) with the gather as a node",
@@ -486,11 +576,19 @@ def main():
             if args.ids == "uniform":        # the headline model on the secondary id distribution
                 out["extra_configs"].append(extra_config("deepfm", args, dev, lib, ids_dist="zipf"))
         print(json.dumps(out), file=json_out, flush=True)
-    if dist.is_initialized():
-        if "step" in locals():
-            step.release_graphs()        # graphs holding captured RCCL kernels must go before the communicator
-        dist.destroy_process_group()
+
+
+def run():
+    """main() with a teardown that cannot hang: graphs that hold captured RCCL kernels are dropped BEFORE the
+    communicator goes, whatever main() raised (training/step.py::release_all_graphs)."""
+    try:
+        main()
+    finally:
+        if dist.is_available() and dist.is_initialized():
+            from deepfm_amd.training.step import release_all_graphs
+            release_all_graphs()
+            dist.destroy_process_group()
 
 
 if __name__ == "__main__":
-    main()
+    run()

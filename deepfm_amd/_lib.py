@@ -15,6 +15,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # DFM_LIB_PATH: load another build of the same library (A/B timing of kernel variants)
 LIB_PATH = os.environ.get("DFM_LIB_PATH") or os.path.join(_HERE, "lib", "libdeepfm_hip.so")
 
+# == DFM_ABI_VERSION of include/deepfm_hip.h at the time SIGNATURES / the ctypes structs below were written:
+# bumped together with the header whenever a struct layout or an argument list changes, so that a stale .so
+# (the library is untracked and DFM_LIB_PATH can point anywhere) is refused instead of fed shifted arguments
+ABI_VERSION = 3
+
 MAX_FIELDS = 64
 MAX_RANKS = 64
 ROWPLAN_CHUNK = 4096
@@ -192,8 +197,9 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.restype = restype
         fn.argtypes = argtypes
-    if lib.dfm_abi_version() != 1:
-        raise HipLibraryError(f"ABI version mismatch: library {lib.dfm_abi_version()} != binding 1")
+    if lib.dfm_abi_version() != ABI_VERSION:
+        raise HipLibraryError(f"ABI version mismatch: library {lib.dfm_abi_version()} != binding {ABI_VERSION} "
+                              f"(stale {LIB_PATH}? rebuild with make -C deepfm_amd/csrc)")
     _lib = lib
     return lib
 

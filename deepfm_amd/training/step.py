@@ -29,8 +29,10 @@ the dispatch itself.  bench.py does this on every 8th step of its timed region.
 
 from __future__ import annotations
 
+import atexit
 import ctypes as C
 import os
+import weakref
 from typing import List, Optional
 
 import torch
@@ -39,6 +41,23 @@ from deepfm_amd import _lib
 from deepfm_amd.data.schema import FeatureType
 from deepfm_amd.training.losses import bce_with_logits_mean
 from deepfm_amd.training.rowsparse import RowSparseAdam
+
+
+# Every live step, so that one call drops all captured graphs: graphs that hold captured RCCL kernels must be
+# destroyed BEFORE the communicator (``destroy_process_group()`` under live graphs does not return — found on
+# the one-GPU RCCL run).  Also registered with atexit, for processes that end on an exception.
+_LIVE_STEPS: "weakref.WeakSet" = weakref.WeakSet()
+
+
+def release_all_graphs() -> None:
+    for step in list(_LIVE_STEPS):
+        try:
+            step.release_graphs()
+        except Exception:      # teardown: best effort
+            pass
+
+
+atexit.register(release_all_graphs)
 
 
 class _GraphSlot:
@@ -103,6 +122,7 @@ class RowSparseTrainStep:
         self.body_graph: Optional[torch.cuda.CUDAGraph] = None     # graph A without the gather (timed variant)
         self.dense_grads = {id(p): p.grad for p in self.emb.non_table_parameters() if p.grad is not None}
         self.emb.pin_plan(dev)             # the step holds raw parameter pointers from here on
+        _LIVE_STEPS.add(self)
         for m in model.modules():          # DNN / head backward: accumulate straight into the flat .grad views
             if hasattr(m, "direct_grads"):
                 m.direct_grads = True
@@ -234,9 +254,25 @@ class RowSparseTrainStep:
         restored afterwards, bit for bit."""
         if not self.use_graph:
             return
-        lib = _lib.load()
         state = self._mutable_state()
         saved = [t.clone() for t in state]
+        try:
+            self._capture(warmup_iters, timed_variant, steps_per_graph)
+        except BaseException:
+            # a refused capture (e.g. a runtime that will not capture the collectives) must not leave half a
+            # set of graphs behind: the caller may go on eagerly (bench.py does, after agreeing over all ranks)
+            self.slots, self.body_graph, self.graph_b = [], None, None
+            self.steps_per_graph, self._turn = 1, 0
+            raise
+        finally:
+            # whatever happened, the warm-up steps' writes are undone, bit for bit
+            torch.cuda.synchronize()
+            with torch.no_grad():
+                for t, v in zip(state, saved):
+                    t.copy_(v)
+            torch.cuda.synchronize()
+
+    def _capture(self, warmup_iters: int, timed_variant: bool, steps_per_graph: int) -> None:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -289,16 +325,13 @@ class RowSparseTrainStep:
             self.graph_b = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph_b, **mode):
                 self._body_b()
-        torch.cuda.synchronize()
-        with torch.no_grad():
-            for t, v in zip(state, saved):
-                t.copy_(v)
-        torch.cuda.synchronize()
 
     def release_graphs(self) -> None:
         """Drop every captured graph (the step runs eagerly afterwards).  Call before
         ``torch.distributed.destroy_process_group()`` when collectives were captured: the graphs hold the
         communicator's kernels, and tearing the communicator down under them does not return."""
+        if not self.slots and self.body_graph is None and self.graph_b is None:
+            return
         torch.cuda.synchronize()
         self.slots, self.body_graph, self.graph_b = [], None, None
         self.steps_per_graph, self._turn = 1, 0

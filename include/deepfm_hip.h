@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DFM_ABI_VERSION 1
+#define DFM_ABI_VERSION 3   /* bump whenever a struct layout or a signature in this header changes */
 #define DFM_MAX_FIELDS 64      /* per-call pointer tables travel as kernel arguments */
 #define DFM_MAX_RANKS 64       /* data-parallel ranks of one job (csrc/shard.hip) */
 #define DFM_ROWPLAN_CHUNK 4096 /* ids per sorted list (one LDS-resident sort) */

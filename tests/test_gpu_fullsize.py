@@ -32,8 +32,16 @@ V, B, S, ND = 1_000_000, 4096, 26, 13
 # Fresh xavier tables at V = 10^6 are ~2e-3: products of two or three of them (CIN) and scores of a softmax
 # (attention) vanish in fp32 noise, and the interaction layers would be checked on zeros.  Configurations 3
 # and 4 therefore scale the tables to a trained-like +-0.25 (what the goldens use) before the first step.
+# "-kinkfree" variants: every BatchNorm bias of the tower (and every CIN bias) is set to +6 / -6 (every third unit
+# dead), so that no pre-activation sits within rounding of the ReLU kink: the gradient is continuous there, NO
+# sample may disagree with the oracle and every moment of every parameter is held to the bar with no outliers.
 KINDS = {
     "deepfm": dict(D=16, table_scale=1.0, kink_share=0.003, ocfg={}),
+    "deepfm-kinkfree": dict(D=16, table_scale=1.0, kink_share=0.0, ocfg={}),
+    "xdeepfm-kinkfree": dict(D=16, table_scale=100.0, kink_share=0.0,
+                             ocfg=dict(cin_layer_sizes=[128, 128, 128], cin_split_half=True)),
+    "attention_deepfm-kinkfree": dict(D=32, table_scale=100.0, kink_share=0.0,
+                                      ocfg=dict(num_heads=4, num_layers=1, use_residual=True)),
     # CIN: 3 x 128 x 16 ReLUs per sample on split-bf16 products (relative error ~1e-5 against the fp32
     # oracle) next to the tower's 448: a few dozen of the batch's 25 M pre-activations land on the other side
     "xdeepfm": dict(D=16, table_scale=100.0, kink_share=0.03,
@@ -55,13 +63,14 @@ def _pool(n, seed):
     return ids, dense, labels
 
 
-@pytest.mark.parametrize("kind", list(KINDS))
-def test_config_two_graph_steps_vs_oracle(kind):
+@pytest.mark.parametrize("case", list(KINDS))
+def test_config_two_graph_steps_vs_oracle(case):
+    kind, kink_free = case.split("-")[0], case.endswith("-kinkfree")
     from deepfm_amd.config import ExperimentConfig
     from deepfm_amd.models import create_model
     from deepfm_amd.training.fused_step import fused_step_class
     from deepfm_amd.training.rowsparse import RowSparseAdam
-    D, table_scale, kink_share = KINDS[kind]["D"], KINDS[kind]["table_scale"], KINDS[kind]["kink_share"]
+    D, table_scale, kink_share = KINDS[case]["D"], KINDS[case]["table_scale"], KINDS[case]["kink_share"]
     RS = (3 * D + 4 + 31) // 32 * 32               # floats per packed record (embedding.py::pack_tables_)
     fields = criteo_fields(V, D)
     cfg = ExperimentConfig()                       # reference defaults: tower [256,128,64], lr 1e-3, l2 1e-5, clip 1
@@ -76,6 +85,17 @@ def test_config_two_graph_steps_vs_oracle(kind):
     with torch.device("cuda"):
         model = create_model(kind, schema_from_fields(fields), cfg)
     model.train()
+    if kink_free:
+        with torch.no_grad():
+            for m in model.dnn.mlp:
+                if isinstance(m, torch.nn.BatchNorm1d):
+                    c = torch.arange(m.bias.numel(), device="cuda")
+                    m.bias.copy_(torch.where(c % 3 == 2, -6.0, 6.0))
+            if kind == "xdeepfm":
+                for conv in model.cin.conv_layers:
+                    c = torch.arange(conv.bias.numel(), device="cuda")
+                    conv.bias.copy_(torch.where(c % 3 == 2, -6.0, 6.0))
+                    conv.weight.mul_(0.25)
     model.embedding.pack_tables_()
     if table_scale != 1.0:
         with torch.no_grad():
@@ -118,7 +138,7 @@ def test_config_two_graph_steps_vs_oracle(kind):
         if "running_" not in k:
             state["m/" + k], state["v/" + k] = np.zeros_like(v), np.zeros_like(v)
     small_fields = [dict(f, vocab=len(uniq[f["name"]]) + 1) if f["type"] == "sparse" else f for f in fields]
-    ocfg = dict(fm_dim=D, hidden_units=cfg.dnn.hidden_units, **KINDS[kind]["ocfg"])
+    ocfg = dict(fm_dim=D, hidden_units=cfg.dnn.hidden_units, **KINDS[case]["ocfg"])
     dense_h, labels_h = npy(dense), npy(labels)
 
     lr, (b1, b2), eps = hp["lr"], (0.9, 0.999), 1e-8
@@ -193,7 +213,7 @@ def test_config_two_graph_steps_vs_oracle(kind):
             state["m/" + k1s[n]][1:, 0], state["v/" + k1s[n]][1:, 0] = m1, v1
         assert len(kinked) <= kink_share * B, \
             f"step {t}: {len(kinked)} samples disagree with the oracle (ReLU-kink allowance: {int(kink_share * B)})"
-        print(f"[fullsize {kind}] step {t}: {len(kinked)} kinked samples, loss {float(step.loss):.6f} "
+        print(f"[fullsize {case}] step {t}: {len(kinked)} kinked samples, loss {float(step.loss):.6f} "
               f"(oracle {float(oloss):.6f}), |g| {float(opt.sq_norm) ** 0.5:.5f}, clip {coef:.5f}")
         # ---- dense parameters: moments against the oracle, then teacher forcing.  A kinked sample moves the
         # gradient row of the flipped unit by ~1/B of its magnitude: bounded outliers (<= 1 % of a tensor,
@@ -212,16 +232,24 @@ def test_config_two_graph_steps_vs_oracle(kind):
                 gscale = float(np.abs(info["grads"][k]).max()) * coef
                 em = np.abs(gm - state["m/" + k])
                 out_m = em > 1e-4 * np.abs(state["m/" + k]) + 1e-3 * gscale       # batch sums of 4096 cancelling terms
-                assert out_m.mean() <= (0.01 if kinked else 0.0) and em.max() <= 1e-2 * gscale, (k, t, out_m.mean(), em.max())
+                if k.startswith("attention.") and kinked:
+                    # every element of these small tensors is a sum over ALL samples with cancellation (~sqrt(B) of one
+                    # sample's term): each kinked sample shifts every element by up to a few % of 1 / sqrt(B) of the scale
+                    assert em.max() <= (1e-3 + 1e-3 * len(kinked)) * gscale, (k, t, float(em.max() / gscale), len(kinked))
+                else:
+                    assert out_m.mean() <= (0.01 if kinked else 0.0) and em.max() <= 1e-2 * gscale, \
+                        (k, t, float(out_m.mean()), float(em.max() / gscale))
                 ev = np.abs(gv - state["v/" + k])
                 out_v = ev > 2e-4 * np.abs(state["v/" + k]) + 2e-6 * gscale ** 2
-                assert out_v.mean() <= (0.01 if kinked else 0.0), (k, t, out_v.mean())
+                att_kinked = k.startswith("attention.") and bool(kinked)
+                assert out_v.mean() <= (0.01 if kinked else 0.0) or \
+                    (att_kinked and ev.max() <= (2e-3 + 2e-3 * len(kinked)) * gscale ** 2), (k, t, float(out_v.mean()))
                 well = (np.abs(info["grads"][k]) * coef > 1e-6) & ~out_m
                 # 2 % of one Adam step; a kinked sample may push a few small-gradient elements further
                 # (the step is lr * g / |g|-like): at most 0.1 % of a tensor, none beyond 20 % of a step
                 err = np.abs(np.where(well, got_p[k].astype(np.float64) - params[k], 0))
                 bound = 1e-4 * np.abs(params[k]) + 0.02 * lr
-                assert (err > bound).mean() <= (1e-3 if kinked else 0.0) and err.max() <= 0.2 * lr, \
+                assert ((err > bound).mean() <= (1e-3 if kinked else 0.0) or att_kinked) and err.max() <= 0.2 * lr, \
                     (k, t, float((err > bound).mean()), float(err.max()))
             params[k][...], state["m/" + k][...], state["v/" + k][...] = got_p[k], gm, gv
         for k in params:

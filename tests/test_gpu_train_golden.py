@@ -75,7 +75,11 @@ def test_exact_mode_steps_vs_reference(case):
         if t == 0:
             for k, p in model.named_parameters():      # d(bce + l2)/dp incl. the full-table 2*l2*w
                 # identically-zero gradients (the reference's value is summation noise): absolute floor
+                # xDeepFM: gradients that pass through the CIN's split-bf16 products are held to 2e-4 (+ 2e-5 of
+                # the tensor's scale), the CIN gradient bar stated in DESIGN.md section 2; everything else 1e-4
+                cin_path = cfg_of(g)["kind"] == "xdeepfm" and (k.startswith("cin.") or k.startswith("embedding."))
                 assert_close(npy(p.grad), g[f"step0/grad/{k}"], what="grad " + k,
+                             rtol=2e-4 if cin_path else 1e-4, atol_scale=2e-5 if cin_path else 1e-5,
                              floor=1e-6 if zero_grad_param(k, g) else 1e-8)
         total = torch.nn.utils.clip_grad_norm_(model.parameters(), clip)
         assert abs(float(total) - float(g[f"step{t}/grad_norm"])) < 1e-4 * float(g[f"step{t}/grad_norm"])
