@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("DFM_LIB_PATH") or os.path.join(_HERE, "lib", "libdeep
 # == DFM_ABI_VERSION of include/deepfm_hip.h at the time SIGNATURES / the ctypes structs below were written:
 # bumped together with the header whenever a struct layout or an argument list changes, so that a stale .so
 # (the library is untracked and DFM_LIB_PATH can point anywhere) is refused instead of fed shifted arguments
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 MAX_FIELDS = 64
 MAX_RANKS = 64
@@ -98,7 +98,8 @@ SIGNATURES = {
     "dfm_cin_get_mode": (_I, []),
     "dfm_embedding_backward_dense": (_I, [_P, C.POINTER(_P), _L, _P, _P, _P, C.POINTER(FieldGrad), _P, _P]),
     "dfm_embedding_backward_dense_fields": (_I, [_P, C.POINTER(_P), _L, _P, _P, _P, C.POINTER(FieldGrad), _P]),
-    "dfm_rowplan_build": (_I, [C.POINTER(_P), C.POINTER(C.c_int32), _I, _L, _P, _P, _P, _P, _P, _P]),
+    "dfm_rowplan_build": (_I, [C.POINTER(_P), C.POINTER(C.c_int32), _I, _L, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "dfm_rowplan_build_update": (_I, [_P, _P, C.POINTER(_P), C.POINTER(C.c_int32), _I, _L, _P, _P, _P, _P, _P, _P, _I]),
     "dfm_rowgrad_build": (_I, [C.POINTER(C.c_int32), _I, _I, _I, _L, _P, _P, _P, _P, _P, _P, _P, _P]),
     "dfm_rowadam_num_partials": (_L, [_I, _I, _I]),
     "dfm_rowadam_merge": (_I, [C.POINTER(Table), _I, _I, _I, _P, _P, _P, _P, _P, _F, _F, _P, _P]),

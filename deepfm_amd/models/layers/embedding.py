@@ -422,7 +422,30 @@ class FeatureEmbedding(nn.Module):
                 g.proj = _lib.ptr(grads.get(id(proj.weight)))
         return arr
 
-    def build_rowplan(self, inputs: List[torch.Tensor], B: int) -> RowSparseBuffers:
+    def _touch_tables(self):
+        """(dfm_table * S) with the second-order table pointers / row strides: the row plan's touch workgroups."""
+        arr = (_lib.Table * len(self._sparse_pos))()
+        for j, i in enumerate(self._sparse_pos):
+            w = self.second_order_embeddings[self.field_names[i]].weight
+            arr[j].w2, arr[j].stride2 = w.data_ptr(), w.stride(0)
+        return arr
+
+    def _rowplan_args(self, ids_ptrs, B: int, touch: bool):
+        S = len(self._sparse_pos)
+        rs = self.rowsparse
+        ids = (C.c_void_p * S)(*ids_ptrs)
+        specs = list(self.schema.fields.values())
+        vocab = (C.c_int32 * S)(*[specs[i].vocabulary_size for i in self._sparse_pos])
+        tabs = self._touch_tables() if touch else None
+        keep = (ids, vocab, tabs)                    # ctypes arrays must outlive the call
+        return keep, (ids, vocab, S, B, rs.sorted_pos.data_ptr(), rs.uniq_rows.data_ptr(), rs.seg_start.data_ptr(),
+                      rs.num_uniq.data_ptr(), self._err.data_ptr(), tabs, self.fm_embed_dim)
+
+    def build_rowplan(self, inputs: List[torch.Tensor], B: int, ids_ptrs: Optional[List[int]] = None,
+                      touch: bool = False) -> RowSparseBuffers:
+        """Row plan of the batch's ids (``inputs``: every field's input tensor, schema order — or ``ids_ptrs``: the
+        device addresses of the SPARSE fields' id columns, e.g. inside a batch record).  ``touch``: the launch also
+        pulls the batch's table rows and ids into the Infinity Cache (for a gather that follows it)."""
         dev = inputs[0].device
         S = len(self._sparse_pos)
         rs = self.rowsparse
@@ -431,13 +454,16 @@ class FeatureEmbedding(nn.Module):
         rs.has_grad = False
         if S == 0 or B == 0:
             return rs
-        ids = self._ptr_array([inputs[i] for i in self._sparse_pos])
-        specs = list(self.schema.fields.values())
-        vocab = (C.c_int32 * S)(*[specs[i].vocabulary_size for i in self._sparse_pos])
-        _lib.check(_lib.load().dfm_rowplan_build(
-            ids, vocab, S, B, rs.sorted_pos.data_ptr(), rs.uniq_rows.data_ptr(), rs.seg_start.data_ptr(),
-            rs.num_uniq.data_ptr(), self._err.data_ptr(), _lib.stream_handle()))
+        if ids_ptrs is None:
+            ids_ptrs = [inputs[i].data_ptr() for i in self._sparse_pos]
+        keep, args = self._rowplan_args(ids_ptrs, B, touch)
+        _lib.check(_lib.load().dfm_rowplan_build(*args, _lib.stream_handle()))
         return rs
+
+    def rowplan_update(self, graph_exec: int, node, ids_ptrs: List[int], B: int, touch: bool) -> None:
+        """``build_rowplan`` was captured into a HIP graph: point its node at other id columns (host-side only)."""
+        keep, args = self._rowplan_args(ids_ptrs, B, touch)
+        _lib.check(_lib.load().dfm_rowplan_build_update(C.c_void_p(graph_exec), node, *args))
 
     # ------------------------------------------------------------------ forward
     def forward(self, batch: Dict[str, torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:

@@ -207,6 +207,7 @@ class ShardedStepMixin:
     touch points — gather, row plan, embedding backward — with their sharded forms."""
 
     exchange_in_body = True
+    rowplan_first_default = False   # the row plan runs over the GLOBAL batch's ids of the owned fields, after the ids all-to-all
     slabs_travel = True          # the tower's d-weight slabs are summed by the gradient pack kernel
 
     def __init__(self, model, optimizer: ShardedRowAdam, batch_size: int, use_graph: bool = True) -> None:

@@ -71,6 +71,7 @@ class _GraphSlot:
 
 class RowSparseTrainStep:
     exchange_in_body = False      # True: the step's collectives are part of _gather / _body_a / _body_b themselves
+    rowplan_first_default = True  # row plan + row touch in front of the gather (False: in line behind it, round 2's order)
 
     def __init__(self, model, optimizer: RowSparseAdam, batch_size: int, use_graph: bool = True) -> None:
         self.model, self.opt, self.B = model, optimizer, batch_size
@@ -108,6 +109,13 @@ class RowSparseTrainStep:
             else:
                 self.inputs.append(self.dense[di]); self._rec_offsets.append(o1 + di * batch_size * 4); di += 1
         self._rec_labels = o2
+        self._rec_id_offsets = [k * batch_size * 8 for k in range(self.n_sparse)]   # SPARSE id columns of a record
+        # Row plan IN FRONT of the gather, on the batch record itself, with row-touch workgroups (csrc/rowplan.hip):
+        # the sort keeps 26 CUs busy for ~13 us either way; here the other CUs use that time to pull the batch's ids
+        # and table rows on-die, and the gather that follows no longer pays cold ids + three HBM round trips behind
+        # the optimizer's dirty lines.  Same plan, same results; one more graph node re-pointed per step.
+        self.rowplan_first = self.n_sparse > 0 and self.rowplan_first_default
+        self._plan_done = False
         self._record: torch.Tensor = self.inbox       # batch record the next gather reads
         F, D = len(specs), self.emb.fm_embed_dim
         self.fo = torch.empty(batch_size, 1, dtype=torch.float32, device=dev)
@@ -174,24 +182,47 @@ class RowSparseTrainStep:
         return ([base + o for o in self._rec_offsets], self.inputs, self.B, self.fo, self.fe), \
             dict(extra_src_ptr=base + self._rec_labels, extra_dst=self.labels, **self._gather_args())
 
+    def _plan_from_record(self, record: torch.Tensor) -> None:
+        base = record.data_ptr()
+        self.emb.build_rowplan(self.inputs, self.B, ids_ptrs=[base + o for o in self._rec_id_offsets], touch=True)
+        self._plan_done = True
+
     def _gather(self, record: Optional[torch.Tensor] = None) -> None:
-        a, kw = self._gather_call(self._record if record is None else record)
+        record = self._record if record is None else record
+        self._plan_done = False
+        if self.rowplan_first:
+            self._plan_from_record(record)
+        a, kw = self._gather_call(record)
         self.emb.forward_staged(*a, **kw)
 
-    def _capture_gather(self, record: torch.Tensor) -> C.c_void_p:
-        """``_gather`` while the stream is being captured; returns the graph node that reads the batch
-        record (the one ``_update_gather`` re-points before every launch)."""
-        self._gather(record)
+    def _capture_gather(self, record: torch.Tensor):
+        """``_gather`` while the stream is being captured; returns the graph node(s) that read the batch
+        record (the ones ``_update_gather`` re-points before every launch): (gather node, row-plan node or None)."""
+        plan_node = None
+        if self.rowplan_first:
+            self._plan_from_record(record)
+            plan_node = C.c_void_p()
+            _lib.check(_lib.load().dfm_graph_last_node(_lib.stream_handle(), C.byref(plan_node)))
+        a, kw = self._gather_call(record)
+        self.emb.forward_staged(*a, **kw)
         node = C.c_void_p()
         _lib.check(_lib.load().dfm_graph_last_node(_lib.stream_handle(), C.byref(node)))
-        return node
+        return (node, plan_node)
 
-    def _update_gather(self, graph_exec: int, node: C.c_void_p, record: torch.Tensor) -> None:
+    def _update_gather(self, graph_exec: int, node, record: torch.Tensor) -> None:
+        node, plan_node = node
+        if plan_node is not None:
+            base = record.data_ptr()
+            self.emb.rowplan_update(graph_exec, plan_node, [base + o for o in self._rec_id_offsets], self.B, True)
         a, kw = self._gather_call(record)
         self.emb.forward_staged_update(graph_exec, node, *a, **kw)
 
     def _build_rowplan(self) -> None:
-        """Row plan of the step's ids (sort / unique / segments per SPARSE field)."""
+        """Row plan of the step's ids (sort / unique / segments per SPARSE field) — unless ``_gather`` already
+        built it from the batch record (``rowplan_first``)."""
+        if self._plan_done:
+            self._plan_done = False
+            return
         self.emb.build_rowplan(self.inputs, self.B)
 
     def _embedding_backward(self, g_fo: torch.Tensor, g_fe: torch.Tensor) -> None:
@@ -263,6 +294,7 @@ class RowSparseTrainStep:
             # set of graphs behind: the caller may go on eagerly (bench.py does, after agreeing over all ranks)
             self.slots, self.body_graph, self.graph_b = [], None, None
             self.steps_per_graph, self._turn = 1, 0
+            self._plan_done = False
             raise
         finally:
             # whatever happened, the warm-up steps' writes are undone, bit for bit
@@ -318,6 +350,7 @@ class RowSparseTrainStep:
         if timed_variant:
             self.body_graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.body_graph, **mode):
+                self._plan_done = self.rowplan_first      # run(eager_gather=True) launches plan + gather eagerly in front
                 body()
         if not single and not fused_exchange:
             self.opt.exchange()

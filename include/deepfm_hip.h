@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DFM_ABI_VERSION 3   /* bump whenever a struct layout or a signature in this header changes */
+#define DFM_ABI_VERSION 4   /* bump whenever a struct layout or a signature in this header changes */
 #define DFM_MAX_FIELDS 64      /* per-call pointer tables travel as kernel arguments */
 #define DFM_MAX_RANKS 64       /* data-parallel ranks of one job (csrc/shard.hip) */
 #define DFM_ROWPLAN_CHUNK 4096 /* ids per sorted list (one LDS-resident sort) */
@@ -179,10 +179,23 @@ int dfm_embedding_backward_dense_fields(const dfm_embedding_plan* plan, const vo
  * Entries of a list behind its num_uniq (+ 1 for d_seg_start) are working space of the library: the tail of
  * d_seg_start carries the list's runs of more than half a chunk and an arrival counter for
  * dfm_rowgrad_build, which sums such a run with several workgroups.
- * Depends on the ids only, so it can run ahead of the forward pass. */
+ * Depends on the ids only, so it can run ahead of the forward pass.
+ * touch_tables (optional; dfm_table per SPARSE field, only w2 / stride2 are read; dim = row length for stride2 = 0):
+ * extra workgroups of the same launch read the ids and TOUCH the first line of every row the batch will gather
+ * (embedding.py:95-98 reads them next), pulling the ids and the 128-B row lines into the Infinity Cache while the
+ * sort occupies 26 of the 256 CUs — launched in FRONT of dfm_embedding_forward_staged on the same batch record
+ * (training/step.py), the gather then finds its operands on-die.  Results do not depend on it.
+ * _update: the launch was captured into a graph; point its node (dfm_graph_last_node) of the instantiated graph
+ * at other id columns — host-side only, rules of dfm_embedding_forward_staged_update. */
+typedef struct dfm_table dfm_table;
 int dfm_rowplan_build(const int64_t* const* ids, const int32_t* vocab, int num_sparse, int64_t n,
                       int32_t* d_sorted_pos, int32_t* d_uniq_rows, int32_t* d_seg_start,
-                      int32_t* d_num_uniq, int32_t* d_error_flag, dfm_stream_t stream);
+                      int32_t* d_num_uniq, int32_t* d_error_flag, const dfm_table* touch_tables, int dim,
+                      dfm_stream_t stream);
+int dfm_rowplan_build_update(void* graph_exec, void* node, const int64_t* const* ids, const int32_t* vocab,
+                             int num_sparse, int64_t n, int32_t* d_sorted_pos, int32_t* d_uniq_rows,
+                             int32_t* d_seg_start, int32_t* d_num_uniq, int32_t* d_error_flag,
+                             const dfm_table* touch_tables, int dim);
 
 /* Row gradients of the distinct ids, contributions added in increasing sample order (runs of more than 64
  * contributions: by a fixed tree — reproducible run to run, equal to the sequential sum up to rounding):

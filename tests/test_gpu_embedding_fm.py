@@ -170,7 +170,7 @@ def test_row_gradients_with_hot_ids_vs_oracle():
     idp = (C.c_void_p * S)(*[t_ids[s].data_ptr() for s in range(S)])
     vocab = (C.c_int32 * S)(*([V] * S))
     _lib.check(lib.dfm_rowplan_build(idp, vocab, S, B, sorted_pos.data_ptr(), uniq.data_ptr(), seg.data_ptr(),
-                                     num.data_ptr(), err.data_ptr(), _lib.stream_handle()))
+                                     num.data_ptr(), err.data_ptr(), None, 0, _lib.stream_handle()))
     outs = []
     for _ in range(2):
         g2 = torch.zeros(chunks, S, CH, D, device="cuda")

@@ -421,7 +421,7 @@ def test_rowplan_key_widths_vs_oracle(vocab, hot):
     ptrs = (C.c_void_p * S)(*[t.data_ptr() for t in d_ids])
     voc = (C.c_int32 * S)(vocab, min(vocab, 50))
     _lib.check(lib.dfm_rowplan_build(ptrs, voc, S, B, sorted_pos.data_ptr(), uniq.data_ptr(), seg.data_ptr(),
-                                     num.data_ptr(), err.data_ptr(), _lib.stream_handle()))
+                                     num.data_ptr(), err.data_ptr(), None, 0, _lib.stream_handle()))
     g_fe = rng.standard_normal((B, F, D)).astype(np.float32)
     g_fo = rng.standard_normal((B, 1)).astype(np.float32)
     row_g2 = torch.zeros(chunks, S, ch, D, device="cuda")

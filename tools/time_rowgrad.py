@@ -40,7 +40,7 @@ def main():
 
         def plan():
             _lib.check(lib.dfm_rowplan_build(idp, vocab, S, B, sorted_pos.data_ptr(), uniq.data_ptr(), seg.data_ptr(),
-                                             num.data_ptr(), err.data_ptr(), _lib.stream_handle()))
+                                             num.data_ptr(), err.data_ptr(), None, 0, _lib.stream_handle()))
 
         def grad():
             _lib.check(lib.dfm_rowgrad_build(fmap, S, F, D, B, g_fo.data_ptr(), g_fe.data_ptr(), sorted_pos.data_ptr(),
