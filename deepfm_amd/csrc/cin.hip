@@ -26,6 +26,8 @@ struct CinMfmaLayer {
   const bf16_t* w_lo;
   const float* bias;
   float* Y;
+  uint32_t* mask;
+  int y_from;
   int C, H, HP, MB, direct, next_off, next_count, out_col;
 };
 struct CinMfmaArgs {
@@ -41,6 +43,7 @@ struct CinBwdLayer {
   const bf16_t* wt_hi;
   const bf16_t* wt_lo;
   const float* Y;
+  const uint32_t* mask;
   const float* hidden;
   int64_t hidden_stride;
   float* dY;
@@ -90,6 +93,8 @@ struct Layout {
   int L = 0, F = 0, D = 0, out_dim = 0;
   std::vector<int> C, H, direct, next_off, out_col;
   std::vector<int64_t> y_off;  // float offset of Y_i inside the saved buffer (per batch of B)
+  std::vector<int64_t> mask_off;  // float offset of layer i's ReLU masks (B*D columns x 4 words), behind every Y
+  int64_t y_floats = 0;        // the Y_i alone (= the dY workspace of the matrix-core backward)
   int64_t saved_floats = 0;
   int max_C = 0, max_H = 0;
   int64_t max_CK = 0;
@@ -124,6 +129,15 @@ int make_layout(const int32_t* sizes, int L, int split_half, int F, int D, int64
     prev = next;
   }
   lo->out_dim = col;
+  lo->y_floats = off;
+  // ReLU masks of the matrix-core path (round 3): 128 bits per (b, d) column and layer.  When the backward will run
+  // on the matrix cores too, cin_fwd_mfma stores these and only the "next" half of every Y (the hidden input of the
+  // following layer); cin_dgrad_mfma reads a 16-byte mask per column where it read 64 scalars of Y.
+  off = (off + 3) / 4 * 4;                       // 16-byte aligned
+  for (int i = 0; i < L; ++i) {
+    lo->mask_off.push_back(off);
+    off += B * D * 4;
+  }
   lo->saved_floats = off;
   return DFM_OK;
 }
@@ -190,7 +204,7 @@ extern "C" size_t dfm_cin_backward_workspace_bytes(const int32_t* layer_sizes, i
   // products of all layers are added by one launch at the end)
   size_t wg = 0;
   for (int i = 0; i < lo.L; ++i) wg += wgrad_region_bytes(batch, lo.C[i], lo.H[i], num_fields);
-  size_t mfma = sizeof(float) * static_cast<size_t>(lo.saved_floats) + 2 * sizeof(bf16_t) * packed_wt_total(lo) + wg + 1024;
+  size_t mfma = sizeof(float) * static_cast<size_t>(lo.y_floats) + 2 * sizeof(bf16_t) * packed_wt_total(lo) + wg + 1024;
   return simple > mfma ? simple : mfma;
 }
 
@@ -220,6 +234,11 @@ extern "C" int dfm_cin_forward(const float* d_x0, int64_t batch, int num_fields,
       CinMfmaLayer& ly = args.layer[i];
       ly.w_hi = hi + off; ly.w_lo = lop + off; ly.bias = biases[i];
       ly.Y = d_saved ? d_saved + lo.y_off[i] : nullptr;
+      // masks + the next half only, when the backward of this (mode, batch, shape) takes the matrix-core kernels
+      // (dfm_cin_set_mode must not change between a forward and its backward)
+      const bool masks = d_saved && mfma_bwd_ok(lo, batch);
+      ly.mask = masks ? reinterpret_cast<uint32_t*>(d_saved + lo.mask_off[i]) : nullptr;
+      ly.y_from = masks ? (i < lo.L - 1 ? lo.next_off[i] : lo.C[i]) : 0;
       ly.C = lo.C[i]; ly.H = lo.H[i]; ly.HP = (lo.H[i] + 1) / 2; ly.MB = (lo.C[i] + 31) / 32;
       ly.direct = lo.direct[i]; ly.next_off = lo.next_off[i];
       ly.next_count = i < lo.L - 1 ? lo.H[i + 1] : 0;
@@ -264,7 +283,7 @@ extern "C" int dfm_cin_backward(const float* d_x0, int64_t batch, int num_fields
   if (mfma_bwd_ok(lo, batch)) {
     const bool split = cin_mode() == 0;
     float* dY_all = static_cast<float*>(d_workspace);
-    bf16_t* hi = reinterpret_cast<bf16_t*>(dY_all + lo.saved_floats);
+    bf16_t* hi = reinterpret_cast<bf16_t*>(dY_all + lo.y_floats);
     bf16_t* lop = hi + packed_wt_total(lo);
     unsigned char* wg_ws = reinterpret_cast<unsigned char*>(lop + packed_wt_total(lo));
     wg_ws += (256 - (reinterpret_cast<uintptr_t>(wg_ws) & 255)) & 255;
@@ -279,6 +298,7 @@ extern "C" int dfm_cin_backward(const float* d_x0, int64_t batch, int num_fields
       CinBwdLayer& ly = args.layer[i];
       ly.wt_hi = hi + off; ly.wt_lo = lop + off;
       ly.Y = d_saved + lo.y_off[i];
+      ly.mask = reinterpret_cast<const uint32_t*>(d_saved + lo.mask_off[i]);
       ly.hidden = i == 0 ? d_x0 : d_saved + lo.y_off[i - 1] + static_cast<int64_t>(lo.next_off[i - 1]) * dim;
       ly.hidden_stride = i == 0 ? static_cast<int64_t>(num_fields) * dim : static_cast<int64_t>(lo.C[i - 1]) * dim;
       ly.dY = dY_all + lo.y_off[i];

@@ -34,6 +34,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef CIN_FWD_VARIANT
 #define CIN_FWD_VARIANT 0
 #endif
+#ifndef CIN_FWD_ABLATE
+#define CIN_FWD_ABLATE 0      // timing-only ablations (tools/build_variant.sh); 0 in the product
+#endif
 #ifndef CIN_FWD_VALU_PER_MFMA
 #define CIN_FWD_VALU_PER_MFMA 4
 #endif
@@ -54,6 +57,8 @@ struct CinMfmaLayer {
   const __bf16* w_lo;
   const float* bias;    // (C)
   float* Y;             // (B, C, D) post-ReLU activations for the backward, or null
+  uint32_t* mask;       // (B*D, 4) ReLU masks, bit c of a column's 128 = (Y[c] > 0), or null; with it only the rows
+  int y_from;           // >= y_from of Y are stored (the "next" half: the hidden input of the following layer)
   int C, H, HP, MB, direct, next_off, next_count, out_col;
 };
 struct CinMfmaArgs {
@@ -231,17 +236,18 @@ __global__ __launch_bounds__(kCinWaves * 64, 1) void cin_fwd_mfma(CinMfmaArgs ar
         for (int fg = 0; fg < FG; ++fg) {
           bf16x8 ah[4], al[4];
           if constexpr (FULL) {
+            const int fga = (CIN_FWD_ABLATE & 2) ? 0 : fg;        // timing-only ablation: one fragment set per slab
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) {
-              ah[mb] = reinterpret_cast<const bf16x8*>(base)[(fg * 4 + mb) * 64 + lane];
-              if (SPLIT) al[mb] = reinterpret_cast<const bf16x8*>(base + SLAB)[(fg * 4 + mb) * 64 + lane];
+              ah[mb] = reinterpret_cast<const bf16x8*>(base)[(fga * 4 + mb) * 64 + lane];
+              if (SPLIT) al[mb] = reinterpret_cast<const bf16x8*>(base + SLAB)[(fga * 4 + mb) * 64 + lane];
             }
           }
           // B operand: Z values of this k-step for the lane's column
           bf16x8 bh, bl;
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
-            const float z = hv * x0r[fg * 8 + j];
+            const float z = hv * x0r[((CIN_FWD_ABLATE & 1) ? 0 : fg) * 8 + j];   // timing-only ablation: one B per slab
             bh[j] = static_cast<__bf16>(z);
             if (SPLIT) bl[j] = static_cast<__bf16>(z - static_cast<float>(bh[j]));
           }
@@ -374,13 +380,16 @@ __global__ __launch_bounds__(kCinWaves * 64, 1) void cin_fwd_mfma(CinMfmaArgs ar
       float* hbase = hid + (4 * hf - ly.next_off) * kCinCols + n;
       const int c_lim = ly.C - 4 * hf, d_lim = ly.direct - 4 * hf;
       const int n_lo = ly.next_off - 4 * hf, n_hi = n_lo + (last ? 0 : ly.next_count);
+      const int y_lo = ly.y_from - 4 * hf;        // rows below are not stored (their masks are)
+      uint32_t mw[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
       for (int mb = 0; mb < 4; ++mb) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int rr = mb * 32 + (r & 3) + 8 * (r >> 2);   // compile-time; row = rr + 4*hf
           const float y = fmaxf(acc[mb][r], 0.f);
-          if (ybase && live && rr < c_lim) ybase[rr * D] = y;
+          if (y > 0.f) mw[mb] |= 1u << ((r & 3) + 8 * (r >> 2));
+          if (!(CIN_FWD_ABLATE & 4) && ybase && live && rr < c_lim && rr >= y_lo) ybase[rr * D] = y;
           if (rr >= n_lo && rr < n_hi) hbase[rr * kCinCols] = y;
           // sum-pool over the D columns of each sample (D consecutive lanes; xor partners share
           // the lane half, hence the row, so the branch is taken pairwise)
@@ -390,6 +399,17 @@ __global__ __launch_bounds__(kCinWaves * 64, 1) void cin_fwd_mfma(CinMfmaArgs ar
             if (live && d == 0) obase[rr] = sum;
           }
         }
+      }
+      if (ly.mask) {
+        // the two lane halves hold the rows with bit 2 clear / set: OR them, one 16-byte store per column
+        uint4 m;
+        uint32_t* mp = reinterpret_cast<uint32_t*>(&m);
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+          const uint32_t mine = mw[mb] << (4 * hf);
+          mp[mb] = mine | static_cast<uint32_t>(__shfl_xor(static_cast<int>(mine), 32, kWave));
+        }
+        if (live && hf == 0) reinterpret_cast<uint4*>(ly.mask)[col] = m;
       }
     }
     (void)SPT;

@@ -30,14 +30,21 @@ namespace dfm {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+#ifndef CIN_BWD_ABLATE
+#define CIN_BWD_ABLATE 0      // timing-only ablations (tools/build_variant.sh); 0 in the product
+#endif
 constexpr int kBwdMaxLayers = 8;
-constexpr int kBwdWaves = 4;
+#ifndef CIN_BWD_WAVES
+#define CIN_BWD_WAVES 4
+#endif
+constexpr int kBwdWaves = CIN_BWD_WAVES;
 constexpr int kBwdCols = 32;
 
 struct CinBwdLayer {
   const __bf16* wt_hi;     // packed (HQ*FG, KS, 64, 8): W^T fragments
   const __bf16* wt_lo;
-  const float* Y;          // (B, C, D) post-ReLU activations of this layer
+  const float* Y;          // (B, C, D) post-ReLU activations of this layer (read only when `mask` is null)
+  const uint32_t* mask;    // (B*D, 4) ReLU masks written by cin_fwd_mfma: bit c of a column's 128 = (Y[c] > 0)
   const float* hidden;     // hidden input of this layer: x0 (layer 0) or Y_{i-1} + next_off*D
   int64_t hidden_stride;   // floats between samples of `hidden`
   float* dY;               // (B, C, D) fp32 out, for the weight gradient
@@ -94,8 +101,17 @@ __global__ __launch_bounds__(256) void cin_pack_wt_all(CinPackWtJobs jobs) {
                    jobs.KS[i], jobs.hi[i], jobs.lo[i]);
 }
 
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
 template <int D, int FG, bool SPLIT>
 __global__ __launch_bounds__(kBwdWaves * 64, 2) void cin_dgrad_mfma(CinBwdArgs args) {
+  constexpr int kThreads = kBwdWaves * 64;
   constexpr int SLAB = 8 /*KS max*/ * 64 * 16;           // bytes of one hi (or lo) block slab
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   unsigned char* wbuf = lds_raw;                          // [2 buffers][hi, lo][KS*64][16 B]
@@ -132,6 +148,12 @@ __global__ __launch_bounds__(kBwdWaves * 64, 2) void cin_dgrad_mfma(CinBwdArgs a
       const float* hbase = dH + (8 * hf - ly.next_off) * kBwdCols + n;
       const int c_lim = ly.C - 8 * hf, d_lim = ly.direct - 8 * hf;
       const int n_lo = ly.next_off - 8 * hf, n_hi = n_lo + (li < args.L - 1 ? ly.next_count : 0);
+      // ReLU mask of the column: one 16-byte load (64 scalar loads of Y before round 3: ~15 us per layer)
+      uint32_t mh[4] = {0u, 0u, 0u, 0u};
+      if (ly.mask && live) {
+        const uint4 m = reinterpret_cast<const uint4*>(ly.mask)[col];
+        mh[0] = m.x >> (8 * hf); mh[1] = m.y >> (8 * hf); mh[2] = m.z >> (8 * hf); mh[3] = m.w >> (8 * hf);
+      }
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
 #pragma unroll
@@ -141,8 +163,9 @@ __global__ __launch_bounds__(kBwdWaves * 64, 2) void cin_dgrad_mfma(CinBwdArgs a
           if (live && cc < c_lim && ks < KS) {
             if (cc < d_lim) g = gbase[cc];
             if (cc >= n_lo && cc < n_hi) g += hbase[cc * kBwdCols];
-            g = ybase[cc * D] > 0.f ? g : 0.f;
-            dybase[cc * D] = g;
+            if (ly.mask) g = ((mh[ks >> 1] >> (16 * (ks & 1) + j)) & 1u) ? g : 0.f;   // bit c = 16 ks + 8 hf + j
+            else if (!(CIN_BWD_ABLATE & 2)) g = ybase[cc * D] > 0.f ? g : 0.f;
+            if (!(CIN_BWD_ABLATE & 1)) dybase[cc * D] = g;
           }
           dyh[ks][j] = static_cast<__bf16>(g);
           if (SPLIT) dyl[ks][j] = static_cast<__bf16>(g - static_cast<float>(dyh[ks][j]));
@@ -156,7 +179,7 @@ __global__ __launch_bounds__(kBwdWaves * 64, 2) void cin_dgrad_mfma(CinBwdArgs a
     // (named registers, not arrays: the compiler kept `uint4 sh[2]` in scratch memory, which put a
     // scratch round trip and a full wait on the global load into every block)
     uint4 sh0 = {}, sh1 = {}, sl0 = {}, sl1 = {};
-    const int p0 = tid, p1 = 256 + tid;
+    const int p0 = tid, p1 = kThreads + tid;
     const bool has0 = p0 < KS * 64, has1 = p1 < KS * 64;
     auto stage_load = [&](int blk) {
       const int64_t e = static_cast<int64_t>(blk) * KS * 64;
@@ -203,11 +226,29 @@ __global__ __launch_bounds__(kBwdWaves * 64, 2) void cin_dgrad_mfma(CinBwdArgs a
           hv[hl] = (live && h < ly.H) ? ly.hidden[b * ly.hidden_stride + h * D + d] : 0.f;
           dhq[hl] = 0.f;
         }
+        // Two accumulators, alternating (round 3): the 32 FMAs that fold block fg - 1's G tile into d hidden / d x0
+        // issue BEHIND block fg's 24 MFMAs, so the matrix pipe keeps running while the VALU consumes the previous
+        // tile (one accumulator: MFMA chain -> wait -> fold -> barrier, 60 us of the launch by ablation).  Only the
+        // last block of a hidden-row quad folds in the open.
+        f32x16 accs[2];
+        auto fold = [&](const f32x16& acc, auto fg_tag) {
+          constexpr int fg = decltype(fg_tag)::value;
+          if (CIN_BWD_ABLATE & 4) {
+            dhq[0] += acc[0]; dx0[fg * 4] += acc[5];
+          } else {
 #pragma unroll
-        for (int fg = 0; fg < FG; ++fg, ++blk) {
+            for (int r = 0; r < 16; ++r) {
+              dhq[r >> 2] = fmaf(x0q[fg * 4 + (r & 3)], acc[r], dhq[r >> 2]);
+              dx0[fg * 4 + (r & 3)] = fmaf(hv[r >> 2], acc[r], dx0[fg * 4 + (r & 3)]);
+            }
+          }
+        };
+        static_for<0, FG>([&](auto fg_tag) {
+          constexpr int fg = decltype(fg_tag)::value;
           const int cur = blk & 1;
           const unsigned char* base = wbuf + cur * 2 * SLAB;
-          f32x16 acc = {};
+          f32x16& acc = accs[fg & 1];
+          acc = f32x16{};
           if constexpr (FULL) {
             bf16x8 ah[4], al[4];
 #pragma unroll
@@ -215,8 +256,10 @@ __global__ __launch_bounds__(kBwdWaves * 64, 2) void cin_dgrad_mfma(CinBwdArgs a
               ah[q] = reinterpret_cast<const bf16x8*>(base)[q * 64 + lane];
               if (SPLIT) al[q] = reinterpret_cast<const bf16x8*>(base + SLAB)[q * 64 + lane];
             }
-            if (blk + 1 < nblk) stage_store(cur ^ 1);          // block blk+1 (loaded one block ago)
-            if (blk + 2 < nblk) stage_load(blk + 2);
+            if (!(CIN_BWD_ABLATE & 16)) {
+              if (blk + 1 < nblk) stage_store(cur ^ 1);          // block blk+1 (loaded one block ago)
+              if (blk + 2 < nblk) stage_load(blk + 2);
+            }
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
 #pragma unroll
@@ -228,7 +271,7 @@ __global__ __launch_bounds__(kBwdWaves * 64, 2) void cin_dgrad_mfma(CinBwdArgs a
                   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[q], dyh[ks], acc, 0, 0, 0);
                 }
               }
-              if (half == 0) {
+              if (half == 0 && !(CIN_BWD_ABLATE & 8)) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                   ah[q] = reinterpret_cast<const bf16x8*>(base)[(4 + q) * 64 + lane];
@@ -253,13 +296,11 @@ __global__ __launch_bounds__(kBwdWaves * 64, 2) void cin_dgrad_mfma(CinBwdArgs a
             }
           }
           // accumulator register r: hidden row 4*hq + (r>>2), field fg*8 + 4*hf + (r&3)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            dhq[r >> 2] = fmaf(x0q[fg * 4 + (r & 3)], acc[r], dhq[r >> 2]);
-            dx0[fg * 4 + (r & 3)] = fmaf(hv[r >> 2], acc[r], dx0[fg * 4 + (r & 3)]);
-          }
+          if constexpr (fg > 0) fold(accs[(fg - 1) & 1], std::integral_constant<int, fg - 1>{});
+          if constexpr (fg == FG - 1) fold(acc, fg_tag);
           __syncthreads();
-        }
+          ++blk;
+        });
         // the other lane half holds the other 4 fields of every group
 #pragma unroll
         for (int hl = 0; hl < 4; ++hl) {
@@ -333,13 +374,6 @@ constexpr int kWgBound = WG_LB;
 #endif
 constexpr int kWgDepth = WG_DEPTH;      // samples of global-load look-ahead (build-time tunables: tools/microbench_cin_wgrad)
 
-template <int I, int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (I < N) {
-    f(std::integral_constant<int, I>{});
-    static_for<I + 1, N>(f);
-  }
-}
 
 // D = embedding dim (8, 16 or 32): one pipeline step is one MFMA k-step = 16 consecutive (b, d) columns —
 // a sample (D = 16), half a sample (D = 32) or two samples (D = 8, lane half hf takes sample 2s + hf).
@@ -348,6 +382,16 @@ __global__ __launch_bounds__(256, kWgBound) void cin_wgrad_mfma(CinWgradArgs a) 
   static_assert(D == 8 || D == 16 || D == 32, "k-steps of 16 columns need D in {8, 16, 32}");
   constexpr int SLAB = 4 * 64 * 16;                       // one sample: 4 row blocks x 64 lanes x 16 B (hi or lo)
   __shared__ __attribute__((aligned(16))) unsigned char wbuf[2 * 2 * SLAB];   // [buf][hi, lo]
+  // B operand through LDS (round 3, D == 16): one k-step is one sample, and a workgroup's 128 k' columns need only
+  // the sample's x0 rows (F x 64 B, contiguous) and 128 / FP + 1 hidden rows — 2.9 KB at F = 39, loaded ONCE per workgroup, coalesced,
+  // one 16-byte load per thread, instead of 64 scattered bytes per lane (16 KB per workgroup and sample through
+  // the texture path: 77 us of the three launches by ablation).  Rows are 80 bytes apart: 16 consecutive rows
+  // read with ds_read_b128 touch every bank once.  Row kOnes holds ones (the bias column's operand).
+  constexpr bool LB = (D == 16) && !(CIN_BWD_ABLATE & 128);
+  // (hidden rows per workgroup: 128 / FP + 1 <= 17 for FP >= 8; 5 at the Criteo shape's FP = 40)
+  constexpr int kBRow = 20, kXRows = 40, kHRows = 17, kOnes = kXRows + kHRows, kBRows = kOnes + 1;
+  static_assert(4 * kOnes <= 256, "one staging thread per 16 bytes of the B image");
+  __shared__ __attribute__((aligned(16))) float bbuf[LB ? 2 * kBRows * kBRow : 4];
   const int lane = lane_id(), wave = wave_id_uniform(), tid = threadIdx.x;
   const int kt = blockIdx.x * 4 + wave;
   const int kcol = kt * 32 + (lane & 31), hf = lane >> 5;
@@ -379,6 +423,28 @@ __global__ __launch_bounds__(256, kWgBound) void cin_wgrad_mfma(CinWgradArgs a) 
   const float* xp0 = kbias ? kWgOnes : a.x0 + (b0 * a.F + (kvalid ? f : 0)) * D;
   const uint32_t hs = kbias ? 0u : static_cast<uint32_t>(a.hidden_stride), xs = kbias ? 0u : static_cast<uint32_t>(a.F * D);
   const uint32_t lane_h = D >= 16 ? 8u * hf : hf * hs, lane_x = D >= 16 ? 8u * hf : hf * xs;   // per-lane constants
+  // LDS-staged B: this thread's row / quarter of the staged image, and this lane's two rows of it
+  const int h_lo = (blockIdx.x * 4 * 32) / a.FP;
+  const int sb_row = tid >> 2, sb_q = tid & 3;
+  const bool sb_on = LB && sb_row < kOnes;
+  const bool sb_x = sb_row < kXRows;
+  const float* pb = sb_x ? a.x0 + (b0 * a.F + min(sb_row, a.F - 1)) * D + 4 * sb_q
+                         : a.hidden + b0 * a.hidden_stride + min(h_lo + sb_row - kXRows, a.H - 1) * D + 4 * sb_q;
+  const int64_t sb_stride = sb_x ? static_cast<int64_t>(a.F) * D : a.hidden_stride;
+  const int lb_x = (kvalid ? f : (kbias ? kOnes : 0)) * kBRow + 8 * hf;
+  const int lb_h = (kvalid ? kXRows + (h - h_lo) : (kbias ? kOnes : kXRows)) * kBRow + 8 * hf;
+  if (LB) {
+    for (int i = tid; i < 2 * kBRows * kBRow; i += 256) bbuf[i] = 1.f;     // the ones rows; the rest is overwritten
+  }
+  float4 rb[kWgDepth];
+  auto load_bs = [&](int s, auto slot_tag) {      // staged B of sample s -> register slot
+    constexpr int SL = decltype(slot_tag)::value;
+    if (sb_on) rb[SL] = ld4g(pb + s * sb_stride);
+  };
+  auto store_bs = [&](float* base, auto slot_tag) {
+    constexpr int SL = decltype(slot_tag)::value;
+    if (sb_on) *reinterpret_cast<float4*>(base + sb_row * kBRow + 4 * sb_q) = rb[SL];
+  };
   // Global loads run kWgDepth samples ahead of their use, in a ring of register slots (compile-time slot
   // numbers: the loop is unrolled by the ring size).  Measured with tools/microbench_cin_wgrad (H = 64
   // layer, kernel + slab reduce): depth 1 168 us, depth 2 174, depth 4 209, depth 6 198 (one wave per
@@ -441,19 +507,33 @@ __global__ __launch_bounds__(256, kWgBound) void cin_wgrad_mfma(CinWgradArgs a) 
 #pragma unroll
       for (int mb = 0; mb < 4; ++mb) ah[mb] = reinterpret_cast<const bf16x8*>(cur)[mb * 64 + lane];
     }
-    store_a(nxt, std::integral_constant<int, SN>{});     // sample s + 1 (the last step stores a copy nobody reads)
-    load_a(min(s + 1 + kWgDepth, n - 1), std::integral_constant<int, SN>{});
+    float4 h0, h1, x0v, x1v;
+    if constexpr (LB) {
+      const float* bc = bbuf + (U & 1) * kBRows * kBRow;
+      h0 = *reinterpret_cast<const float4*>(bc + lb_h); h1 = *reinterpret_cast<const float4*>(bc + lb_h + 4);
+      x0v = *reinterpret_cast<const float4*>(bc + lb_x); x1v = *reinterpret_cast<const float4*>(bc + lb_x + 4);
+    }
+    if (!(CIN_BWD_ABLATE & 64)) {
+      store_a(nxt, std::integral_constant<int, SN>{});     // sample s + 1 (the last step stores a copy nobody reads)
+      if constexpr (LB) store_bs(bbuf + ((U & 1) ^ 1) * kBRows * kBRow, std::integral_constant<int, SN>{});
+      load_a(min(s + 1 + kWgDepth, n - 1), std::integral_constant<int, SN>{});
+      if constexpr (LB) load_bs(min(s + 1 + kWgDepth, n - 1), std::integral_constant<int, SN>{});
+    }
 #ifdef DFM_CIN_STAMPS
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
     WG_STAMP(st_a)
     bf16x8 bh, bl;
-    {
+    if constexpr (LB) {
+      const float4 z0 = {h0.x * x0v.x, h0.y * x0v.y, h0.z * x0v.z, h0.w * x0v.w};
+      const float4 z1 = {h1.x * x1v.x, h1.y * x1v.y, h1.z * x1v.z, h1.w * x1v.w};
+      split8(z0, z1, bh, bl);
+    } else {
       const float4 z0 = {hb0[SL].x * xb0[SL].x, hb0[SL].y * xb0[SL].y, hb0[SL].z * xb0[SL].z, hb0[SL].w * xb0[SL].w};
       const float4 z1 = {hb1[SL].x * xb1[SL].x, hb1[SL].y * xb1[SL].y, hb1[SL].z * xb1[SL].z, hb1[SL].w * xb1[SL].w};
       split8(z0, z1, bh, bl);
+      if (!(CIN_BWD_ABLATE & 32)) load_b(min(s + kWgDepth, n - 1), slot_tag);
     }
-    load_b(min(s + kWgDepth, n - 1), slot_tag);
     WG_STAMP(st_b)
     if constexpr (FULL) {
       // hi fragments first, the lo fragments only once the hi ones are dead (16 live registers of A)
@@ -490,7 +570,15 @@ __global__ __launch_bounds__(256, kWgBound) void cin_wgrad_mfma(CinWgradArgs a) 
     constexpr int kUnroll = kWgDepth % 2 ? 2 * kWgDepth : kWgDepth;   // slots and the two LDS buffers both cycle
     using S0 = std::integral_constant<int, 0>;
     load_a(0, S0{});
-    static_for<0, kWgDepth>([&](auto i) { load_b(min(static_cast<int>(i), n - 1), i); });
+    if constexpr (LB) {
+      static_assert(kWgDepth == 1, "the LDS-staged B operand is written for one step of look-ahead");
+      load_bs(0, S0{});
+      __syncthreads();                         // the ones fill above is complete before rows are written over it
+      store_bs(bbuf, S0{});
+      load_bs(min(1, n - 1), S0{});
+    } else {
+      static_for<0, kWgDepth>([&](auto i) { load_b(min(static_cast<int>(i), n - 1), i); });
+    }
     store_a(wbuf, S0{});
     static_for<1, kWgDepth>([&](auto i) { load_a(min(static_cast<int>(i), n - 1), i); });
     load_a(min(kWgDepth, n - 1), S0{});
