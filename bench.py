@@ -79,6 +79,8 @@ def parse():
     ap.add_argument("--rowplan-inline", action="store_true",
                     help="A/B: row plan behind the gather from the staged ids (round 2's order) instead of in front of it on "
                          "the batch record with row-touch workgroups")
+    ap.add_argument("--no-plan-lookahead", action="store_true",
+                    help="A/B: every step of a multi-step graph builds its own row plan (no dfm_step_apply_plan)")
     ap.add_argument("--gather-samples", type=int, default=32,
                     help="timed gather dispatches wanted for the roofline: those of the timed region plus single steps "
                          "run after it (outside `value`) until this many are collected")
@@ -372,6 +374,7 @@ def main():
     from deepfm_amd.training.step import RowSparseTrainStep
     lib = _lib.load()
     RowSparseTrainStep.rowplan_first_default = not args.rowplan_inline
+    RowSparseTrainStep.plan_lookahead_default = not args.no_plan_lookahead
     _lib.check(lib.dfm_gather_set_shape(args.gather_shape))        # before any capture: the graphs keep the kernel
     B, V, D = args.batch, args.vocab, args.dim
     n_sparse, n_dense = 26, 13
@@ -532,8 +535,10 @@ def main():
                 "hip_graph": bool(step.use_graph and not args.no_graph),
                 "steps_per_graph": G,
                 "capture_fallback": capture_fallback,
-                "rowplan": "in front of the gather, on the batch record, + row touch" if getattr(step, "rowplan_first", False)
-                           else "behind the gather, from the staged ids",
+                "rowplan": ("inside the previous step's apply launch for steps 2.. of a graph; first step: "
+                            if getattr(step, "_plan_sets", None) else "") +
+                           ("in front of the gather, on the batch record, + row touch" if getattr(step, "rowplan_first", False)
+                            else "behind the gather, from the staged ids"),
                 **({"dp_layout": "field-sharded tables (a deviation from north_star's replicated tables + all-reduce: "
                                  "DESIGN.md section 6 — replicated tables top out near 3.5x at 8 GPUs)"}
                    if dist.is_initialized() and step.exchange_in_body else {}),

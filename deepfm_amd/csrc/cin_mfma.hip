@@ -31,23 +31,9 @@ namespace dfm {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-#ifndef CIN_FWD_VARIANT
-#define CIN_FWD_VARIANT 0
-#endif
 #ifndef CIN_FWD_ABLATE
 #define CIN_FWD_ABLATE 0      // timing-only ablations (tools/build_variant.sh); 0 in the product
 #endif
-#ifndef CIN_FWD_VALU_PER_MFMA
-#define CIN_FWD_VALU_PER_MFMA 4
-#endif
-template <int I, int N, class F>
-__device__ __forceinline__ void static_for_cin(F&& f) {
-  if constexpr (I < N) {
-    f(std::integral_constant<int, I>{});
-    static_for_cin<I + 1, N>(f);
-  }
-}
-
 constexpr int kCinMaxLayers = 8;
 constexpr int kCinWaves = 8;          // waves per workgroup = per CU (share the weight slabs)
 constexpr int kCinCols = 32;          // columns per wave
@@ -288,79 +274,11 @@ __global__ __launch_bounds__(kCinWaves * 64, 1) void cin_fwd_mfma(CinMfmaArgs ar
 #endif
       }
     };
-#if CIN_FWD_VARIANT >= 1
-    // Software-pipelined form of the FULL loop (CIN_FWD_VARIANT build switch, tools/build_variant.sh): the B operand
-    // of k-step t+1 is generated (VALU) while the 12 MFMAs of k-step t issue — in program order the B
-    // generation stands BEFORE the MFMAs it overlaps, and sched_group_barrier pins the interleave
-    // (1 MFMA : CIN_FWD_VALU_PER_MFMA VALU), so that the matrix pipe sees back-to-back MFMAs from ONE wave
-    // instead of relying on the partner wave to fill the gaps.
-    auto gen_b = [&](float hvv, auto fg_tag, bf16x8& bh, bf16x8& bl) {
-      constexpr int fg = decltype(fg_tag)::value;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float z = hvv * x0r[fg * 8 + j];
-        bh[j] = static_cast<__bf16>(z);
-        if (SPLIT) bl[j] = static_cast<__bf16>(z - static_cast<float>(bh[j]));
-      }
-    };
-    auto kloop_pipe = [&]() {
-      bf16x8 bh_c, bl_c;
-      float hv = hid[hf * kCinCols + n];
-      gen_b(hv, std::integral_constant<int, 0>{}, bh_c, bl_c);
-      for (int hp = 0; hp < ly.HP; ++hp) {
-        const int cur = hp & 1;
-        const unsigned char* base = wbuf + cur * 2 * SLAB;
-        const int hp_n = hp + 1 < ly.HP ? hp + 1 : hp;           // clamped: the last prefetch is never used
-        const float hv_n = hid[(2 * hp_n + hf) * kCinCols + n];
-        if (hp + 1 < ly.HP) stage_store(cur ^ 1);
-        if (hp + 2 < ly.HP) stage_load(hp + 2);
-        static_for_cin<0, FG>([&](auto fg_tag) {
-          constexpr int fg = decltype(fg_tag)::value;
-          bf16x8 ah[4], al[4];
-#pragma unroll
-          for (int mb = 0; mb < 4; ++mb) {
-            ah[mb] = reinterpret_cast<const bf16x8*>(base)[(fg * 4 + mb) * 64 + lane];
-            if (SPLIT) al[mb] = reinterpret_cast<const bf16x8*>(base + SLAB)[(fg * 4 + mb) * 64 + lane];
-          }
-          bf16x8 bh_n, bl_n;
-          if constexpr (fg + 1 < FG) gen_b(hv, std::integral_constant<int, fg + 1>{}, bh_n, bl_n);
-          else gen_b(hv_n, std::integral_constant<int, 0>{}, bh_n, bl_n);
-#pragma unroll
-          for (int mb = 0; mb < 4; ++mb)
-            acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mb], bh_c, acc[mb], 0, 0, 0);
-          if (SPLIT) {
-#pragma unroll
-            for (int mb = 0; mb < 4; ++mb)
-              acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mb], bl_c, acc[mb], 0, 0, 0);
-#pragma unroll
-            for (int mb = 0; mb < 4; ++mb)
-              acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mb], bh_c, acc[mb], 0, 0, 0);
-          }
-#if CIN_FWD_VARIANT >= 2
-          // interleave: DS reads first (8), then per MFMA a few VALU of the next step's B generation
-          __builtin_amdgcn_sched_group_barrier(0x100, SPLIT ? 8 : 4, 0);
-#pragma unroll
-          for (int i = 0; i < (SPLIT ? 12 : 4); ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, CIN_FWD_VALU_PER_MFMA, 0);
-          }
-#endif
-          bh_c = bh_n; bl_c = bl_n;
-        });
-        hv = hv_n;
-        __syncthreads();
-      }
-    };
-#endif
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
 #ifdef DFM_CIN_STAMPS
     { const unsigned long long t = wall_clock64(); st_pre += t - st_mark; }
 #endif
-#if CIN_FWD_VARIANT >= 1
-    if (MB == 4) kloop_pipe();
-#else
     if (MB == 4) kloop(std::true_type{});
-#endif
     else kloop(std::false_type{});
 #ifdef DFM_CIN_STAMPS
     st_mark = wall_clock64();

@@ -14,6 +14,7 @@
 //
 // The bodies are the ones of the stand-alone kernels (tail_bodies.h): identical arithmetic and
 // reduction order, so grouped and stand-alone launches give bit-identical results.
+#include "rowplan_body.h"
 #include "tail_bodies.h"
 
 using namespace dfm;
@@ -123,6 +124,45 @@ __global__ __launch_bounds__(kTailThreads) void step_apply_kernel(
                        step_ptr);
   else
     dense_adam_body(blk - row_blocks, p, m, v, g, n, clip_coef, lr, b1, b2, eps, step_ptr, zero_grad ? g : nullptr);
+}
+
+// step_apply of step t + the ROW PLAN of step t + 1 (+ its row touch) in one launch (round 3).  The plan needs only
+// the next batch's ids, and on its own it keeps 26 CUs busy for ~13 us in the step's dependent chain; here its
+// workgroups are the FIRST blocks of the optimizer's last launch — they start at once and sort beside the
+// row-wise Adam, which is bound by HBM latency, not by CUs.  1024-thread workgroups with the plan's dynamic LDS:
+// an apply workgroup runs four of step_apply_kernel's 256-thread blocks (their bodies index by the flat thread
+// number only).  The next step then starts at its gather.  Ids: (S, n) int64, column s at ids_base + s * ids_stride
+// (a batch record); vocab on the device; plan outputs = the OTHER set of plan buffers.
+template <typename KeyT, int SHIFT>
+__global__ __launch_bounds__(rowplan::SORT_THREADS) void step_apply_plan_kernel(
+    int plan_blocks, const int64_t* __restrict__ ids_base, int64_t ids_stride, const int32_t* __restrict__ vocab,
+    int64_t plan_n, int chunks, int32_t* __restrict__ p_sorted_pos, int32_t* __restrict__ p_uniq_rows,
+    int32_t* __restrict__ p_seg_start, int32_t* __restrict__ p_num_uniq, int32_t* p_error,
+    int row_blocks4, TableArgs tabs, int S, int D, int L, const int32_t* __restrict__ uniq_rows,
+    const int32_t* __restrict__ num_uniq, const float* __restrict__ row_g2, const float* __restrict__ row_g1,
+    const int32_t* __restrict__ owner_flag, const float* __restrict__ clip_coef, float lr, float b1, float b2,
+    float eps, const int32_t* __restrict__ step_ptr, float* __restrict__ p, float* __restrict__ m,
+    float* __restrict__ v, float* __restrict__ g, int64_t n, int zero_grad) {
+  if (static_cast<int>(blockIdx.x) < plan_blocks) {
+    const int s = blockIdx.x % S, y = blockIdx.x / S;
+    const int64_t* src = ids_base + s * ids_stride;
+    if (y < chunks) {
+      rowplan::rowplan_chunk_body<KeyT, SHIFT>(src, vocab[s], s, y, S, plan_n, p_sorted_pos, p_uniq_rows, p_seg_start,
+                                               p_num_uniq, p_error, 0);
+    } else {
+      const int q = y - chunks;
+      const dfm_table tb = tabs.t[s];
+      rowplan::rowplan_touch_body(src, vocab[s], tb.w2, tb.stride2, q / rowplan::kTouchParts, q % rowplan::kTouchParts,
+                                  plan_n);
+    }
+    return;
+  }
+  const int blk = (static_cast<int>(blockIdx.x) - plan_blocks) * (rowplan::SORT_THREADS / kTailThreads);
+  if (blk < row_blocks4)
+    rowadam_apply_body(blk, tabs, S, D, L, uniq_rows, num_uniq, row_g2, row_g1, owner_flag, clip_coef, lr, b1, b2, eps,
+                       step_ptr);
+  else
+    dense_adam_body(blk - row_blocks4, p, m, v, g, n, clip_coef, lr, b1, b2, eps, step_ptr, zero_grad ? g : nullptr);
 }
 
 namespace {
@@ -280,5 +320,124 @@ extern "C" int dfm_step_apply(const dfm_table* tables, int num_sparse, int dim, 
                      static_cast<int>(rb), ta, num_sparse, dim, num_lists, d_uniq_rows, d_num_uniq, d_row_g2, d_row_g1,
                      d_owner_flag, d_clip_coef, lr, beta1, beta2, eps, d_step, d_p, d_m, d_v, d_g, n, zero_grad);
   DFM_LAUNCH_CHECK();
+  return DFM_OK;
+}
+
+// ---- dfm_step_apply + the next step's row plan in one launch -----------------------------------------
+namespace {
+struct ApplyPlanLaunch {
+  const void* func = nullptr;
+  dim3 grid, block;
+  unsigned lds = 0;
+  int plan_blocks = 0, chunks = 0, row_blocks4 = 0, S = 0, D = 0, L = 0, zero_grad = 0;
+  const int64_t* ids_base = nullptr;
+  int64_t ids_stride = 0, plan_n = 0, n = 0;
+  const int32_t* vocab = nullptr;
+  int32_t *p_sorted_pos = nullptr, *p_uniq_rows = nullptr, *p_seg_start = nullptr, *p_num_uniq = nullptr, *p_error = nullptr;
+  TableArgs tabs;
+  const int32_t *uniq_rows = nullptr, *num_uniq = nullptr, *owner_flag = nullptr, *step_ptr = nullptr;
+  const float *row_g2 = nullptr, *row_g1 = nullptr, *clip_coef = nullptr;
+  float lr = 0, b1 = 0, b2 = 0, eps = 0;
+  float *p = nullptr, *m = nullptr, *v = nullptr, *g = nullptr;
+  void* params[36];
+  void bind() {
+    int k = 0;
+    params[k++] = &plan_blocks; params[k++] = &ids_base; params[k++] = &ids_stride; params[k++] = &vocab;
+    params[k++] = &plan_n; params[k++] = &chunks; params[k++] = &p_sorted_pos; params[k++] = &p_uniq_rows;
+    params[k++] = &p_seg_start; params[k++] = &p_num_uniq; params[k++] = &p_error; params[k++] = &row_blocks4;
+    params[k++] = &tabs; params[k++] = &S; params[k++] = &D; params[k++] = &L; params[k++] = &uniq_rows;
+    params[k++] = &num_uniq; params[k++] = &row_g2; params[k++] = &row_g1; params[k++] = &owner_flag;
+    params[k++] = &clip_coef; params[k++] = &lr; params[k++] = &b1; params[k++] = &b2; params[k++] = &eps;
+    params[k++] = &step_ptr; params[k++] = &p; params[k++] = &m; params[k++] = &v; params[k++] = &g; params[k++] = &n;
+    params[k++] = &zero_grad;
+  }
+};
+
+int describe_apply_plan(const dfm_table* tables, int num_sparse, int dim, int num_lists, const int32_t* d_uniq_rows,
+                        const int32_t* d_num_uniq, const float* d_row_g2, const float* d_row_g1,
+                        const int32_t* d_owner_flag, const float* d_clip_coef, float lr, float beta1, float beta2,
+                        float eps, const int32_t* d_step, float* d_p, float* d_m, float* d_v, float* d_g, int64_t n,
+                        int zero_grad, const int64_t* d_next_ids, int64_t ids_stride, const int32_t* d_vocab,
+                        int max_vocab, int64_t batch, int32_t* d_next_sorted_pos, int32_t* d_next_uniq_rows,
+                        int32_t* d_next_seg_start, int32_t* d_next_num_uniq, int32_t* d_error_flag, ApplyPlanLaunch* a) {
+  DFM_REQUIRE(tables && d_uniq_rows && d_num_uniq && d_row_g2 && d_row_g1 && d_owner_flag && d_step && d_p && d_m &&
+                  d_v && d_g, "null argument");
+  DFM_REQUIRE(d_next_ids && d_vocab && d_next_sorted_pos && d_next_uniq_rows && d_next_seg_start && d_next_num_uniq,
+              "null row-plan argument");
+  DFM_REQUIRE(num_sparse > 0 && num_sparse <= DFM_MAX_FIELDS && num_lists > 0 && n > 0, "bad sizes");
+  DFM_REQUIRE(dim > 0 && dim % 4 == 0 && dim <= 256, "dim must be a multiple of 4 and <= 256");
+  DFM_REQUIRE(batch > 0 && batch < (int64_t(1) << 31) && ids_stride >= batch && max_vocab > 0, "bad batch / id stride");
+  if (int rc = fill_tables(tables, num_sparse, dim, &a->tabs, true)) return rc;
+  const bool narrow = max_vocab < (1 << 20) - 1;           // as dfm_rowplan_build
+  a->func = narrow ? reinterpret_cast<const void*>(step_apply_plan_kernel<uint32_t, 12>)
+                   : reinterpret_cast<const void*>(step_apply_plan_kernel<unsigned long long, 32>);
+  a->lds = rowplan::lds_bytes(narrow);
+  static bool allowed[2] = {false, false};
+  if (!allowed[narrow ? 0 : 1]) {
+    DFM_HIP_TRY(hipFuncSetAttribute(a->func, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(a->lds)));
+    allowed[narrow ? 0 : 1] = true;
+  }
+  constexpr int kPer = rowplan::SORT_THREADS / kTailThreads;
+  const int64_t rb = row_blocks(num_sparse, dim, num_lists), ab = (n + kTailThreads - 1) / kTailThreads;
+  const int64_t rb4 = (rb + kPer - 1) / kPer * kPer;
+  a->chunks = static_cast<int>((batch + CH - 1) / CH);
+  a->plan_blocks = num_sparse * a->chunks * (1 + rowplan::kTouchParts);
+  a->row_blocks4 = static_cast<int>(rb4);
+  a->grid = dim3(static_cast<unsigned>(a->plan_blocks + rb4 / kPer + (ab + kPer - 1) / kPer));
+  a->block = dim3(rowplan::SORT_THREADS);
+  a->S = num_sparse; a->D = dim; a->L = num_lists; a->zero_grad = zero_grad;
+  a->ids_base = d_next_ids; a->ids_stride = ids_stride; a->vocab = d_vocab; a->plan_n = batch; a->n = n;
+  a->p_sorted_pos = d_next_sorted_pos; a->p_uniq_rows = d_next_uniq_rows; a->p_seg_start = d_next_seg_start;
+  a->p_num_uniq = d_next_num_uniq; a->p_error = d_error_flag;
+  a->uniq_rows = d_uniq_rows; a->num_uniq = d_num_uniq; a->row_g2 = d_row_g2; a->row_g1 = d_row_g1;
+  a->owner_flag = d_owner_flag; a->clip_coef = d_clip_coef; a->lr = lr; a->b1 = beta1; a->b2 = beta2; a->eps = eps;
+  a->step_ptr = d_step; a->p = d_p; a->m = d_m; a->v = d_v; a->g = d_g;
+  a->bind();
+  return DFM_OK;
+}
+}  // namespace
+
+#define DFM_APPLY_PLAN_ARGS                                                                                              \
+  tables, num_sparse, dim, num_lists, d_uniq_rows, d_num_uniq, d_row_g2, d_row_g1, d_owner_flag, d_clip_coef, lr, beta1, \
+      beta2, eps, d_step, d_p, d_m, d_v, d_g, n, zero_grad, d_next_ids, ids_stride, d_vocab, max_vocab, batch,           \
+      d_next_sorted_pos, d_next_uniq_rows, d_next_seg_start, d_next_num_uniq, d_error_flag
+
+extern "C" int dfm_step_apply_plan(const dfm_table* tables, int num_sparse, int dim, int num_lists,
+                                   const int32_t* d_uniq_rows, const int32_t* d_num_uniq, const float* d_row_g2,
+                                   const float* d_row_g1, const int32_t* d_owner_flag, const float* d_clip_coef,
+                                   float lr, float beta1, float beta2, float eps, const int32_t* d_step, float* d_p,
+                                   float* d_m, float* d_v, float* d_g, int64_t n, int zero_grad,
+                                   const int64_t* d_next_ids, int64_t ids_stride, const int32_t* d_vocab, int max_vocab,
+                                   int64_t batch, int32_t* d_next_sorted_pos, int32_t* d_next_uniq_rows,
+                                   int32_t* d_next_seg_start, int32_t* d_next_num_uniq, int32_t* d_error_flag,
+                                   dfm_stream_t stream) {
+  ApplyPlanLaunch a;
+  if (int rc = describe_apply_plan(DFM_APPLY_PLAN_ARGS, &a)) return rc;
+  DFM_HIP_TRY(hipLaunchKernel(a.func, a.grid, a.block, a.params, a.lds, as_stream(stream)));
+  DFM_LAUNCH_CHECK();
+  return DFM_OK;
+}
+
+extern "C" int dfm_step_apply_plan_update(void* graph_exec, void* node, const dfm_table* tables, int num_sparse, int dim,
+                                          int num_lists, const int32_t* d_uniq_rows, const int32_t* d_num_uniq,
+                                          const float* d_row_g2, const float* d_row_g1, const int32_t* d_owner_flag,
+                                          const float* d_clip_coef, float lr, float beta1, float beta2, float eps,
+                                          const int32_t* d_step, float* d_p, float* d_m, float* d_v, float* d_g, int64_t n,
+                                          int zero_grad, const int64_t* d_next_ids, int64_t ids_stride,
+                                          const int32_t* d_vocab, int max_vocab, int64_t batch,
+                                          int32_t* d_next_sorted_pos, int32_t* d_next_uniq_rows,
+                                          int32_t* d_next_seg_start, int32_t* d_next_num_uniq, int32_t* d_error_flag) {
+  DFM_REQUIRE(graph_exec && node, "null argument");
+  ApplyPlanLaunch a;
+  if (int rc = describe_apply_plan(DFM_APPLY_PLAN_ARGS, &a)) return rc;
+  hipKernelNodeParams p;
+  memset(&p, 0, sizeof(p));
+  p.func = const_cast<void*>(a.func);
+  p.gridDim = a.grid;
+  p.blockDim = a.block;
+  p.sharedMemBytes = a.lds;
+  p.kernelParams = a.params;
+  p.extra = nullptr;
+  DFM_HIP_TRY(hipGraphExecKernelNodeSetParams(static_cast<hipGraphExec_t>(graph_exec), static_cast<hipGraphNode_t>(node), &p));
   return DFM_OK;
 }

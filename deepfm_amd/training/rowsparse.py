@@ -24,6 +24,7 @@ the same deterministic merge (``csrc/rowadam.hip``) so replicas stay bit-identic
 
 from __future__ import annotations
 
+import ctypes as C
 from typing import Optional
 
 import torch
@@ -122,6 +123,13 @@ class RowSparseAdam:
             p.grad = self.flat_grad[off:off + n].view_as(p)
             off += padded(n)
         self._owner = None
+        self.next_plan = None            # (next batch's ids pointer, target RowSparseBuffers): set by the step, see apply()
+        self._vocab_dev, self._max_vocab, self._keep_tabs = None, 0, None
+        specs = list(self.row_emb.schema.fields.values())
+        vocab = [specs[i].vocabulary_size for i in self.row_emb._sparse_pos]
+        if vocab:                            # vocabulary sizes on the device, for dfm_step_apply_plan (not creatable under capture)
+            self._vocab_dev = torch.tensor(vocab, dtype=torch.int32, device=self.device)
+            self._max_vocab = max(vocab)
         self._gathered = None
         self._partials = None
         self._match = None
@@ -209,12 +217,40 @@ class RowSparseAdam:
                                               self.max_grad_norm or 0.0, self.sq_norm.data_ptr(),
                                               self.clip_coef.data_ptr(), self.step_count.data_ptr(),
                                               _lib.ptr(self.seed_tick), stream))
-        _lib.check(lib.dfm_step_apply(tabs, self.num_sparse, self.dim, lists, uniq.data_ptr(), num.data_ptr(),
-                                      g2.data_ptr(), g1.data_ptr(), self._owner.data_ptr(), self.clip_coef.data_ptr(),
-                                      self.lr, self.betas[0], self.betas[1], self.eps, self.step_count.data_ptr(),
-                                      self.flat_param.data_ptr(), self.flat_m.data_ptr(), self.flat_v.data_ptr(),
-                                      self.flat_grad.data_ptr(), n_dense, 1, stream))
+        if self.next_plan is not None:
+            # the row plan (+ row touch) of the NEXT step rides in this launch (csrc/step_tail.hip)
+            ids_ptr, target = self.next_plan
+            self.next_plan = None
+            _lib.check(lib.dfm_step_apply_plan(*self._apply_plan_args(self._cur, ids_ptr, target), stream))
+        else:
+            _lib.check(lib.dfm_step_apply(tabs, self.num_sparse, self.dim, lists, uniq.data_ptr(), num.data_ptr(),
+                                          g2.data_ptr(), g1.data_ptr(), self._owner.data_ptr(), self.clip_coef.data_ptr(),
+                                          self.lr, self.betas[0], self.betas[1], self.eps, self.step_count.data_ptr(),
+                                          self.flat_param.data_ptr(), self.flat_m.data_ptr(), self.flat_v.data_ptr(),
+                                          self.flat_grad.data_ptr(), n_dense, 1, stream))
         self.row_emb.rowsparse.has_grad = False
+
+    def _apply_plan_args(self, cur, ids_ptr: int, target):
+        """Arguments of dfm_step_apply_plan (without the stream): ``cur`` = this step's lists (``_cur``), ``ids_ptr`` =
+        device address of the next batch's (S, B) int64 id columns, ``target`` = the RowSparseBuffers the next step's
+        plan goes to."""
+        uniq, num, g2, g1, lists = cur
+        if self._vocab_dev is None:
+            raise RuntimeError("RowSparseAdam: no SPARSE fields to plan for")
+        tabs = self._table_struct()
+        self._keep_tabs = tabs
+        B = target.batch
+        return (tabs, self.num_sparse, self.dim, lists, uniq.data_ptr(), num.data_ptr(), g2.data_ptr(), g1.data_ptr(),
+                self._owner.data_ptr(), self.clip_coef.data_ptr(), self.lr, self.betas[0], self.betas[1], self.eps,
+                self.step_count.data_ptr(), self.flat_param.data_ptr(), self.flat_m.data_ptr(), self.flat_v.data_ptr(),
+                self.flat_grad.data_ptr(), self.flat_param.numel(), 1, ids_ptr, B, self._vocab_dev.data_ptr(),
+                self._max_vocab, B, target.sorted_pos.data_ptr(), target.uniq_rows.data_ptr(), target.seg_start.data_ptr(),
+                target.num_uniq.data_ptr(), self.row_emb._err.data_ptr())
+
+    def apply_plan_update(self, graph_exec: int, node, cur, ids_ptr: int, target) -> None:
+        """The captured dfm_step_apply_plan node of an instantiated graph -> the next launch's record (host-side only)."""
+        _lib.check(_lib.load().dfm_step_apply_plan_update(C.c_void_p(graph_exec), node,
+                                                          *self._apply_plan_args(cur, ids_ptr, target)))
 
     def _dense_source(self):
         """(every rank's dense gradient buffer, floats between ranks) for the prepare launch's rank-ordered

@@ -72,6 +72,7 @@ class _GraphSlot:
 class RowSparseTrainStep:
     exchange_in_body = False      # True: the step's collectives are part of _gather / _body_a / _body_b themselves
     rowplan_first_default = True  # row plan + row touch in front of the gather (False: in line behind it, round 2's order)
+    plan_lookahead_default = True # steps 2.. of a multi-step graph: the plan is built by the previous step's apply launch
 
     def __init__(self, model, optimizer: RowSparseAdam, batch_size: int, use_graph: bool = True) -> None:
         self.model, self.opt, self.B = model, optimizer, batch_size
@@ -116,6 +117,11 @@ class RowSparseTrainStep:
         # the optimizer's dirty lines.  Same plan, same results; one more graph node re-pointed per step.
         self.rowplan_first = self.n_sparse > 0 and self.rowplan_first_default
         self._plan_done = False
+        # Inside a graph of several steps, step k + 1's row plan (+ row touch) rides in step k's last optimizer launch
+        # (dfm_step_apply_plan) instead of opening step k + 1: two sets of plan buffers alternate, and a third node per
+        # step is re-pointed at launch.  Only the first step of a graph builds its plan in front of its gather.
+        self.plan_lookahead = self.rowplan_first and self.plan_lookahead_default
+        self._plan_sets = None
         self._record: torch.Tensor = self.inbox       # batch record the next gather reads
         F, D = len(specs), self.emb.fm_embed_dim
         self.fo = torch.empty(batch_size, 1, dtype=torch.float32, device=dev)
@@ -195,11 +201,15 @@ class RowSparseTrainStep:
         a, kw = self._gather_call(record)
         self.emb.forward_staged(*a, **kw)
 
-    def _capture_gather(self, record: torch.Tensor):
+    def _capture_gather(self, record: torch.Tensor, with_plan: bool = True):
         """``_gather`` while the stream is being captured; returns the graph node(s) that read the batch
-        record (the ones ``_update_gather`` re-points before every launch): (gather node, row-plan node or None)."""
+        record (the ones ``_update_gather`` re-points before every launch): (gather node, row-plan node or None).
+        ``with_plan`` False: the plan of this step was built by the previous step's apply launch."""
         plan_node = None
-        if self.rowplan_first:
+        self._plan_done = False
+        if self.rowplan_first and not with_plan:
+            self._plan_done = True
+        elif self.rowplan_first:
             self._plan_from_record(record)
             plan_node = C.c_void_p()
             _lib.check(_lib.load().dfm_graph_last_node(_lib.stream_handle(), C.byref(plan_node)))
@@ -336,17 +346,41 @@ class RowSparseTrainStep:
             raise ValueError("steps_per_graph > 1 needs the whole step inside one graph (one rank, or the in-graph exchange)")
         self.steps_per_graph = steps_per_graph
         self.slots = []
+        lib = _lib.load()
+        # plan look-ahead: whole steps in one graph, several of them, plan built from the batch record
+        look = self.plan_lookahead and steps_per_graph > 1 and (single or fused_exchange) and self.emb.rowsparse is not None
+        sets = None
+        if look:
+            from deepfm_amd.models.layers.embedding import RowSparseBuffers
+            rs = self.emb.rowsparse
+            sets = self._plan_sets = [rs, RowSparseBuffers(rs.num_sparse, rs.dim, rs.batch, rs.row_g2.device)]
         for _ in range(2):
             slot = _GraphSlot()
             # keep_graph: the captured graph stays alive, so the gather's node handle stays valid for
             # hipGraphExecKernelNodeSetParams on the exec instantiated from it
             slot.graph = torch.cuda.CUDAGraph(keep_graph=True)
             with torch.cuda.graph(slot.graph, **mode):
-                for _k in range(steps_per_graph):
-                    slot.nodes.append(self._capture_gather(self.pad))
+                for k in range(steps_per_graph):
+                    if look:
+                        self.emb.rowsparse = sets[k % 2]
+                    # (subclasses with their own gather — the field-sharded step — keep their signature)
+                    read_nodes = (self._capture_gather(self.pad, with_plan=not (look and k > 0)) if self.rowplan_first
+                                  else self._capture_gather(self.pad))
+                    apply_node = cur = target = None
+                    if look and k + 1 < steps_per_graph:
+                        # this step's apply launch also builds step k + 1's plan, into the other set of buffers
+                        target = sets[(k + 1) % 2]
+                        self.opt.next_plan = (self.pad.data_ptr() + self._rec_id_offsets[0], target)
                     body()
+                    if target is not None:
+                        apply_node = C.c_void_p()
+                        _lib.check(lib.dfm_graph_last_node(_lib.stream_handle(), C.byref(apply_node)))
+                        cur = self.opt._cur
+                    slot.nodes.append((read_nodes, apply_node, cur, target))
             slot.graph.instantiate()
             self.slots.append(slot)
+        if look:
+            self.emb.rowsparse = sets[0]       # single steps (eager, timed variant) and every graph's first step
         if timed_variant:
             self.body_graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.body_graph, **mode):
@@ -421,8 +455,10 @@ class RowSparseTrainStep:
         else:
             slot.done = torch.cuda.Event()
         ex = slot.graph.raw_cuda_graph_exec()
-        for node, rec in zip(slot.nodes, records):
-            self._update_gather(ex, node, rec)
+        for k, ((read_nodes, apply_node, cur, target), rec) in enumerate(zip(slot.nodes, records)):
+            self._update_gather(ex, read_nodes, rec)
+            if apply_node is not None:       # step k's apply launch sorts step k + 1's ids: point it at that record
+                self.opt.apply_plan_update(ex, apply_node, cur, records[k + 1].data_ptr() + self._rec_id_offsets[0], target)
         slot.graph.replay()
         self._after_graph_a(slot.done)
 

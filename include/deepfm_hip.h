@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DFM_ABI_VERSION 4   /* bump whenever a struct layout or a signature in this header changes */
+#define DFM_ABI_VERSION 5   /* bump whenever a struct layout or a signature in this header changes */
 #define DFM_MAX_FIELDS 64      /* per-call pointer tables travel as kernel arguments */
 #define DFM_MAX_RANKS 64       /* data-parallel ranks of one job (csrc/shard.hip) */
 #define DFM_ROWPLAN_CHUNK 4096 /* ids per sorted list (one LDS-resident sort) */
@@ -614,6 +614,28 @@ int dfm_step_apply(const dfm_table* tables, int num_sparse, int dim, int num_lis
                    const float* d_row_g1, const int32_t* d_owner_flag, const float* d_clip_coef, float lr,
                    float beta1, float beta2, float eps, const int32_t* d_step, float* d_p, float* d_m,
                    float* d_v, float* d_g, int64_t n, int zero_grad, dfm_stream_t stream);
+/* dfm_step_apply of step t + dfm_rowplan_build (with its row touch) of step t + 1 in ONE launch: the plan depends on
+ * the next batch's ids only (trainer.py:212-217 hands batches over one by one; a graph of several steps knows them
+ * all), and sorts on the first workgroups of the optimizer's last launch instead of costing a ~13 us launch of its
+ * own at the head of the next step.  d_next_ids: (num_sparse, batch) int64, column s at d_next_ids + s * ids_stride
+ * (a batch record); d_vocab (num_sparse) int32 on the device, max_vocab their maximum; d_next_*: the plan buffers of
+ * the NEXT step (not the ones this step's lists live in).  _update: re-point the captured node at another record. */
+int dfm_step_apply_plan(const dfm_table* tables, int num_sparse, int dim, int num_lists,
+                        const int32_t* d_uniq_rows, const int32_t* d_num_uniq, const float* d_row_g2,
+                        const float* d_row_g1, const int32_t* d_owner_flag, const float* d_clip_coef, float lr,
+                        float beta1, float beta2, float eps, const int32_t* d_step, float* d_p, float* d_m,
+                        float* d_v, float* d_g, int64_t n, int zero_grad, const int64_t* d_next_ids,
+                        int64_t ids_stride, const int32_t* d_vocab, int max_vocab, int64_t batch,
+                        int32_t* d_next_sorted_pos, int32_t* d_next_uniq_rows, int32_t* d_next_seg_start,
+                        int32_t* d_next_num_uniq, int32_t* d_error_flag, dfm_stream_t stream);
+int dfm_step_apply_plan_update(void* graph_exec, void* node, const dfm_table* tables, int num_sparse, int dim,
+                               int num_lists, const int32_t* d_uniq_rows, const int32_t* d_num_uniq,
+                               const float* d_row_g2, const float* d_row_g1, const int32_t* d_owner_flag,
+                               const float* d_clip_coef, float lr, float beta1, float beta2, float eps,
+                               const int32_t* d_step, float* d_p, float* d_m, float* d_v, float* d_g, int64_t n,
+                               int zero_grad, const int64_t* d_next_ids, int64_t ids_stride, const int32_t* d_vocab,
+                               int max_vocab, int64_t batch, int32_t* d_next_sorted_pos, int32_t* d_next_uniq_rows,
+                               int32_t* d_next_seg_start, int32_t* d_next_num_uniq, int32_t* d_error_flag);
 
 /* ---------------------------------------------------------------------------------
  * Exact-fp32 GEMM on the matrix cores (v_mfma_f32_32x32x2_f32) for the DNN tower's Linear

@@ -30,8 +30,10 @@ def main():
     fused = len(sys.argv) > 3 and sys.argv[3] in ("fused", "sharded")
     sharded = len(sys.argv) > 3 and sys.argv[3] == "sharded"      # field-sharded tables (training/sharded.py)
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    torch.cuda.set_device(0)
-    dev = torch.device("cuda", 0)
+    # DFM_WORKER_ONE_GPU_PER_RANK=1 (multi-GPU boxes): rank r on cuda:r, the layout bench.py --gpus N runs
+    local = int(os.environ.get("LOCAL_RANK", "0")) if os.environ.get("DFM_WORKER_ONE_GPU_PER_RANK") == "1" else 0
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
     # a fourth argument "nccl" (single rank only): the RCCL backend, so that collectives can be captured
     backend = sys.argv[4] if len(sys.argv) > 4 else "gloo"
     dist.init_process_group(backend, device_id=dev if backend == "nccl" else None)
