@@ -68,12 +68,9 @@ def parse():
     ap.add_argument("--no-extra-configs", action="store_true",
                     help="skip BASELINE.json configurations 3 and 4 (xDeepFM / AttentionDeepFM) after the headline")
     ap.add_argument("--extra-steps", type=int, default=60, help="timed steps of each extra configuration")
-    ap.add_argument("--timing-every", type=int, default=0,
-                    help="one launch in n of the timed region is a single step whose gather is launched eagerly with HIP "
-                         "events on the dispatch (the others are graph launches of --steps-per-graph steps); "
-                         "0 = automatic: 3, or 2 for runs of 40 steps or fewer (more samples)")
-    ap.add_argument("--steps-per-graph", type=int, default=4,
-                    help="consecutive training steps captured in one HIP graph (1 under data parallelism)")
+    ap.add_argument("--steps-per-graph", type=int, default=0,
+                    help="consecutive training steps captured in one HIP graph (1 under data parallelism); 0 = automatic: "
+                         "4..8, chosen so that the timed region is whole graphs plus two timed single steps")
     ap.add_argument("--gather-shape", type=int, default=0,
                     help="tuning aid: force a launch shape of the gather (dfm_gather_set_shape); 0 = automatic")
     ap.add_argument("--rowplan-inline", action="store_true",
@@ -262,7 +259,7 @@ def extra_config(name, args, dev, lib, ids_dist="uniform"):
     cin_sizes = [128, 128, 128] if name == "xdeepfm" else None
     model, opt, step, fields, cfg, hp, fused = build_step(name, V, D, B, dev, args, cin_sizes)
     n_sparse, n_dense = 26, 13
-    G = 1 if (args.no_graph or (opt.split and not step.exchange_in_body)) else args.steps_per_graph
+    G = 1 if (args.no_graph or (opt.split and not step.exchange_in_body)) else (args.steps_per_graph or 4)
     warm, steps = -(-10 // G) * G, max(args.extra_steps // G, 1) * G                   # whole graph launches
     ids, dense, labels = make_pool(warm + steps, n_sparse, n_dense, B, V, 101, dev, ids_dist)     # every batch used once
     records = step.pack_batches(ids, dense, labels)
@@ -337,8 +334,6 @@ def extra_config(name, args, dev, lib, ids_dist="uniform"):
 
 def main():
     args = parse()
-    if args.timing_every <= 0:
-        args.timing_every = 2 if args.steps <= 40 else 3
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -387,7 +382,23 @@ def main():
     records = step.pack_batches(ids, dense, labels)      # one record per batch, resident in HBM
     step.load_packed(records[0])
     # several steps per graph need the whole step inside ONE graph: one rank without the split exchange path
-    spg = 1 if ((opt.split and not step.exchange_in_body) or args.no_graph) else args.steps_per_graph
+    def choose_graph_shape(steps):
+        """(steps per graph, timed single steps inside the timed region): the fewest timed singles >= 2 such that the
+        other steps fill whole graphs of 4..8 steps (a single step costs ~55 us more than its share of a graph: at the
+        driver's --steps 20, 2 + 3 x 6 instead of 4 + 4 x 4 is 6 us per step)."""
+        if args.steps_per_graph > 0:
+            g = args.steps_per_graph
+            t = 2 + (steps - 2) % g if steps >= 2 else 0
+            return g, t
+        for t in range(2, 10):
+            for g in (4, 5, 6, 7, 8):
+                if steps - t >= g and (steps - t) % g == 0:
+                    return g, t
+        return 4, 2 + (steps - 2) % 4 if steps >= 2 else 0
+    auto_g, n_timed_region = choose_graph_shape(args.steps)
+    spg = 1 if ((opt.split and not step.exchange_in_body) or args.no_graph) else auto_g
+    if spg == 1:
+        n_timed_region = max(args.steps // 3, 1)
     # Graph capture must succeed on EVERY rank or on none: ranks that replay a graph and ranks that launch eagerly
     # would issue different collective sequences.  A failed capture leaves the step's state restored
     # (RowSparseTrainStep.capture), so the eager fallback starts from the same parameters.
@@ -425,23 +436,27 @@ def main():
     def rec(i):
         return next(feed) if feed is not None else records[i]
 
-    def plan(lo, hi, timing):
+    def plan(lo, hi, n_timed):
         """How steps lo..hi-1 are launched: ('group', i) = steps i..i+G-1 in ONE graph launch; ('timed', i) /
-        ('single', i) = one step with the gather launched eagerly in front of the gather-less copy of the
-        graph (the only place HIP events can be attached to its dispatch).  With timing on, one timed
-        single step opens every cycle of `timing_every` launches; leftovers (hi - lo not a multiple of G)
-        run as single steps."""
-        out, i, launch = [], lo, 0
+        ('single', i) = one step with the row plan and the gather launched eagerly in front of the gather-less copy
+        of the graph (the only place HIP events can be attached to the gather's dispatch; ~55 us more than a step
+        inside a group).  ``n_timed`` timed single steps come first; steps that do not fill a
+        group run as single steps (none when (hi - lo - n_timed) is a multiple of G: choose_graph_shape)."""
+        n = hi - lo
+        if args.no_graph:
+            return [("timed" if k < n_timed else "single", lo + k) for k in range(n)]
+        n_timed = min(n_timed, n)
+        groups = (n - n_timed) // G
+        # the timed single steps OPEN the region: their ~0.5 ms of device time covers the host-side preparation of
+        # the first multi-step graph launch (three node updates per step + the launch of ~100 nodes), which would
+        # otherwise leave the device idle right after the region's opening synchronisation
+        out, i = [], lo
+        for _ in range(n_timed):
+            out.append(("timed", i)); i += 1
+        for _ in range(groups):
+            out.append(("group", i)); i += G
         while i < hi:
-            if args.no_graph:
-                out.append(("timed" if timing else "single", i)); i += 1
-            elif timing and launch % args.timing_every == 0:
-                out.append(("timed", i)); i += 1
-            elif i + G <= hi:
-                out.append(("group", i)); i += G
-            else:
-                out.append(("single", i)); i += 1
-            launch += 1
+            out.append(("single", i)); i += 1
         return out
 
     def execute(p):
@@ -451,16 +466,21 @@ def main():
             else:
                 step.run_from(rec(i), eager_gather=not args.no_graph)
 
-    execute(plan(0, args.warmup, False))
+    if G > 1 and args.warmup < 2 * G and feed is None:
+        # both instantiated copies of the step graph get one untimed launch (their first launch uploads the exec): W can
+        # be smaller than two graphs (the driver's --warmup 5); these steps come on top of the W warm-up steps
+        for _ in range(2):
+            step.run_group([records[k % total] for k in range(G)])
+    execute(plan(0, args.warmup, 0))
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    # The gather is a node of the step's graph.  Once per `timing_every` launches of the timed region a step
+    # The gather is a node of the step's graph.  A few steps of the timed region (choose_graph_shape) launch
     # launches it eagerly instead, in front of a gather-less copy of the graph, with HIP start/stop events
     # attached to the dispatch (hipExtLaunchKernel): the same kernel, arguments and position in the step,
     # timed like rocprofv3's kernel trace times it.  (--no-graph: every step is eager and timed.)
     timing = not args.no_gather_timing
-    timed_plan = plan(args.warmup, total, timing)
+    timed_plan = plan(args.warmup, total, n_timed_region if timing else 0)
     n_timed = sum(1 for kind, _ in timed_plan if kind == "timed")
     if n_timed:
         _lib.check(lib.dfm_gather_timing_begin(n_timed))
@@ -570,9 +590,10 @@ def main():
                 "min_launch_us": min(gather_us) if gather_us else None,
                 "launches_timed": len(gather_us),
                 "launches_timed_in_region": n_in_region, "launches_timed_after_region": n_after,
-                "timer": f"HIP start/stop events attached to the gather dispatch (hipExtLaunchKernel, on the launch stream): one launch "
-                         f"in {args.timing_every} of the timed region is a single step whose gather is launched eagerly in front of a "
-                         f"gather-less copy of the step's graph; the other launches are graphs of {G} step(s) with the gather as a node",
+                "timer": f"HIP start/stop events attached to the gather dispatch (hipExtLaunchKernel, on the launch stream): "
+                         f"{n_in_region} step(s) of the timed region are single steps whose gather is launched eagerly in front of a "
+                         f"gather-less copy of the step's graph (the other launches are graphs of {G} step(s) with the gather as a "
+                         f"node), {n_after} more such steps follow the region",
                 "rocprof": pmc,
             },
         }
