@@ -525,8 +525,8 @@ def main():
         world == 1 and timing and args.vocab_profile == "equal" and not args.no_gather_sweep) else None
 
     pmc = None
-    pmc_path = os.path.join(ROOT, "profiles", "r02_gather_pmc.json")
-    if os.path.exists(pmc_path) and B == 4096 and V == 1_000_000 and D == 16:
+    pmc_path = next((q for q in (os.path.join(ROOT, "profiles", f"r{r:02d}_gather_pmc.json") for r in (3, 2)) if os.path.exists(q)), "")
+    if pmc_path and B == 4096 and V == 1_000_000 and D == 16:
         with open(pmc_path) as fh:
             pmc = json.load(fh)
     if rank == 0:

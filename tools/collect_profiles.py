@@ -36,7 +36,7 @@ def pmc(counter):
 r128, r64, r32 = pmc("TCC_EA0_RDREQ_128B_sum"), pmc("TCC_EA0_RDREQ_64B_sum"), pmc("TCC_EA0_RDREQ_32B_sum")
 w64, wall = pmc("TCC_EA0_WRREQ_64B_sum"), pmc("TCC_EA0_WRREQ_sum")
 stats = {r["Name"]: r for r in csv.DictReader(open(os.path.join(src, "bench_kernel_stats.csv")))}
-gk = [k for k in stats if k.startswith("void emb_fwd_pair") and "true>" in k]
+gk = [k for k in stats if k.startswith("void emb_fwd_pair") and "true" in k]
 out = {"kernel": gk[0] if gk else None,
        "command": "tools/profile_round.sh: rocprofv3 --pmc <one counter> --kernel-trace -- python3 bench.py --steps 40 --warmup 8 "
                   "--no-cpu-baseline --no-extra-configs (one pass per counter)"}
