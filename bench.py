@@ -448,8 +448,9 @@ def main():
         n_timed = min(n_timed, n)
         groups = (n - n_timed) // G
         # the timed single steps OPEN the region: their ~0.5 ms of device time covers the host-side preparation of
-        # the first multi-step graph launch (three node updates per step + the launch of ~100 nodes), which would
-        # otherwise leave the device idle right after the region's opening synchronisation
+        # the first multi-step graph launch (three node updates per step + the launch of ~100 nodes: ~0.4 ms), which
+        # would otherwise leave the device idle right after the region's opening synchronisation (measured: one single
+        # in front instead of two costs the 20-step region 0.009 ms per step)
         out, i = [], lo
         for _ in range(n_timed):
             out.append(("timed", i)); i += 1
@@ -459,10 +460,17 @@ def main():
             out.append(("single", i)); i += 1
         return out
 
-    def execute(p):
-        for kind, i in p:
+    def execute(p, after=None):
+        """``after``: record index the launch that follows this plan starts with (None: unknown)."""
+        for j, (kind, i) in enumerate(p):
+            nxt = p[j + 1][1] if j + 1 < len(p) else after
             if kind == "group":
-                step.run_group([rec(i + k) for k in range(G)]) if G > 1 else step.run_from(rec(i))
+                if G > 1:
+                    # the launch's last optimizer kernel also sorts the NEXT launch's first batch (training/step.py)
+                    step.run_group([rec(i + k) for k in range(G)],
+                                   next_record=records[nxt] if (nxt is not None and feed is None) else None)
+                else:
+                    step.run_from(rec(i))
             else:
                 step.run_from(rec(i), eager_gather=not args.no_graph)
 
@@ -471,7 +479,7 @@ def main():
         # be smaller than two graphs (the driver's --warmup 5); these steps come on top of the W warm-up steps
         for _ in range(2):
             step.run_group([records[k % total] for k in range(G)])
-    execute(plan(0, args.warmup, 0))
+    execute(plan(0, args.warmup, 0), after=args.warmup if args.warmup < total else None)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -512,6 +520,10 @@ def main():
         rec2 = step.pack_batches(ids2, dense2, labels2)
         _lib.check(lib.dfm_gather_timing_begin(n_after))
         for i in range(n_after):
+            if G > 1 and getattr(step, "cont_slots", None):
+                # a graph launch whose last apply plans for the timed step: its gather then follows the same launch
+                # (step_apply_plan) as every graph-node gather does
+                step.run_group([records[(i * G + k) % total] for k in range(G)], next_record=rec2[i])
             step.run_from(rec2[i], eager_gather=True)
         torch.cuda.synchronize()
         us2 = (C.c_float * n_after)()

@@ -122,6 +122,9 @@ class RowSparseTrainStep:
         # step is re-pointed at launch.  Only the first step of a graph builds its plan in front of its gather.
         self.plan_lookahead = self.rowplan_first and self.plan_lookahead_default
         self._plan_sets = None
+        self.cont_slots: List[_GraphSlot] = []
+        self._turn_cont = 0
+        self._handoff_ptr: Optional[int] = None      # record (data_ptr) whose plan the previous launch left in the hand-off set
         self._record: torch.Tensor = self.inbox       # batch record the next gather reads
         F, D = len(specs), self.emb.fm_embed_dim
         self.fo = torch.empty(batch_size, 1, dtype=torch.float32, device=dev)
@@ -196,8 +199,11 @@ class RowSparseTrainStep:
     def _gather(self, record: Optional[torch.Tensor] = None) -> None:
         record = self._record if record is None else record
         self._plan_done = False
-        if self.rowplan_first:
+        if self.rowplan_first and self._handoff_ptr is not None and self._handoff_ptr == record.data_ptr():
+            self._plan_done = True             # the previous launch's last apply built this record's plan (hand-off set)
+        elif self.rowplan_first:
             self._plan_from_record(record)
+        self._handoff_ptr = None
         a, kw = self._gather_call(record)
         self.emb.forward_staged(*a, **kw)
 
@@ -303,6 +309,7 @@ class RowSparseTrainStep:
             # a refused capture (e.g. a runtime that will not capture the collectives) must not leave half a
             # set of graphs behind: the caller may go on eagerly (bench.py does, after agreeing over all ranks)
             self.slots, self.body_graph, self.graph_b = [], None, None
+            self.cont_slots, self._turn_cont, self._handoff_ptr = [], 0, None
             self.steps_per_graph, self._turn = 1, 0
             self._plan_done = False
             raise
@@ -351,10 +358,16 @@ class RowSparseTrainStep:
         look = self.plan_lookahead and steps_per_graph > 1 and (single or fused_exchange) and self.emb.rowsparse is not None
         sets = None
         if look:
+            # three sets of plan buffers: H ("hand-off": the plan a launch starts from — built by its own first node or
+            # by the LAST apply of the previous launch) and A / B alternating inside the graph
             from deepfm_amd.models.layers.embedding import RowSparseBuffers
             rs = self.emb.rowsparse
-            sets = self._plan_sets = [rs, RowSparseBuffers(rs.num_sparse, rs.dim, rs.batch, rs.row_g2.device)]
-        for _ in range(2):
+            mk = lambda: RowSparseBuffers(rs.num_sparse, rs.dim, rs.batch, rs.row_g2.device)
+            sets = self._plan_sets = [rs, mk(), mk()]          # [H, A, B]
+        self.cont_slots = []
+        ids0 = self.pad.data_ptr() + (self._rec_id_offsets[0] if self._rec_id_offsets else 0)
+
+        def capture_slot(cont: bool) -> _GraphSlot:
             slot = _GraphSlot()
             # keep_graph: the captured graph stays alive, so the gather's node handle stays valid for
             # hipGraphExecKernelNodeSetParams on the exec instantiated from it
@@ -362,15 +375,16 @@ class RowSparseTrainStep:
             with torch.cuda.graph(slot.graph, **mode):
                 for k in range(steps_per_graph):
                     if look:
-                        self.emb.rowsparse = sets[k % 2]
+                        self.emb.rowsparse = sets[0] if k == 0 else sets[1 + (k - 1) % 2]
                     # (subclasses with their own gather — the field-sharded step — keep their signature)
-                    read_nodes = (self._capture_gather(self.pad, with_plan=not (look and k > 0)) if self.rowplan_first
-                                  else self._capture_gather(self.pad))
+                    read_nodes = (self._capture_gather(self.pad, with_plan=not (look and (k > 0 or cont)))
+                                  if self.rowplan_first else self._capture_gather(self.pad))
                     apply_node = cur = target = None
-                    if look and k + 1 < steps_per_graph:
-                        # this step's apply launch also builds step k + 1's plan, into the other set of buffers
-                        target = sets[(k + 1) % 2]
-                        self.opt.next_plan = (self.pad.data_ptr() + self._rec_id_offsets[0], target)
+                    if look:
+                        # this step's apply launch also builds the NEXT step's plan: the following step of the graph
+                        # (other set), or — last step — the first step of the next launch (hand-off set)
+                        target = sets[1 + k % 2] if k + 1 < steps_per_graph else sets[0]
+                        self.opt.next_plan = (ids0, target)
                     body()
                     if target is not None:
                         apply_node = C.c_void_p()
@@ -378,9 +392,14 @@ class RowSparseTrainStep:
                         cur = self.opt._cur
                     slot.nodes.append((read_nodes, apply_node, cur, target))
             slot.graph.instantiate()
-            self.slots.append(slot)
+            return slot
+
+        for _ in range(2):
+            self.slots.append(capture_slot(False))
         if look:
-            self.emb.rowsparse = sets[0]       # single steps (eager, timed variant) and every graph's first step
+            for _ in range(2):                 # "continuation" flavour: no plan node, the plan is already in the hand-off set
+                self.cont_slots.append(capture_slot(True))
+            self.emb.rowsparse = sets[0]       # single steps (eager, timed variant) and every launch's first step
         if timed_variant:
             self.body_graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.body_graph, **mode):
@@ -401,6 +420,7 @@ class RowSparseTrainStep:
             return
         torch.cuda.synchronize()
         self.slots, self.body_graph, self.graph_b = [], None, None
+        self.cont_slots, self._turn_cont, self._handoff_ptr = [], 0, None
         self.steps_per_graph, self._turn = 1, 0
         import gc
         gc.collect()
@@ -408,7 +428,8 @@ class RowSparseTrainStep:
 
     def run_from(self, record: torch.Tensor, eager_gather: bool = False) -> None:
         """One step on a ``pack_batches()`` record: the gather reads its inputs from the record and
-        refreshes the static input buffers — ids, dense values, labels — the rest of the step reads."""
+        refreshes the static input buffers — ids, dense values, labels — the rest of the step reads.
+        (A record that the previous ``run_group(..., next_record=record)`` planned for starts at its gather.)"""
         if record.numel() != self.packed_bytes or record.dtype != torch.uint8 or not record.is_contiguous():
             raise ValueError("run_from expects one contiguous pack_batches() record")
         if record.data_ptr() % 16:
@@ -427,15 +448,17 @@ class RowSparseTrainStep:
             if self.body_graph is None:
                 raise RuntimeError("run(eager_gather=True) needs capture(timed_variant=True)")
             self._gather()                 # eager: dfm_gather_timing_begin may attach events to this dispatch
-            self.body_graph.replay()
+            self.body_graph.replay()       # (its apply plans for nobody: the next launch builds its own plan)
             self._after_graph_a(None)
             return
         if self.steps_per_graph != 1:
             raise RuntimeError(f"the graphs hold {self.steps_per_graph} steps each: use run_group()")
         self._launch([self._record])
 
-    def run_group(self, records) -> None:
-        """``steps_per_graph`` consecutive steps, one graph launch: ``records[k]`` is step k's batch record."""
+    def run_group(self, records, next_record: Optional[torch.Tensor] = None) -> None:
+        """``steps_per_graph`` consecutive steps, one graph launch: ``records[k]`` is step k's batch record.
+        ``next_record`` (optional): the record the NEXT launch (``run_group`` or ``run_from``) starts with — this
+        launch's last optimizer kernel then builds its row plan, and the next launch starts at its gather."""
         if len(records) != self.steps_per_graph:
             raise ValueError(f"run_group expects {self.steps_per_graph} records")
         if not self.slots:
@@ -445,11 +468,16 @@ class RowSparseTrainStep:
         for r in records:
             if r.numel() != self.packed_bytes or r.dtype != torch.uint8 or not r.is_contiguous() or r.data_ptr() % 16:
                 raise ValueError("run_group expects contiguous, 16-byte aligned pack_batches() records")
-        self._launch(list(records))
+        self._launch(list(records), next_record)
 
-    def _launch(self, records) -> None:
-        slot = self.slots[self._turn]
-        self._turn ^= 1
+    def _launch(self, records, next_record: Optional[torch.Tensor] = None) -> None:
+        cont = bool(self.cont_slots) and self._handoff_ptr is not None and self._handoff_ptr == records[0].data_ptr()
+        if cont:
+            slot = self.cont_slots[self._turn_cont]
+            self._turn_cont ^= 1
+        else:
+            slot = self.slots[self._turn]
+            self._turn ^= 1
         if slot.done is not None:
             slot.done.synchronize()        # its previous launch (two launches ago) has left the device
         else:
@@ -457,8 +485,10 @@ class RowSparseTrainStep:
         ex = slot.graph.raw_cuda_graph_exec()
         for k, ((read_nodes, apply_node, cur, target), rec) in enumerate(zip(slot.nodes, records)):
             self._update_gather(ex, read_nodes, rec)
-            if apply_node is not None:       # step k's apply launch sorts step k + 1's ids: point it at that record
-                self.opt.apply_plan_update(ex, apply_node, cur, records[k + 1].data_ptr() + self._rec_id_offsets[0], target)
+            if apply_node is not None:       # step k's apply launch sorts the next step's ids: point it at that record
+                nxt = records[k + 1] if k + 1 < len(records) else (next_record if next_record is not None else records[0])
+                self.opt.apply_plan_update(ex, apply_node, cur, nxt.data_ptr() + self._rec_id_offsets[0], target)
+        self._handoff_ptr = next_record.data_ptr() if (next_record is not None and self.cont_slots) else None
         slot.graph.replay()
         self._after_graph_a(slot.done)
 

@@ -401,12 +401,30 @@ def test_graph_node_updates_and_eager_gather_variant_are_bitwise_equal_to_eager(
     fields = criteo_fields(300, 16)
     ids, dense, labels = _pool(fields, n, B, rng)
     results = []
-    for mode in ("eager", "graph", "mixed", "groups"):
+    for mode in ("eager", "graph", "mixed", "groups", "handoff"):
         _, _, model, hp, opt, Step = _fused_pair(B, seed=8)
         step = Step(model, opt, B, use_graph=mode != "eager")
         recs = step.pack_batches(torch.from_numpy(ids).cuda(), torch.from_numpy(dense).cuda(), torch.from_numpy(labels).cuda())
-        step.capture(timed_variant=True, steps_per_graph=3 if mode == "groups" else 1)
+        step.capture(timed_variant=True, steps_per_graph=3 if mode in ("groups", "handoff") else 1)
         losses = []
+        if mode == "handoff":
+            # round 3: a launch's LAST optimizer kernel builds the row plan of the record the next launch starts with
+            # (run_group(next_record=...)): the next launch — a group in its plan-less "continuation" flavour, or a single
+            # step whose eager part is the gather alone — must give the same bits; a wrong announcement (a launch that
+            # starts with another record than the one planned for) falls back to the stand-alone plan
+            assert step.cont_slots and len(step._plan_sets) == 3
+            step.run_group([recs[0], recs[1], recs[2]], next_record=recs[3])
+            losses.append(step.loss.clone())
+            step.run_from(recs[3], eager_gather=True)          # starts from the hand-off plan
+            losses.append(step.loss.clone())
+            step.run_group([recs[4], recs[5], recs[6]], next_record=recs[4])
+            losses.append(step.loss.clone())
+            snap7 = {k: npy(v).copy() for k, v in model.state_dict().items()}
+            # continuation flavour twice in a row, then an announcement that is not honoured
+            step.run_group([recs[4], recs[5], recs[6]], next_record=recs[0])
+            step.run_group([recs[0], recs[1], recs[2]], next_record=recs[5])
+            step.run_group([recs[4], recs[5], recs[6]])
+            torch.cuda.synchronize()
         if mode == "groups":
             # three steps per graph launch (run_group), a single eager-gather step in between
             assert step.steps_per_graph == 3
@@ -418,7 +436,11 @@ def test_graph_node_updates_and_eager_gather_variant_are_bitwise_equal_to_eager(
             losses.append(step.loss.clone())
             step.run_group([recs[4], recs[5], recs[6]])
             losses.append(step.loss.clone())
-        for i in range(n if mode != "groups" else 0):
+        if mode == "groups":       # the same extra launches as the hand-off run, every one with its own stand-alone plan
+            snap7 = {k: npy(v).copy() for k, v in model.state_dict().items()}
+            for grp in ([4, 5, 6], [0, 1, 2], [4, 5, 6]):
+                step.run_group([recs[j] for j in grp])
+        for i in range(n if mode not in ("groups", "handoff") else 0):
             if mode == "mixed" and i % 3 == 1:
                 step.run_from(recs[i], eager_gather=True)
             else:
@@ -426,13 +448,17 @@ def test_graph_node_updates_and_eager_gather_variant_are_bitwise_equal_to_eager(
             losses.append(step.loss.clone())
         torch.cuda.synchronize()
         assert torch.equal(step.ids, torch.from_numpy(ids[n - 1]).cuda())      # static inputs: the last batch
-        results.append(({k: npy(v).copy() for k, v in model.state_dict().items()}, [float(l) for l in losses]))
+        results.append(({k: npy(v).copy() for k, v in model.state_dict().items()}, [float(l) for l in losses],
+                        snap7 if mode in ("groups", "handoff") else None))
     ref_losses = results[0][1]
-    for mode, other in zip(("graph", "mixed", "groups"), results[1:]):
-        want = ref_losses if mode != "groups" else [ref_losses[2], ref_losses[3], ref_losses[6]]
+    for mode, other in zip(("graph", "mixed", "groups", "handoff"), results[1:]):
+        want = ref_losses if mode in ("graph", "mixed") else [ref_losses[2], ref_losses[3], ref_losses[6]]
         assert other[1] == want, f"{mode}: losses differ"
+        after7 = other[0] if mode in ("graph", "mixed") else other[2]             # groups / handoff go on for three more launches
         for k in results[0][0]:
-            assert np.array_equal(other[0][k], results[0][0][k]), k
+            assert np.array_equal(after7[k], results[0][0][k]), (mode, k)
+    for k in results[3][0]:                                                        # ... and still agree with each other
+        assert np.array_equal(results[4][0][k], results[3][0][k]), ("handoff vs groups", k)
 
 
 def test_fused_step_rejects_ineligible_models():
