@@ -250,7 +250,10 @@ class FeatureEmbedding(nn.Module):
         _lib.check(lib.dfm_embedding_plan_create(arr, n, self.fm_embed_dim, C.byref(handle)))
         self._plan, self._plan_key = handle, key
         self._plan_uniform = bool(lib.dfm_embedding_plan_is_uniform(handle))
-        self._err = torch.zeros(1, dtype=torch.int32, device=device)
+        # ONE error flag per module and device, not per plan: captured graphs keep its address, and a re-made plan
+        # (restore_tables() -> release_foreign() on a table shard) must go on reporting through the same word
+        if self._err is None or self._err.device != torch.device(device):
+            self._err = torch.zeros(1, dtype=torch.int32, device=device)
         return handle
 
     # ------------------------------------------------------------------ inputs

@@ -106,13 +106,29 @@ class TableShard:
                 w = holder.weight
                 w.data = torch.empty(0, w.shape[1], dtype=w.dtype, device=w.device)
             emb.packed.pop(n, None)
+        emb._drop_plan()                 # a plan made by a plain forward still points at the tables just freed
         self.released = True
+        self._guard_state_dict()
+
+    def _guard_state_dict(self) -> None:
+        """``model.state_dict()`` on a released shard would silently save 0-row tables: make it raise instead."""
+        if getattr(self.model, "_dfm_shard_guard", None) is not None:
+            return
+        shard = self
+
+        def hook(module, prefix, keep_vars):
+            if shard.released:
+                raise RuntimeError("state_dict() of a model whose foreign embedding tables are released: call "
+                                   "shard.restore_tables() first (collective), shard.release_foreign() afterwards")
+        self.model._dfm_shard_guard = self.model.register_state_dict_pre_hook(hook)
 
     @torch.no_grad()
     def restore_tables(self) -> None:
         """Collective: every rank gets every table back from its owner (weights + Adam moments in the
         packed records), e.g. before ``state_dict()`` / evaluation with the plain forward.  The shard
-        keeps working afterwards; ``release_foreign`` frees the copies again."""
+        keeps working afterwards — also a step captured as a graph: its kernels hold the receive buffers, not
+        the restored copies — and ``release_foreign`` frees the copies again
+        (tests/test_gpu_sharded.py::test_restore_state_dict_release_then_continue)."""
         emb = self.model.embedding
         for s, n in enumerate(self.sparse_names):
             spec = emb.schema.fields[n]
@@ -260,6 +276,8 @@ class ShardedStepMixin:
                 views[name] = (self.rows_recv.as_strided((B, D), (c * D, 1), off + j * D),
                                self.rows_recv.as_strided((B, 1), (c, 1), off + B * c * D + j))
             off += B * c * (D + 1)
+        if not shard.released:
+            shard.release_foreign()                       # (drops the embedding's plan: before the row source is bound)
         self.emb.pin_plan(dev, False)
         self.emb.bind_row_source(views)
         self.emb.pin_plan(dev)
@@ -269,8 +287,6 @@ class ShardedStepMixin:
         for t, spec in zip(self.inputs, self.model.schema.fields.values()):
             self.local_inputs.append(self.sample_ids if spec.feature_type is FeatureType.SPARSE else t)
         self.gid_inputs = [self.gids[j] for j in range(nf)]
-        if not shard.released:
-            shard.release_foreign()
 
     # ------------------------------------------------------------------ forward half
     def _stage(self, record: torch.Tensor) -> None:

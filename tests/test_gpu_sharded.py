@@ -134,6 +134,40 @@ def test_sharded_graph_replay_equals_eager_bitwise(spg):
         assert torch.equal(eager[k], graph[k]), k
 
 
+def test_restore_state_dict_release_then_continue():
+    """Checkpointing a sharded job in mid-run (round-2 ADVICE): restore_tables() -> state_dict() (model and optimizer)
+    -> release_foreign() -> more steps of the SAME captured graph must equal the uninterrupted run bit for bit;
+    state_dict() on a released shard raises instead of silently saving 0-row tables; the embedding's error flag keeps
+    its address across the re-made plan."""
+    from deepfm_amd.training.sharded import make_sharded_step
+    B, V, steps = 512, 300, 6
+    results = []
+    for interrupted in (False, True):
+        model = _model("deepfm", V, 16)
+        step, opt, shard = make_sharded_step(model, B, use_graph=True, lr=1e-2, l2=1e-5, max_grad_norm=1.0)
+        step.seed.fill_(1234)
+        ids, dense, labels = _batches(steps, B, V, 7)
+        recs = step.pack_batches(ids, dense, labels)
+        step.capture()
+        err_ptr = shard.emb._err.data_ptr()
+        for i in range(steps):
+            if interrupted and i == 3:
+                with pytest.raises(RuntimeError):
+                    model.state_dict()                        # released: would save empty tables
+                shard.restore_tables()
+                sd, osd = model.state_dict(), opt.state_dict()
+                assert sd["embedding.second_order_embeddings.C26.weight"].shape[0] == V and osd["step"] == 3
+                shard.release_foreign()
+                assert shard.emb._err.data_ptr() == err_ptr
+            step.run_from(recs[i])
+        torch.cuda.synchronize()
+        shard.restore_tables()
+        results.append(_state(model, opt))
+        step.release_graphs()
+    for k in results[0]:
+        assert torch.equal(results[0][k], results[1][k]), k
+
+
 def test_field_shards_partition():
     from deepfm_amd.training.sharded import FieldShards
     sh = FieldShards(26, 8)
