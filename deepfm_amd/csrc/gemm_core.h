@@ -114,6 +114,21 @@ __device__ __forceinline__ void store_slice(float* __restrict__ lds, const float
   }
 }
 
+// One of the four floats of store_slice (J = 0..3): the interleaved form of the pipeline step spreads the eight
+// LDS writes of a slice over the gaps of the MFMA chain.
+template <bool KC, bool MASK, int J>
+__device__ __forceinline__ void store_piece(float* __restrict__ lds, const float4& vin, bool okv) {
+  const int p = threadIdx.x;
+  const float e = J == 0 ? vin.x : (J == 1 ? vin.y : (J == 2 ? vin.z : vin.w));
+  const float v = (!MASK || okv) ? e : 0.f;
+  if (KC) lds[(p >> 3) * LDS_STRIDE + (p & 7) * 4 + J] = v;
+  else lds[((p & 15) * 4 + J) * LDS_STRIDE + (p >> 4)] = v;
+}
+
+#ifndef GEMM_INTERLEAVE
+#define GEMM_INTERLEAVE 1
+#endif
+
 // The whole k loop of one output tile.  On return `acc` is complete in the waves with
 // pos.khalf == 0; every wave has passed the same barriers and `sm` is free for the epilogue.
 //
@@ -154,6 +169,38 @@ __device__ __forceinline__ void pipe_step(const float* __restrict__ A, int64_t l
   constexpr bool kBareA = !CHECK && A_FAST, kBareB = !CHECK && B_FAST;
   if (CHECK && kc >= ke) return;
   float na[kFrag], nb[kFrag];
+  if constexpr (GEMM_INTERLEAVE && !CHECK) {
+    // Steady state, interleaved (round 3): the 8 MFMAs of a slice are one dependent chain — the wave sits at each
+    // of them for its 64-cycle pass — and everything else of the step is independent of it (the NEXT slice's
+    // fragment reads, the slice after's LDS writes, a far slice's global loads).  Issued in front of the chain they
+    // kept the matrix pipe idle for the whole LDS phase, in BOTH waves of a SIMD at once (the per-slice barrier
+    // puts them in lock-step: ~1670 cycles per slice against 1024 of MFMA work); issued in the chain's gaps — two
+    // fragment reads and one LDS write behind every MFMA, the global loads behind the last two — they cost nothing.
+    const float* pa = sm.a[b1] + (pos.wm + pos.r) * LDS_STRIDE + pos.hf + pos.khalf * (BK / 2);
+    const float* pb = sm.b[b1] + (pos.wn + pos.r) * LDS_STRIDE + pos.hf + pos.khalf * (BK / 2);
+    static_assert(kFrag == 8, "the gap schedule below is written for 8 MFMAs per slice");
+#define DFM_GAP(I, STORE)                                                                   \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[I], fb[I], acc, 0, 0, 0);                 \
+    na[I] = pa[2 * (I)]; nb[I] = pb[2 * (I)];                                               \
+    STORE;                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_sched_barrier(0);
+    DFM_GAP(0, (store_piece<A_KC, !kBareA, 0>(sm.a[b2], va[slot], oka[slot])))
+    DFM_GAP(1, (store_piece<A_KC, !kBareA, 1>(sm.a[b2], va[slot], oka[slot])))
+    DFM_GAP(2, (store_piece<A_KC, !kBareA, 2>(sm.a[b2], va[slot], oka[slot])))
+    DFM_GAP(3, (store_piece<A_KC, !kBareA, 3>(sm.a[b2], va[slot], oka[slot])))
+    DFM_GAP(4, (store_piece<B_KC, !kBareB, 0>(sm.b[b2], vb[slot], okb[slot])))
+    DFM_GAP(5, (store_piece<B_KC, !kBareB, 1>(sm.b[b2], vb[slot], okb[slot])))
+    DFM_GAP(6, (store_piece<B_KC, !kBareB, 2>(sm.b[b2], vb[slot], okb[slot])))
+    DFM_GAP(7, (store_piece<B_KC, !kBareB, 3>(sm.b[b2], vb[slot], okb[slot])))
+#undef DFM_GAP
+    // the slot is free now: slice s + 6 on its way
+    if (kBareA) { va[slot] = spa.load(kc + (kPrefetch + 2) * BK); oka[slot] = true; }
+    else load_slice<A_KC, A_FAST>(A, lda, m0, M, kc + (kPrefetch + 2) * BK, ke, va[slot], oka[slot]);
+    if (kBareB) { vb[slot] = spb.load(kc + (kPrefetch + 2) * BK); okb[slot] = true; }
+    else load_slice<B_KC, B_FAST>(B, ldb, n0, N, kc + (kPrefetch + 2) * BK, ke, vb[slot], okb[slot]);
+    __builtin_amdgcn_sched_barrier(0);
+  } else {
 #pragma unroll
   for (int i = 0; i < kFrag; ++i) na[i] = nb[i] = 0.f;
   if (!CHECK || kc + BK < ke) read_frags(sm, b1, pos, na, nb);
@@ -173,6 +220,7 @@ __device__ __forceinline__ void pipe_step(const float* __restrict__ A, int64_t l
 #pragma unroll
   for (int i = 0; i < kFrag; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[i], acc, 0, 0, 0);
   __builtin_amdgcn_sched_barrier(0);
+  }
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < kFrag; ++i) { fa[i] = na[i]; fb[i] = nb[i]; }
