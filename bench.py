@@ -78,6 +78,9 @@ def parse():
                          "the batch record with row-touch workgroups")
     ap.add_argument("--no-plan-lookahead", action="store_true",
                     help="A/B: every step of a multi-step graph builds its own row plan (no dfm_step_apply_plan)")
+    ap.add_argument("--tower-mode", type=int, default=-1, choices=(-1, 0, 1),
+                    help="arithmetic of the DNN tower's BACKWARD GEMMs (dfm_tower_set_mode): 0 exact fp32 matrix pipe, "
+                         "1 bf16 x 3 split on the bf16 pipe; -1 = the package default (training/step.py::TOWER_MODE_DEFAULT)")
     ap.add_argument("--gather-samples", type=int, default=32,
                     help="timed gather dispatches wanted for the roofline: those of the timed region plus single steps "
                          "run after it (outside `value`) until this many are collected")
@@ -368,6 +371,8 @@ def main():
     from deepfm_amd import _lib
     from deepfm_amd.training.step import RowSparseTrainStep
     lib = _lib.load()
+    from deepfm_amd.training import step as step_mod
+    _lib.check(lib.dfm_tower_set_mode(step_mod.TOWER_MODE_DEFAULT if args.tower_mode < 0 else args.tower_mode))
     RowSparseTrainStep.rowplan_first_default = not args.rowplan_inline
     RowSparseTrainStep.plan_lookahead_default = not args.no_plan_lookahead
     _lib.check(lib.dfm_gather_set_shape(args.gather_shape))        # before any capture: the graphs keep the kernel
@@ -611,6 +616,8 @@ def main():
         }
         out["config"]["env_switches"] = switches          # every DFM_* variable seen at run time
         out["config"]["cin_mode"] = lib.dfm_cin_get_mode()
+        out["config"]["tower_mode"] = {0: "exact fp32 MFMA (forward and backward)",
+                                       1: "forward exact fp32 MFMA; backward GEMMs bf16 x 3 split on the bf16 MFMA pipe"}[lib.dfm_tower_get_mode()]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model, fields, cfg, hp, ids[:8], dense[:8], labels[:8],
                                                args.cpu_seconds)

@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("DFM_LIB_PATH") or os.path.join(_HERE, "lib", "libdeep
 # == DFM_ABI_VERSION of include/deepfm_hip.h at the time SIGNATURES / the ctypes structs below were written:
 # bumped together with the header whenever a struct layout or an argument list changes, so that a stale .so
 # (the library is untracked and DFM_LIB_PATH can point anywhere) is refused instead of fed shifted arguments
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 MAX_FIELDS = 64
 MAX_RANKS = 64
@@ -167,6 +167,8 @@ SIGNATURES = {
                                  _L, _I, _P, _L, _P, _I, _L, _P, _P, _P, _P, _P, _P]),
     "dfm_step_apply_plan_update": (_I, [_P, _P, C.POINTER(Table), _I, _I, _I, _P, _P, _P, _P, _P, _P, _F, _F, _F, _F, _P,
                                         _P, _P, _P, _P, _L, _I, _P, _L, _P, _I, _L, _P, _P, _P, _P, _P]),
+    "dfm_tower_set_mode": (_I, [_I]),
+    "dfm_tower_get_mode": (_I, []),
     "dfm_fm_forward": (_I, [_P, _L, _I, _I, _P, _P]),
     "dfm_fm_backward": (_I, [_P, _P, _L, _I, _I, _P, _P]),
     "dfm_copy_2d": (_I, [_P, _L, _P, _L, _L, _I, _P]),

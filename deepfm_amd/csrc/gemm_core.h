@@ -11,6 +11,8 @@
 // fragment reads), double buffered, and consumed from register fragments (see mainloop).
 #pragma once
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace dfm {
@@ -281,6 +283,170 @@ __device__ __forceinline__ void mainloop(const float* __restrict__ A, int64_t ld
   // combine the two k-halves: waves 4-7 park their tile in LDS (the staging buffers are free after
   // the loop's last barrier), waves 0-3 add it (fixed order: half 0 + half 1)
   float* park = &sm.a[0][0];                   // 4 tiles x 16 regs x 64 lanes = 16 KiB <= sizeof(sm.a)
+  if (pos.khalf == 1) {
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) park[(pos.tile * 16 + reg) * 64 + lane] = acc[reg];
+  }
+  __syncthreads();
+  if (pos.khalf == 0) {
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) acc[reg] += park[(pos.tile * 16 + reg) * 64 + lane];
+  }
+  __syncthreads();
+}
+
+// =====================================================================================
+// The same 64 x 64 tile product on the bf16 matrix pipe, bf16 x 3 split (round 3; the tower's BACKWARD only):
+//   a = ah + al, b = bh + bl (bf16 each, 2^-17 relative),  a b ~ ah bh + ah bl + al bh,  fp32 accumulate
+// — the CIN's arithmetic.  v_mfma_f32_32x32x16_bf16 runs at 16x the fp32 MFMA rate, the split issues 3x: the
+// matrix-pipe time of a tile falls 5.3x.  Why only the backward: its inputs (d z, activations, weights) are
+// fixed by the exact-fp32 forward, so the ReLU / dropout masks are fp32's; bf16 x 3 in the FORWARD moves every
+// pre-activation by ~1e-5 and flips ~27 ReLUs per step at B = 4096, which breaks the parity bar on most of the
+// first layer's gradient elements (tools/emulate_tower_bf16x3.py: forward + backward 70-97 % outside, backward
+// only 0 % outside, max 1.1e-5 of scale against fp32's 1.2e-5).
+//
+// Accumulator layout, tile decomposition (4 tiles x 2 k-halves) and the k-half combine are the fp32 loop's, so
+// every epilogue is shared.  64-deep slices: a k-half takes two 16-deep k-steps per slice (6 MFMAs per wave),
+// operands are split to bf16 hi / lo on their way into LDS, fragment-shaped:
+//   plane[ks (4)][h (2)][row (64)][8 bf16]   (lane (row r, half h) of k-step ks reads 16 contiguous bytes)
+// K-contiguous operands: a thread converts 8 consecutive k of one row -> one ds_write_b128 per plane;
+// K-strided ones: a thread loads two consecutive k for 4 rows and writes 4 packed (k, k+1) pairs per plane.
+// FAST operands only (16-byte pieces all-or-nothing); the k tail reads as zero, rows are clamped.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+constexpr int BKX = 64;
+constexpr int kPlane = 4 * 2 * 64 * 8;          // bf16 elements of one plane (hi or lo) of one operand: 8 KB
+struct SmemX3 {
+  __bf16 a[2][2][kPlane];                       // [buffer][hi, lo]
+  __bf16 b[2][2][kPlane];
+};
+static_assert(sizeof(SmemX3) == 64 * 1024, "two operands x two buffers x (hi, lo) x 8 KB");
+
+// this thread's two 16-byte pieces of a 64 x 64 operand slice
+template <bool KC>
+struct PieceX3 {
+  const float* ptr;       // this thread's piece 0 at absolute k = 0 (row(s) clamped)
+  int64_t kstep;          // elements per unit of k
+  int k_off;              // k of piece 0 inside a slice (piece 1: KC: + 4, strided: + 1)
+  int lds0;               // KC: element offset of the 8 bf16 this thread writes; strided: of its first packed pair
+  __device__ __forceinline__ PieceX3(const float* base, int64_t ld, int r0, int rows) {
+    const int p = threadIdx.x;
+    if (KC) {             // row p >> 3, k = 8 (p & 7) .. + 7
+      const int r = r0 + (p >> 3), k8 = p & 7;
+      const int rc = r < rows ? r : rows - 1;
+      ptr = base + static_cast<int64_t>(rc) * ld;
+      kstep = 1; k_off = 8 * k8;
+      lds0 = (((k8 >> 1) * 2 + (k8 & 1)) * 64 + (p >> 3)) * 8;
+    } else {              // k pair 2 (p >> 4), 2 (p >> 4) + 1; rows 4 (p & 15) .. + 3
+      const int kq = p >> 4, r = r0 + (p & 15) * 4;
+      const int rc = r < rows ? r : rows - 4;
+      ptr = base + rc;
+      kstep = ld; k_off = 2 * kq;
+      const int k = 2 * kq;                       // k-step k >> 4, half (k >> 3) & 1, element k & 7 (even)
+      lds0 = ((((k >> 4) * 2 + ((k >> 3) & 1)) * 64 + (p & 15) * 4) * 8) + (k & 7);
+    }
+  }
+  // the slice that starts at absolute k0; pieces at k >= ke read k = 0 (always inside the operand) and are zeroed
+  __device__ __forceinline__ void load(int k0, int ke, float4& v0, float4& v1, bool& ok0, bool& ok1) const {
+    const int ka = k0 + k_off, kb = ka + (KC ? 4 : 1);
+    ok0 = ka < ke; ok1 = kb < ke;
+    v0 = ld4(ptr + static_cast<int64_t>(ok0 ? ka : 0) * kstep);
+    v1 = ld4(ptr + static_cast<int64_t>(ok1 ? kb : 0) * kstep);
+  }
+};
+
+__device__ __forceinline__ void split2(float v, __bf16& hi, __bf16& lo) {
+  hi = static_cast<__bf16>(v);
+  lo = static_cast<__bf16>(v - static_cast<float>(hi));
+}
+
+template <bool KC>
+__device__ __forceinline__ void store_x3(__bf16* __restrict__ hi, __bf16* __restrict__ lo, const PieceX3<KC>& pc,
+                                         const float4& a0, const float4& a1, bool ok0, bool ok1) {
+  const float z = 0.f;
+  const float v[8] = {ok0 ? a0.x : z, ok0 ? a0.y : z, ok0 ? a0.z : z, ok0 ? a0.w : z,
+                      ok1 ? a1.x : z, ok1 ? a1.y : z, ok1 ? a1.z : z, ok1 ? a1.w : z};
+  if (KC) {
+    bf16x8 h, l;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { __bf16 hh, ll; split2(v[j], hh, ll); h[j] = hh; l[j] = ll; }
+    *reinterpret_cast<bf16x8*>(hi + pc.lds0) = h;
+    *reinterpret_cast<bf16x8*>(lo + pc.lds0) = l;
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {              // row r: (k, k + 1) = (v[r], v[4 + r])
+      bf16x2 h, l;
+      __bf16 hh, ll;
+      split2(v[r], hh, ll); h[0] = hh; l[0] = ll;
+      split2(v[4 + r], hh, ll); h[1] = hh; l[1] = ll;
+      *reinterpret_cast<bf16x2*>(hi + pc.lds0 + r * 8) = h;
+      *reinterpret_cast<bf16x2*>(lo + pc.lds0 + r * 8) = l;
+    }
+  }
+}
+
+template <bool A_KC, bool B_KC>
+__device__ __forceinline__ void mainloop_x3(const float* __restrict__ A, int64_t lda, const float* __restrict__ B,
+                                            int64_t ldb, int M, int N, int m0, int n0, int kb, int ke, SmemX3& sm,
+                                            const TilePos& pos, f32x16& acc) {
+  const int lane = lane_id();
+  const PieceX3<A_KC> pa(A, lda, m0, M);
+  const PieceX3<B_KC> pb(B, ldb, n0, N);
+  const int nsl = (ke - kb + BKX - 1) / BKX;
+  // two register sets of prefetched slices, alternating: step s converts slice s + 1 (requested two steps ago)
+  // into the other LDS buffer (its readers left it at the last barrier) and requests slice s + 3 into the registers
+  // that just emptied
+  // (compile-time set / buffer numbers — the loop is unrolled by two: a run-time index would put the sets in scratch)
+  struct Set { float4 a0, a1, b0, b1; bool oa0, oa1, ob0, ob1; };
+  Set st0, st1;
+  auto request = [&](int sl, Set& t) {
+    pa.load(kb + sl * BKX, ke, t.a0, t.a1, t.oa0, t.oa1);
+    pb.load(kb + sl * BKX, ke, t.b0, t.b1, t.ob0, t.ob1);
+  };
+  auto convert = [&](int buf, const Set& t) {
+    store_x3<A_KC>(sm.a[buf][0], sm.a[buf][1], pa, t.a0, t.a1, t.oa0, t.oa1);
+    store_x3<B_KC>(sm.b[buf][0], sm.b[buf][1], pb, t.b0, t.b1, t.ob0, t.ob1);
+  };
+  st1 = Set{};
+  request(0, st0);
+  if (nsl > 1) request(1, st1);
+  convert(0, st0);
+  if (nsl > 2) request(2, st0);
+  __syncthreads();
+  // this wave's fragments: k-steps 2 khalf and 2 khalf + 1 of the slice, rows wm + r (A) / wn + r (B), half hf
+  const int fa = (((2 * pos.khalf) * 2 + pos.hf) * 64 + pos.wm + pos.r) * 8;
+  const int fb = (((2 * pos.khalf) * 2 + pos.hf) * 64 + pos.wn + pos.r) * 8;
+  constexpr int kStepElems = 2 * 64 * 8;        // one k-step further
+  // step s (parity P = s & 1): multiply LDS buffer P; the OTHER register set holds slice s + 1 -> buffer P ^ 1, then
+  // takes slice s + 3
+  auto step = [&](int s, auto parity, Set& other) {
+    constexpr int P = decltype(parity)::value;
+    bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      ah[q] = *reinterpret_cast<const bf16x8*>(sm.a[P][0] + fa + q * kStepElems);
+      al[q] = *reinterpret_cast<const bf16x8*>(sm.a[P][1] + fa + q * kStepElems);
+      bh[q] = *reinterpret_cast<const bf16x8*>(sm.b[P][0] + fb + q * kStepElems);
+      bl[q] = *reinterpret_cast<const bf16x8*>(sm.b[P][1] + fb + q * kStepElems);
+    }
+    if (s + 1 < nsl) convert(P ^ 1, other);
+    if (s + 3 < nsl) request(s + 3, other);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[q], bh[q], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[q], bl[q], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[q], bh[q], acc, 0, 0, 0);
+    }
+    __syncthreads();
+  };
+  int s = 0;
+  for (; s + 1 < nsl; s += 2) {
+    step(s, std::integral_constant<int, 0>{}, st1);
+    step(s + 1, std::integral_constant<int, 1>{}, st0);
+  }
+  if (s < nsl) step(s, std::integral_constant<int, 0>{}, st1);
+  // combine the two k-halves as the fp32 loop does (fixed order: half 0 + half 1)
+  float* park = reinterpret_cast<float*>(&sm.a[0][0][0]);      // 16 KiB
   if (pos.khalf == 1) {
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) park[(pos.tile * 16 + reg) * 64 + lane] = acc[reg];

@@ -519,12 +519,14 @@ struct FmBwd {
   int dim;
 };
 
-template <bool FAST, int EPI>   // EPI 0: plain store, 1: BatchNorm mask of the lower layer, 2: + FM backward
+// X3: both products on the bf16 matrix pipe with the bf16 x 3 split (gemm_core.h::mainloop_x3; FAST operands only) —
+// selected by dfm_tower_set_mode(1), never implicitly.
+template <bool FAST, int EPI, bool X3 = false>   // EPI 0: plain store, 1: BatchNorm mask of the lower layer, 2: + FM backward
 __global__ __launch_bounds__(kThreads) void linear_bwd_kernel(
     const float* __restrict__ dz, const float* __restrict__ x, const float* __restrict__ w,
     float* __restrict__ g_x, int M, int N, int K, int dw_tiles_n, int dw_tiles, int splits,
     int dw_blocks, int k_per_split, float* __restrict__ slabs, int dx_tiles_n, BnBwd bn, FmBwd fmb) {
-  __shared__ Smem sm;
+  __shared__ typename std::conditional<X3, SmemX3, Smem>::type sm;
   const TilePos pos;
   f32x16 acc = {};
   const int wg = blockIdx.x;
@@ -536,7 +538,8 @@ __global__ __launch_bounds__(kThreads) void linear_bwd_kernel(
     const int m0 = (tile / dw_tiles_n) * BM, n0 = (tile % dw_tiles_n) * BN;
     const int kb = sp * k_per_split;
     const int ke = kb + k_per_split < M ? kb + k_per_split : M;
-    mainloop<false, false, FAST, FAST>(dz, N, x, K, N, K, m0, n0, kb, ke, sm, pos, acc);
+    if constexpr (X3) mainloop_x3<false, false>(dz, N, x, K, N, K, m0, n0, kb, ke, sm, pos, acc);
+    else mainloop<false, false, FAST, FAST>(dz, N, x, K, N, K, m0, n0, kb, ke, sm, pos, acc);
     const int n = n0 + pos.col();
     if (pos.khalf == 0 && n < K) {
       float* sl = slabs + static_cast<int64_t>(sp) * N * K;      // summed by slab_reduce_kernel
@@ -551,7 +554,8 @@ __global__ __launch_bounds__(kThreads) void linear_bwd_kernel(
   // ---- dx (M x K) = dz W: A = dz (k-contiguous), B = W (k-strided) ----
   const int t = bid - dw_blocks;
   const int m0 = (t / dx_tiles_n) * BM, n0 = (t % dx_tiles_n) * BN;
-  mainloop<true, false, FAST, FAST>(dz, N, w, K, M, K, m0, n0, 0, N, sm, pos, acc);
+  if constexpr (X3) mainloop_x3<true, false>(dz, N, w, K, M, K, m0, n0, 0, N, sm, pos, acc);
+  else mainloop<true, false, FAST, FAST>(dz, N, w, K, M, K, m0, n0, 0, N, sm, pos, acc);
   if (pos.khalf == 1) return;
   if (EPI == 1) {
     bn_mask_tile(bn, acc, pos, m0, n0, M, K);
@@ -901,6 +905,17 @@ void dw_split_plan(int n_out, int k_in, int m, int* splits, int* k_per_split) {
 }
 }  // namespace
 
+// Arithmetic of the tower's BACKWARD GEMMs (dfm_linear_backward): 0 = exact fp32 matrix pipe (default),
+// 1 = bf16 x 3 split on the bf16 pipe (gemm_core.h::mainloop_x3).  The forward always runs exact fp32.  An explicit
+// API call, recorded by bench.py (config.tower_mode) — nothing outside the caller's code changes what a run computes.
+static int g_tower_mode = 0;
+extern "C" int dfm_tower_set_mode(int mode) {
+  DFM_REQUIRE(mode == 0 || mode == 1, "tower mode %d outside [0, 1]", mode);
+  g_tower_mode = mode;
+  return DFM_OK;
+}
+extern "C" int dfm_tower_get_mode(void) { return g_tower_mode; }
+
 extern "C" int dfm_linear_backward_splits(int64_t batch, int out_features, int in_features) {
   int splits, kps;
   dw_split_plan(out_features, in_features, static_cast<int>(batch), &splits, &kps);
@@ -944,7 +959,15 @@ extern "C" int dfm_linear_backward(const float* d_dz, int64_t batch, int out_fea
   hipLaunchKernelGGL((linear_bwd_kernel<F, E>), grid, dim3(kThreads), 0, as_stream(stream), d_dz, d_x, d_w,        \
                      d_g_x, M, N, K, dw_tn, dw_t, splits, dw_blocks, k_per_split, slabs, dx_tn, dbn, dfm_)
   const int epi = bn_below ? 1 : (fm ? 2 : 0);
-  if (fast) {
+  // bf16 x 3 backward (dfm_tower_set_mode(1)): 16-byte-regular operands, an out_features extent the 8-wide k groups
+  // of the d-input product divide, and batch splits that start on even rows (the strided pieces pair k, k + 1)
+  if (g_tower_mode == 1 && fast && N % 8 == 0 && M % 2 == 0 && k_per_split % 2 == 0) {
+#define DFM_LBWD3(E)                                                                                              \
+  hipLaunchKernelGGL((linear_bwd_kernel<true, E, true>), grid, dim3(kThreads), 0, as_stream(stream), d_dz, d_x,    \
+                     d_w, d_g_x, M, N, K, dw_tn, dw_t, splits, dw_blocks, k_per_split, slabs, dx_tn, dbn, dfm_)
+    if (epi == 0) DFM_LBWD3(0); else if (epi == 1) DFM_LBWD3(1); else DFM_LBWD3(2);
+#undef DFM_LBWD3
+  } else if (fast) {
     if (epi == 0) DFM_LBWD(true, 0); else if (epi == 1) DFM_LBWD(true, 1); else DFM_LBWD(true, 2);
   } else {
     if (epi == 0) DFM_LBWD(false, 0); else if (epi == 1) DFM_LBWD(false, 1); else DFM_LBWD(false, 2);

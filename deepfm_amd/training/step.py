@@ -43,6 +43,10 @@ from deepfm_amd.training.losses import bce_with_logits_mean
 from deepfm_amd.training.rowsparse import RowSparseAdam
 
 
+# Arithmetic of the tower's backward GEMMs that bench.py / the tools select by default (dfm_tower_set_mode): the library
+# itself starts in mode 0 and only changes on an explicit call.
+TOWER_MODE_DEFAULT = 0
+
 # Every live step, so that one call drops all captured graphs: graphs that hold captured RCCL kernels must be
 # destroyed BEFORE the communicator (``destroy_process_group()`` under live graphs does not return — found on
 # the one-GPU RCCL run).  Also registered with atexit, for processes that end on an exception.

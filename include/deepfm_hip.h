@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DFM_ABI_VERSION 5   /* bump whenever a struct layout or a signature in this header changes */
+#define DFM_ABI_VERSION 6   /* bump whenever a struct layout or a signature in this header changes */
 #define DFM_MAX_FIELDS 64      /* per-call pointer tables travel as kernel arguments */
 #define DFM_MAX_RANKS 64       /* data-parallel ranks of one job (csrc/shard.hip) */
 #define DFM_ROWPLAN_CHUNK 4096 /* ids per sorted list (one LDS-resident sort) */
@@ -563,6 +563,13 @@ typedef struct dfm_slab_ref {
 } dfm_slab_ref;
 int dfm_linear_backward_finish(const dfm_slab_ref* refs, int count, dfm_stream_t stream);
 /* Number of batch splits (slabs) dfm_linear_backward leaves in its workspace for this shape. */
+/* Arithmetic of dfm_linear_backward's two GEMMs (the DNN tower's backward, dnn.py:45-59 under autograd): 0 = exact
+ * fp32 matrix pipe (default), 1 = bf16 x 3 split on the bf16 pipe (fp32 accumulate, 2^-16 per product) — the
+ * forward (dfm_linear_bn_forward, dfm_gemm_f32) always runs exact fp32, so ReLU / dropout masks never change.
+ * Process-wide, explicit; applies to calls enqueued afterwards (a captured graph keeps what it captured). */
+int dfm_tower_set_mode(int mode);
+int dfm_tower_get_mode(void);
+
 int dfm_linear_backward_splits(int64_t batch, int out_features, int in_features);
 
 /* ---------------------------------------------------------------------------------

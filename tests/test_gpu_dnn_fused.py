@@ -226,3 +226,39 @@ def test_gemm_f32_all_layouts(shape):
     c = torch.ones(M, N, device="cuda")
     _gemm(at, M, False, bt, N, False, c, M, N, K, accumulate=True)
     assert_close(npy(c), npy(want + 1.0), rtol=1e-5, atol_scale=2e-6, what="accumulate")
+
+
+@pytest.mark.parametrize("B,N,K,epi", [(4096, 256, 624, "fm"), (4096, 128, 256, "plain"), (4096, 64, 128, "plain"),
+                                       (4096, 256, 2496, "plain"), (778, 64, 40, "plain"), (130, 32, 24, "plain")])
+def test_linear_backward_bf16x3_vs_fp64(B, N, K, epi):
+    """dfm_tower_set_mode(1): d W = d z^T x and d x = d z W of the tower's backward on the bf16 pipe with the bf16 x 3
+    split (gemm_core.h::mainloop_x3) — at the tower's own shapes (configs 2 and 4), a ragged batch and a ragged k tail —
+    against float64, held to the SAME bar as the exact-fp32 kernel (1e-4 relative + 1e-5 of the scale), which is run
+    beside it on the same inputs."""
+    import ctypes as C
+    from deepfm_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(B + N + K)
+    dz = torch.from_numpy(rng.standard_normal((B, N)).astype(np.float32) * 1e-3).cuda()
+    x = torch.from_numpy(rng.standard_normal((B, K)).astype(np.float32)).cuda()
+    w = torch.from_numpy((rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)).cuda()
+    want_dw = (dz.double().T @ x.double()).cpu().numpy()
+    want_dx = (dz.double() @ w.double()).cpu().numpy()
+    ws = torch.zeros(max(lib.dfm_linear_backward_workspace_bytes(B, N, K) // 4, 1), dtype=torch.float32, device="cuda")
+    old = lib.dfm_tower_get_mode()
+    try:
+        for mode in (0, 1):
+            _lib.check(lib.dfm_tower_set_mode(mode))
+            g_w = torch.zeros(N, K, device="cuda")
+            g_x = torch.empty(B, K, device="cuda")
+            ref = (_lib.SlabRef * 1)()
+            ref[0].workspace, ref[0].g_w = ws.data_ptr(), g_w.data_ptr()
+            ref[0].batch, ref[0].out_features, ref[0].in_features = B, N, K
+            _lib.check(lib.dfm_linear_backward(dz.data_ptr(), B, N, x.data_ptr(), K, w.data_ptr(), g_x.data_ptr(), None,
+                                               None, 3, ws.data_ptr(), _lib.stream_handle()))
+            _lib.check(lib.dfm_linear_backward_finish(ref, 1, _lib.stream_handle()))
+            torch.cuda.synchronize()
+            assert_close(npy(g_w), want_dw, what=f"dW mode {mode}")
+            assert_close(npy(g_x), want_dx, what=f"dx mode {mode}")
+    finally:
+        _lib.check(lib.dfm_tower_set_mode(old))

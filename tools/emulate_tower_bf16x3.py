@@ -32,6 +32,9 @@ def mm(a, b, mode):
 
 
 def tower(x, Ws, gs, bs, w_head, y, mode):
+    bwd_mode = mode
+    if mode == "x3bwd":            # exact-fp32 forward (the ReLU masks are fp32's), bf16 x 3 in the backward GEMMs only
+        mode, bwd_mode = "f32", "x3"
     dt = np.float64 if mode == "f64" else np.float32
     h, cache = x.astype(dt), []
     for W, g, b in zip(Ws, gs, bs):
@@ -44,16 +47,16 @@ def tower(x, Ws, gs, bs, w_head, y, mode):
         h = a.astype(dt)
     logit = mm(h, w_head.T, mode).astype(dt)[:, 0]
     d = ((1 / (1 + np.exp(-logit)) - y) / len(y)).astype(dt)[:, None]
-    grads = {"head": mm(d.T, h, mode)}
-    gh = mm(d, w_head, mode).astype(dt)
+    grads = {"head": mm(d.T, h, bwd_mode)}
+    gh = mm(d, w_head, bwd_mode).astype(dt)
     for i in reversed(range(len(Ws))):
         hin, zh, rstd, a = cache[i]
         ga = gh * (a > 0)
         grads[f"gamma{i}"], grads[f"beta{i}"] = (ga * zh).sum(0), ga.sum(0)
         gz = ga * gs[i]
         gz = rstd * (gz - gz.mean(0) - zh * (gz * zh).mean(0))
-        grads[f"W{i}"] = mm(gz.T, hin, mode)
-        gh = mm(gz, Ws[i], mode).astype(dt)
+        grads[f"W{i}"] = mm(gz.T, hin, bwd_mode)
+        gh = mm(gz, Ws[i], bwd_mode).astype(dt)
     grads["x"] = gh
     return logit, grads
 
@@ -78,13 +81,13 @@ def main(kink_free=False):
     y = (rng.random(B) < 0.25).astype(np.float32)
     ref_l, ref_g = tower(x, Ws, gs, bs, w_head, y, "f64")
     print(f"--- {'kink-free tower (BatchNorm biases +-6)' if kink_free else 'natural tower (BatchNorm biases 0)'}")
-    print(f"{'tensor':10s} {'fp32: share outside / max err':>32s} {'bf16x3: share outside / max err':>34s}")
-    res = {m: tower(x, Ws, gs, bs, w_head, y, m) for m in ("f32", "x3")}
+    print(f"{'tensor':10s} {'fp32: share outside / max err':>32s} {'bf16x3: share outside / max err':>34s} {'bf16x3 backward only':>26s}")
+    res = {m: tower(x, Ws, gs, bs, w_head, y, m) for m in ("f32", "x3", "x3bwd")}
     rows = [("logits", lambda r: r[0])] + [(k, (lambda k: lambda r: r[1][k])(k)) for k in ref_g]
     for name, get in rows:
         ref = ref_l if name == "logits" else ref_g[name]
-        a, b = outside(get(res["f32"]), ref), outside(get(res["x3"]), ref)
-        print(f"{name:10s} {a[0]:>20.2e} / {a[1]:.1e} {b[0]:>22.2e} / {b[1]:.1e}")
+        a, b, c = outside(get(res["f32"]), ref), outside(get(res["x3"]), ref), outside(get(res["x3bwd"]), ref)
+        print(f"{name:10s} {a[0]:>20.2e} / {a[1]:.1e} {b[0]:>22.2e} / {b[1]:.1e} {c[0]:>16.2e} / {c[1]:.1e}")
 
 
 if __name__ == "__main__":
