@@ -78,9 +78,10 @@ def parse():
                          "the batch record with row-touch workgroups")
     ap.add_argument("--no-plan-lookahead", action="store_true",
                     help="A/B: every step of a multi-step graph builds its own row plan (no dfm_step_apply_plan)")
-    ap.add_argument("--tower-mode", type=int, default=-1, choices=(-1, 0, 1),
-                    help="arithmetic of the DNN tower's BACKWARD GEMMs (dfm_tower_set_mode): 0 exact fp32 matrix pipe, "
-                         "1 bf16 x 3 split on the bf16 pipe; -1 = the package default (training/step.py::TOWER_MODE_DEFAULT)")
+    ap.add_argument("--tower-mode", type=int, default=-1, choices=(-1, 0, 1, 2),
+                    help="arithmetic of the DNN tower's GEMMs (dfm_tower_set_mode): 0 exact fp32 matrix pipe, 1 fp32 forward + "
+                         "bf16 x 3 backward, 2 bf16 x 6 (fp32-faithful) forward and backward; -1 = the package default "
+                         "(training/step.py::TOWER_MODE_DEFAULT)")
     ap.add_argument("--gather-samples", type=int, default=32,
                     help="timed gather dispatches wanted for the roofline: those of the timed region plus single steps "
                          "run after it (outside `value`) until this many are collected")
@@ -617,7 +618,12 @@ def main():
         out["config"]["env_switches"] = switches          # every DFM_* variable seen at run time
         out["config"]["cin_mode"] = lib.dfm_cin_get_mode()
         out["config"]["tower_mode"] = {0: "exact fp32 MFMA (forward and backward)",
-                                       1: "forward exact fp32 MFMA; backward GEMMs bf16 x 3 split on the bf16 MFMA pipe"}[lib.dfm_tower_get_mode()]
+                                       1: "forward exact fp32 MFMA; backward GEMMs bf16 x 3 split on the bf16 MFMA pipe",
+                                       2: "bf16 x 6 on the bf16 MFMA pipe, forward and backward: every fp32 operand split "
+                                          "exactly into three bf16 values, six partial products, fp32 accumulate "
+                                          "(2^-23 per product: fp32-faithful)"}[lib.dfm_tower_get_mode()]
+        out["config"]["tower_mode_id"] = int(lib.dfm_tower_get_mode())
+        out["config"]["tower_planes"] = bool(getattr(step, "x6", False))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model, fields, cfg, hp, ids[:8], dense[:8], labels[:8],
                                                args.cpu_seconds)

@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("DFM_LIB_PATH") or os.path.join(_HERE, "lib", "libdeep
 # == DFM_ABI_VERSION of include/deepfm_hip.h at the time SIGNATURES / the ctypes structs below were written:
 # bumped together with the header whenever a struct layout or an argument list changes, so that a stale .so
 # (the library is untracked and DFM_LIB_PATH can point anywhere) is refused instead of fed shifted arguments
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 MAX_FIELDS = 64
 MAX_RANKS = 64
@@ -69,6 +69,12 @@ class SlabRef(C.Structure):
     """struct dfm_slab_ref"""
     _fields_ = [("workspace", C.c_void_p), ("g_w", C.c_void_p), ("batch", C.c_int64), ("out_features", C.c_int32),
                 ("in_features", C.c_int32), ("splits", C.c_int32), ("reserved", C.c_int32)]
+
+
+class SplitJob(C.Structure):
+    """struct dfm_split_job"""
+    _fields_ = [("src", C.c_void_p), ("rows", C.c_int64), ("cols", C.c_int64), ("planes_f", C.c_void_p),
+                ("planes_s", C.c_void_p)]
 
 
 class HeadTail(C.Structure):
@@ -169,6 +175,16 @@ SIGNATURES = {
                                         _P, _P, _P, _P, _L, _I, _P, _L, _P, _I, _L, _P, _P, _P, _P, _P]),
     "dfm_tower_set_mode": (_I, [_I]),
     "dfm_tower_get_mode": (_I, []),
+    "dfm_planes_bytes": (_SZ, [_L, _L]),
+    "dfm_tower_x6_supported": (_I, [_L, _I, _I]),
+    "dfm_split_planes": (_I, [C.POINTER(SplitJob), _I, _P]),
+    "dfm_linear_bn_forward_x6": (_I, [_P, _L, _P, _P, _P, _L, _I, _I, _P, _P, _P]),
+    "dfm_bn_relu_dropout_apply_planes": (_I, [_P, _L, _I, _P, _P, _P, _P, _P, _P, _P, _F, _F, _F, _P, _I, _P, _P, _P,
+                                              _P]),
+    "dfm_bn_backward_apply_planes": (_I, [C.POINTER(BnBwd), _L, _I, C.POINTER(HeadTail), _P, _P, _P, _P]),
+    "dfm_linear_backward_x6_splits": (_I, [_L, _I, _I]),
+    "dfm_linear_backward_x6_workspace_bytes": (_SZ, [_L, _I, _I]),
+    "dfm_linear_backward_x6": (_I, [_P, _P, _L, _I, _P, _P, _I, _P, _P, C.POINTER(BnBwd), C.POINTER(FmBwd), _P, _P]),
     "dfm_fm_forward": (_I, [_P, _L, _I, _I, _P, _P]),
     "dfm_fm_backward": (_I, [_P, _P, _L, _I, _I, _P, _P]),
     "dfm_copy_2d": (_I, [_P, _L, _P, _L, _L, _I, _P]),

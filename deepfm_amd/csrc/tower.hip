@@ -34,6 +34,7 @@
 // are bitwise reproducible run to run.
 #include "dropout.h"
 #include "gemm_core.h"
+#include "gemm_x6.h"
 
 using namespace dfm;
 using namespace dfm::gemm;
@@ -150,20 +151,10 @@ __device__ __forceinline__ void update_running_stats(float* __restrict__ running
 
 }  // namespace
 
-// =====================================================================================
-// forward: z = x W^T + b, per-tile column statistics.  grid tiles_m * tiles_n (n fastest)
-// =====================================================================================
-template <bool FAST>
-__global__ __launch_bounds__(kThreads) void linear_bn_fwd_kernel(
-    const float* __restrict__ x, int64_t ldx, const float* __restrict__ w, const float* __restrict__ bias,
-    float* __restrict__ z, int M, int N, int K, int tiles_n, float* __restrict__ partial) {
-  __shared__ Smem sm;
-  const TilePos pos;
-  const int lt = xcd_logical_index(blockIdx.x, gridDim.x);
-  const int m0 = (lt / tiles_n) * BM, n0 = (lt % tiles_n) * BN;
-  f32x16 acc = {};
-  mainloop<true, true, FAST, FAST>(x, ldx, w, K, M, N, m0, n0, 0, K, sm, pos, acc);
-  if (pos.khalf == 1) return;
+// Epilogue of the forward tile (writer waves): z = acc + bias, per-tile column statistics (tile mean, M2).
+__device__ __forceinline__ void fwd_tile_epilogue(const f32x16& acc, const TilePos& pos, int m0, int n0, int M, int N,
+                                                  const float* __restrict__ bias, float* __restrict__ z,
+                                                  float* __restrict__ partial) {
   const int n = n0 + pos.col();
   const bool okn = n < N;
   const float bv = (bias && okn) ? bias[n] : 0.f;
@@ -196,15 +187,36 @@ __global__ __launch_bounds__(kThreads) void linear_bn_fwd_kernel(
   }
 }
 
+// =====================================================================================
+// forward: z = x W^T + b, per-tile column statistics.  grid tiles_m * tiles_n (n fastest)
+// =====================================================================================
+template <bool FAST>
+__global__ __launch_bounds__(kThreads) void linear_bn_fwd_kernel(
+    const float* __restrict__ x, int64_t ldx, const float* __restrict__ w, const float* __restrict__ bias,
+    float* __restrict__ z, int M, int N, int K, int tiles_n, float* __restrict__ partial) {
+  __shared__ Smem sm;
+  const TilePos pos;
+  const int lt = xcd_logical_index(blockIdx.x, gridDim.x);
+  const int m0 = (lt / tiles_n) * BM, n0 = (lt % tiles_n) * BN;
+  f32x16 acc = {};
+  mainloop<true, true, FAST, FAST>(x, ldx, w, K, M, N, m0, n0, 0, K, sm, pos, acc);
+  if (pos.khalf == 1) return;
+  fwd_tile_epilogue(acc, pos, m0, n0, M, N, bias, z, partial);
+}
+
 // a = dropout(relu(gamma * (z - mean) * rstd + beta)) for 64 columns x 32 rows per workgroup, after
 // merging the (count, mean, M2) of the column's 32-row tiles (Chan's formula about tile 0's mean, so
 // nothing cancels).  grid (column tiles, row groups); row group 0 also publishes the statistics.
+// PLANES (dfm_tower_set_mode(2)): the workgroup also leaves its 32 x 64 tile of `a` as bf16 x 3 planes in both roles
+// (gemm_x6.h) for the GEMMs that consume it; `out` may then be null.  M % 32 == 0 on that path.
+template <bool PLANES>
 __global__ __launch_bounds__(kApThreads) void bn_relu_dropout_apply_kernel(
     const float* __restrict__ z, int M, int N, const float* __restrict__ partial, const float* __restrict__ gamma,
     const float* __restrict__ beta, float* __restrict__ mean_rstd, float* __restrict__ running_mean,
     float* __restrict__ running_var, int64_t* __restrict__ num_batches, float momentum, float eps, uint32_t thresh,
-    float inv_keep, const int64_t* __restrict__ seed_ptr, int salt, float* __restrict__ out) {
+    float inv_keep, const int64_t* __restrict__ seed_ptr, int salt, float* __restrict__ out, Planes pf, Planes ps) {
   __shared__ float red[2][kApRowLanes][kApCols];
+  __shared__ __attribute__((aligned(16))) float tile[PLANES ? kTileRows * kTileStride : 4];
   const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
   const int c = blockIdx.x * kApCols + cl * 4;
   const bool okc = c < N;                       // N % 4 == 0: a float4 is all in or all out
@@ -231,24 +243,31 @@ __global__ __launch_bounds__(kApThreads) void bn_relu_dropout_apply_kernel(
     if (running_mean) update_running_stats(running_mean, running_var, c, mu, var, M, momentum);
     if (blockIdx.x == 0 && cl == 0 && num_batches) num_batches[0] += 1;
   }
-  if (!okc) return;
-  const int64_t seed = seed_ptr ? seed_ptr[0] : 0;
-  const float4 ga = ld4(gamma + c), be = ld4(beta + c);
-  const float gav[4] = {ga.x, ga.y, ga.z, ga.w}, bev[4] = {be.x, be.y, be.z, be.w};
+  if (!PLANES && !okc) return;
   const int r0 = blockIdx.y * kApRows;
+  if (okc) {
+    const int64_t seed = seed_ptr ? seed_ptr[0] : 0;
+    const float4 ga = ld4(gamma + c), be = ld4(beta + c);
+    const float gav[4] = {ga.x, ga.y, ga.z, ga.w}, bev[4] = {be.x, be.y, be.z, be.w};
 #pragma unroll
-  for (int i = 0; i < kApRows / kApRowLanes; ++i) {
-    const int m = r0 + rl + i * kApRowLanes;
-    if (m < M) {
-      const int64_t idx = static_cast<int64_t>(m) * N + c;
-      const float4 zv = ld4(z + idx);
-      const float zz[4] = {zv.x, zv.y, zv.z, zv.w};
-      float o[4];
+    for (int i = 0; i < kApRows / kApRowLanes; ++i) {
+      const int m = r0 + rl + i * kApRowLanes;
+      if (m < M) {
+        const int64_t idx = static_cast<int64_t>(m) * N + c;
+        const float4 zv = ld4(z + idx);
+        const float zz[4] = {zv.x, zv.y, zv.z, zv.w};
+        float o[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
-        o[u] = fmaxf(fmaf(gav[u], (zz[u] - mu[u]) * rs[u], bev[u]), 0.f) * drop_scale(seed, salt, idx + u, thresh, inv_keep);
-      st4(out + idx, make_float4(o[0], o[1], o[2], o[3]));
+        for (int u = 0; u < 4; ++u)
+          o[u] = fmaxf(fmaf(gav[u], (zz[u] - mu[u]) * rs[u], bev[u]), 0.f) * drop_scale(seed, salt, idx + u, thresh, inv_keep);
+        if (!PLANES || out) st4(out + idx, make_float4(o[0], o[1], o[2], o[3]));
+        if (PLANES) st4(&tile[(rl + i * kApRowLanes) * kTileStride + cl * 4], make_float4(o[0], o[1], o[2], o[3]));
+      }
     }
+  }
+  if (PLANES) {
+    __syncthreads();
+    emit_planes_from_tile(tile, r0, blockIdx.x * kApCols, M, N, pf, ps);
   }
 }
 
@@ -265,11 +284,14 @@ struct HeadTail {
 // after merging the per-tile column sums of dy and dy*xhat: `partial` has T rows of `stride` floats,
 // the two planes at column offsets 0 and off1 (dx epilogue: [T][2][N]; head_bce: [blocks][3K+2]).
 // Row group 0 adds d gamma / d beta (and finishes the head's d w, d b, loss).  dz may alias dy.
+template <bool PLANES>   // as bn_relu_dropout_apply_kernel: d z also as planes (both roles); dz may then be null
 __global__ __launch_bounds__(kApThreads) void bn_bwd_apply_kernel(
     const float* __restrict__ dy, const float* __restrict__ z, int M, int N, const float* __restrict__ mean_rstd,
     const float* __restrict__ gamma, const float* __restrict__ partial, int T, int stride, int off1,
-    float* __restrict__ g_gamma, float* __restrict__ g_beta, HeadTail head, float* __restrict__ dz) {
+    float* __restrict__ g_gamma, float* __restrict__ g_beta, HeadTail head, float* __restrict__ dz, Planes pf,
+    Planes ps) {
   __shared__ float red[2][kApRowLanes][kApCols];
+  __shared__ __attribute__((aligned(16))) float tile[PLANES ? kTileRows * kTileStride : 4];
   const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
   const int c = blockIdx.x * kApCols + cl * 4;
   const bool okc = c < N;
@@ -312,26 +334,33 @@ __global__ __launch_bounds__(kApThreads) void bn_bwd_apply_kernel(
       }
     }
   }
-  if (!okc) return;
-  const float invM = 1.f / static_cast<float>(M);
-  const float4 muv = ld4(mean_rstd + c), rsv = ld4(mean_rstd + N + c), gav = ld4(gamma + c);
-  const float mu[4] = {muv.x, muv.y, muv.z, muv.w}, rs[4] = {rsv.x, rsv.y, rsv.z, rsv.w};
-  const float ga[4] = {gav.x, gav.y, gav.z, gav.w};
-  const float m1[4] = {s1.x * invM, s1.y * invM, s1.z * invM, s1.w * invM};
-  const float m2[4] = {s2.x * invM, s2.y * invM, s2.z * invM, s2.w * invM};
+  if (!PLANES && !okc) return;
   const int r0 = blockIdx.y * kApRows;
+  if (okc) {
+    const float invM = 1.f / static_cast<float>(M);
+    const float4 muv = ld4(mean_rstd + c), rsv = ld4(mean_rstd + N + c), gav = ld4(gamma + c);
+    const float mu[4] = {muv.x, muv.y, muv.z, muv.w}, rs[4] = {rsv.x, rsv.y, rsv.z, rsv.w};
+    const float ga[4] = {gav.x, gav.y, gav.z, gav.w};
+    const float m1[4] = {s1.x * invM, s1.y * invM, s1.z * invM, s1.w * invM};
+    const float m2[4] = {s2.x * invM, s2.y * invM, s2.z * invM, s2.w * invM};
 #pragma unroll
-  for (int i = 0; i < kApRows / kApRowLanes; ++i) {
-    const int m = r0 + rl + i * kApRowLanes;
-    if (m < M) {
-      const int64_t idx = static_cast<int64_t>(m) * N + c;
-      const float4 dv = ld4(dy + idx), zv = ld4(z + idx);
-      const float dd[4] = {dv.x, dv.y, dv.z, dv.w}, zz[4] = {zv.x, zv.y, zv.z, zv.w};
-      float o[4];
+    for (int i = 0; i < kApRows / kApRowLanes; ++i) {
+      const int m = r0 + rl + i * kApRowLanes;
+      if (m < M) {
+        const int64_t idx = static_cast<int64_t>(m) * N + c;
+        const float4 dv = ld4(dy + idx), zv = ld4(z + idx);
+        const float dd[4] = {dv.x, dv.y, dv.z, dv.w}, zz[4] = {zv.x, zv.y, zv.z, zv.w};
+        float o[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) o[u] = ga[u] * rs[u] * (dd[u] - m1[u] - (zz[u] - mu[u]) * rs[u] * m2[u]);
-      st4(dz + idx, make_float4(o[0], o[1], o[2], o[3]));
+        for (int u = 0; u < 4; ++u) o[u] = ga[u] * rs[u] * (dd[u] - m1[u] - (zz[u] - mu[u]) * rs[u] * m2[u]);
+        if (!PLANES || dz) st4(dz + idx, make_float4(o[0], o[1], o[2], o[3]));
+        if (PLANES) st4(&tile[(rl + i * kApRowLanes) * kTileStride + cl * 4], make_float4(o[0], o[1], o[2], o[3]));
+      }
     }
+  }
+  if (PLANES) {
+    __syncthreads();
+    emit_planes_from_tile(tile, r0, blockIdx.x * kApCols, M, N, pf, ps);
   }
 }
 
@@ -519,6 +548,45 @@ struct FmBwd {
   int dim;
 };
 
+// d weight tile (N x K slab of one batch split; summed by slab_reduce_kernel / the optimizer's prepare launch)
+__device__ __forceinline__ void dw_tile_store(const f32x16& acc, const TilePos& pos, int m0, int n0, int N, int K,
+                                              float* __restrict__ sl) {
+  const int n = n0 + pos.col();
+  if (pos.khalf == 0 && n < K) {
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int m = m0 + pos.row(reg);
+      if (m < N) sl[static_cast<int64_t>(m) * K + n] = acc[reg];
+    }
+  }
+}
+
+// d input tile: EPI 0 plain store, 1 the lower layer's BatchNorm mask, 2 + FM backward / another consumer's gradient
+template <int EPI>
+__device__ __forceinline__ void dx_tile_epilogue(const f32x16& acc, const TilePos& pos, int m0, int n0, int M, int K,
+                                                 float* __restrict__ g_x, const BnBwd& bn, const FmBwd& fmb) {
+  if (pos.khalf == 1) return;
+  if (EPI == 1) {
+    bn_mask_tile(bn, acc, pos, m0, n0, M, K);
+    return;
+  }
+  const int n = n0 + pos.col();
+  if (n >= K) return;
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg) {
+    const int m = m0 + pos.row(reg);
+    if (m < M) {
+      const int64_t off = static_cast<int64_t>(m) * K + n;
+      float v = acc[reg];
+      if (EPI == 2) {   // d e = d flat + g_fm * (S - e) (fm.py:18-23 backward) + what another layer sent back
+        if (fmb.g_fm) v += fmb.g_fm[m] * (fmb.fm_sum[static_cast<int64_t>(m) * fmb.dim + n % fmb.dim] - fmb.e[off]);
+        if (fmb.addend) v += fmb.addend[off];
+      }
+      g_x[off] = v;
+    }
+  }
+}
+
 // X3: both products on the bf16 matrix pipe with the bf16 x 3 split (gemm_core.h::mainloop_x3; FAST operands only) —
 // selected by dfm_tower_set_mode(1), never implicitly.
 template <bool FAST, int EPI, bool X3 = false>   // EPI 0: plain store, 1: BatchNorm mask of the lower layer, 2: + FM backward
@@ -540,15 +608,7 @@ __global__ __launch_bounds__(kThreads) void linear_bwd_kernel(
     const int ke = kb + k_per_split < M ? kb + k_per_split : M;
     if constexpr (X3) mainloop_x3<false, false>(dz, N, x, K, N, K, m0, n0, kb, ke, sm, pos, acc);
     else mainloop<false, false, FAST, FAST>(dz, N, x, K, N, K, m0, n0, kb, ke, sm, pos, acc);
-    const int n = n0 + pos.col();
-    if (pos.khalf == 0 && n < K) {
-      float* sl = slabs + static_cast<int64_t>(sp) * N * K;      // summed by slab_reduce_kernel
-#pragma unroll
-      for (int reg = 0; reg < 16; ++reg) {
-        const int m = m0 + pos.row(reg);
-        if (m < N) sl[static_cast<int64_t>(m) * K + n] = acc[reg];
-      }
-    }
+    dw_tile_store(acc, pos, m0, n0, N, K, slabs + static_cast<int64_t>(sp) * N * K);
     return;
   }
   // ---- dx (M x K) = dz W: A = dz (k-contiguous), B = W (k-strided) ----
@@ -556,26 +616,7 @@ __global__ __launch_bounds__(kThreads) void linear_bwd_kernel(
   const int m0 = (t / dx_tiles_n) * BM, n0 = (t % dx_tiles_n) * BN;
   if constexpr (X3) mainloop_x3<true, false>(dz, N, w, K, M, K, m0, n0, 0, N, sm, pos, acc);
   else mainloop<true, false, FAST, FAST>(dz, N, w, K, M, K, m0, n0, 0, N, sm, pos, acc);
-  if (pos.khalf == 1) return;
-  if (EPI == 1) {
-    bn_mask_tile(bn, acc, pos, m0, n0, M, K);
-    return;
-  }
-  const int n = n0 + pos.col();
-  if (n >= K) return;
-#pragma unroll
-  for (int reg = 0; reg < 16; ++reg) {
-    const int m = m0 + pos.row(reg);
-    if (m < M) {
-      const int64_t off = static_cast<int64_t>(m) * K + n;
-      float v = acc[reg];
-      if (EPI == 2) {   // d e = d flat + g_fm * (S - e) (fm.py:18-23 backward) + what another layer sent back
-        if (fmb.g_fm) v += fmb.g_fm[m] * (fmb.fm_sum[static_cast<int64_t>(m) * fmb.dim + n % fmb.dim] - fmb.e[off]);
-        if (fmb.addend) v += fmb.addend[off];
-      }
-      g_x[off] = v;
-    }
-  }
+  dx_tile_epilogue<EPI>(acc, pos, m0, n0, M, K, g_x, bn, fmb);
 }
 
 // g_w += sum_s slab_s (fixed order) for every Linear of the tower in ONE launch: the batch-split
@@ -690,36 +731,78 @@ extern "C" int dfm_linear_bn_forward(const float* d_x, int64_t ldx, const float*
   return DFM_OK;
 }
 
+namespace {
+// planes arguments of the apply entry points: both roles or none; batch % 32 == 0 and features % 8 == 0
+bool planes_args_ok(const void* pf, const void* ps, int64_t batch, int features) {
+  if (!pf && !ps) return true;
+  return pf && ps && aligned16(pf) && aligned16(ps) && batch % 32 == 0 && features % 8 == 0;
+}
+}  // namespace
+
+static int bn_relu_dropout_apply_impl(const float* d_z, int64_t batch, int features, const void* d_workspace,
+                                      const float* d_gamma, const float* d_beta, float* d_mean_rstd,
+                                      float* d_running_mean, float* d_running_var, int64_t* d_num_batches,
+                                      float momentum, float eps, float p_drop, const int64_t* d_seed, int salt,
+                                      float* d_out, void* d_planes_f, void* d_planes_s, dfm_stream_t stream) {
+  DFM_REQUIRE(d_z && d_workspace && d_gamma && d_beta && d_mean_rstd && (d_out || d_planes_f), "null argument");
+  DFM_REQUIRE(planes_args_ok(d_planes_f, d_planes_s, batch, features),
+              "planes: both roles, 16-byte aligned, batch %% 32 == 0, features %% 8 == 0");
+  DFM_REQUIRE(batch > 0 && batch < (1 << 30) && features > 0 && features % 4 == 0,
+              "features must be a positive multiple of 4");
+  DFM_REQUIRE(aligned16(d_z) && aligned16(d_workspace) && aligned16(d_mean_rstd) && aligned16(d_gamma) &&
+                  aligned16(d_beta) && (!d_out || aligned16(d_out)), "pointers must be 16-byte aligned");
+  DFM_REQUIRE(p_drop >= 0.f && p_drop < 1.f && (p_drop == 0.f || d_seed), "bad dropout arguments");
+  const int M = static_cast<int>(batch);
+  const dim3 grid(tiles(features, kApCols), tiles(M, kApRows));
+  if (d_planes_f) {
+    hipLaunchKernelGGL(bn_relu_dropout_apply_kernel<true>, grid, dim3(kApThreads), 0, as_stream(stream), d_z, M,
+                       features, static_cast<const float*>(d_workspace), d_gamma, d_beta, d_mean_rstd, d_running_mean,
+                       d_running_var, d_num_batches, momentum, eps, dropout_thresh(p_drop), 1.f / (1.f - p_drop),
+                       d_seed, salt, d_out, make_planes(d_planes_f, M, features), make_planes(d_planes_s, features, M));
+  } else {
+    hipLaunchKernelGGL(bn_relu_dropout_apply_kernel<false>, grid, dim3(kApThreads), 0, as_stream(stream), d_z, M,
+                       features, static_cast<const float*>(d_workspace), d_gamma, d_beta, d_mean_rstd, d_running_mean,
+                       d_running_var, d_num_batches, momentum, eps, dropout_thresh(p_drop), 1.f / (1.f - p_drop),
+                       d_seed, salt, d_out, Planes{}, Planes{});
+  }
+  DFM_LAUNCH_CHECK();
+  return DFM_OK;
+}
+
 extern "C" int dfm_bn_relu_dropout_apply(const float* d_z, int64_t batch, int features, const void* d_workspace,
                                          const float* d_gamma, const float* d_beta, float* d_mean_rstd,
                                          float* d_running_mean, float* d_running_var, int64_t* d_num_batches,
                                          float momentum, float eps, float p_drop, const int64_t* d_seed, int salt,
                                          float* d_out, dfm_stream_t stream) {
-  DFM_REQUIRE(d_z && d_workspace && d_gamma && d_beta && d_mean_rstd && d_out, "null argument");
-  DFM_REQUIRE(batch > 0 && batch < (1 << 30) && features > 0 && features % 4 == 0,
-              "features must be a positive multiple of 4");
-  DFM_REQUIRE(aligned16(d_z) && aligned16(d_workspace) && aligned16(d_mean_rstd) && aligned16(d_gamma) &&
-                  aligned16(d_beta) && aligned16(d_out), "pointers must be 16-byte aligned");
-  DFM_REQUIRE(p_drop >= 0.f && p_drop < 1.f && (p_drop == 0.f || d_seed), "bad dropout arguments");
-  const int M = static_cast<int>(batch);
-  const dim3 grid(tiles(features, kApCols), tiles(M, kApRows));
-  hipLaunchKernelGGL(bn_relu_dropout_apply_kernel, grid, dim3(kApThreads), 0, as_stream(stream), d_z, M, features,
-                     static_cast<const float*>(d_workspace), d_gamma, d_beta, d_mean_rstd, d_running_mean,
-                     d_running_var, d_num_batches, momentum, eps, dropout_thresh(p_drop), 1.f / (1.f - p_drop), d_seed,
-                     salt, d_out);
-  DFM_LAUNCH_CHECK();
-  return DFM_OK;
+  DFM_REQUIRE(d_out, "null argument");
+  return bn_relu_dropout_apply_impl(d_z, batch, features, d_workspace, d_gamma, d_beta, d_mean_rstd, d_running_mean,
+                                    d_running_var, d_num_batches, momentum, eps, p_drop, d_seed, salt, d_out, nullptr,
+                                    nullptr, stream);
 }
 
-extern "C" int dfm_bn_backward_apply(const dfm_bn_bwd* bn, int64_t batch, int features, const dfm_head_tail* head,
-                                     float* d_dz, dfm_stream_t stream) {
-  DFM_REQUIRE(bn && d_dz, "null argument");
+extern "C" int dfm_bn_relu_dropout_apply_planes(const float* d_z, int64_t batch, int features, const void* d_workspace,
+                                                const float* d_gamma, const float* d_beta, float* d_mean_rstd,
+                                                float* d_running_mean, float* d_running_var, int64_t* d_num_batches,
+                                                float momentum, float eps, float p_drop, const int64_t* d_seed,
+                                                int salt, float* d_out, void* d_planes_f, void* d_planes_s,
+                                                dfm_stream_t stream) {
+  DFM_REQUIRE(d_planes_f && d_planes_s, "null argument");
+  return bn_relu_dropout_apply_impl(d_z, batch, features, d_workspace, d_gamma, d_beta, d_mean_rstd, d_running_mean,
+                                    d_running_var, d_num_batches, momentum, eps, p_drop, d_seed, salt, d_out,
+                                    d_planes_f, d_planes_s, stream);
+}
+
+static int bn_backward_apply_impl(const dfm_bn_bwd* bn, int64_t batch, int features, const dfm_head_tail* head,
+                                  float* d_dz, void* d_planes_f, void* d_planes_s, dfm_stream_t stream) {
+  DFM_REQUIRE(bn && (d_dz || d_planes_f), "null argument");
+  DFM_REQUIRE(planes_args_ok(d_planes_f, d_planes_s, batch, features),
+              "planes: both roles, 16-byte aligned, batch %% 32 == 0, features %% 8 == 0");
   DFM_REQUIRE(batch > 0 && batch < (1 << 30) && features > 0 && features % 4 == 0,
               "features must be a positive multiple of 4");
   BnBwd d = {};
   DFM_REQUIRE(fill_bn(bn, &d), "incomplete dfm_bn_bwd");
   DFM_REQUIRE(aligned16(d.dy) && aligned16(d.z) && aligned16(d.mean_rstd) && aligned16(d.gamma) &&
-                  aligned16(d.partial) && aligned16(d.g_gamma) && aligned16(d.g_beta) && aligned16(d_dz),
+                  aligned16(d.partial) && aligned16(d.g_gamma) && aligned16(d.g_beta) && (!d_dz || aligned16(d_dz)),
               "pointers must be 16-byte aligned");
   const int M = static_cast<int>(batch);
   HeadTail ht = {};
@@ -731,10 +814,30 @@ extern "C" int dfm_bn_backward_apply(const dfm_bn_bwd* bn, int64_t batch, int fe
     stride = 3 * features + 4;
   }
   const dim3 grid(tiles(features, kApCols), tiles(M, kApRows));
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, grid, dim3(kApThreads), 0, as_stream(stream), d.dy, d.z, M, features,
-                     d.mean_rstd, d.gamma, d.partial, T, stride, off1, d.g_gamma, d.g_beta, ht, d_dz);
+  if (d_planes_f) {
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, grid, dim3(kApThreads), 0, as_stream(stream), d.dy, d.z, M, features,
+                       d.mean_rstd, d.gamma, d.partial, T, stride, off1, d.g_gamma, d.g_beta, ht, d_dz,
+                       make_planes(d_planes_f, M, features), make_planes(d_planes_s, features, M));
+  } else {
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, grid, dim3(kApThreads), 0, as_stream(stream), d.dy, d.z, M, features,
+                       d.mean_rstd, d.gamma, d.partial, T, stride, off1, d.g_gamma, d.g_beta, ht, d_dz, Planes{},
+                       Planes{});
+  }
   DFM_LAUNCH_CHECK();
   return DFM_OK;
+}
+
+extern "C" int dfm_bn_backward_apply(const dfm_bn_bwd* bn, int64_t batch, int features, const dfm_head_tail* head,
+                                     float* d_dz, dfm_stream_t stream) {
+  DFM_REQUIRE(d_dz, "null argument");
+  return bn_backward_apply_impl(bn, batch, features, head, d_dz, nullptr, nullptr, stream);
+}
+
+extern "C" int dfm_bn_backward_apply_planes(const dfm_bn_bwd* bn, int64_t batch, int features,
+                                            const dfm_head_tail* head, float* d_dz, void* d_planes_f,
+                                            void* d_planes_s, dfm_stream_t stream) {
+  DFM_REQUIRE(d_planes_f && d_planes_s, "null argument");
+  return bn_backward_apply_impl(bn, batch, features, head, d_dz, d_planes_f, d_planes_s, stream);
 }
 
 namespace {
@@ -905,12 +1008,14 @@ void dw_split_plan(int n_out, int k_in, int m, int* splits, int* k_per_split) {
 }
 }  // namespace
 
-// Arithmetic of the tower's BACKWARD GEMMs (dfm_linear_backward): 0 = exact fp32 matrix pipe (default),
-// 1 = bf16 x 3 split on the bf16 pipe (gemm_core.h::mainloop_x3).  The forward always runs exact fp32.  An explicit
-// API call, recorded by bench.py (config.tower_mode) — nothing outside the caller's code changes what a run computes.
+// Arithmetic of the tower's GEMMs: 0 = exact fp32 matrix pipe, 1 = fp32 forward, bf16 x 3 backward
+// (gemm_core.h::mainloop_x3, inside dfm_linear_backward), 2 = bf16 x 6 forward and backward (gemm_x6.h: fp32-faithful
+// products on the bf16 pipe; the fused steps then call the *_x6 / *_planes entry points below — the library only
+// records the choice).  An explicit API call, recorded by bench.py (config.tower_mode) — nothing outside the
+// caller's code changes what a run computes.
 static int g_tower_mode = 0;
 extern "C" int dfm_tower_set_mode(int mode) {
-  DFM_REQUIRE(mode == 0 || mode == 1, "tower mode %d outside [0, 1]", mode);
+  DFM_REQUIRE(mode >= 0 && mode <= 2, "tower mode %d outside [0, 2]", mode);
   g_tower_mode = mode;
   return DFM_OK;
 }
@@ -973,6 +1078,252 @@ extern "C" int dfm_linear_backward(const float* d_dz, int64_t batch, int out_fea
     if (epi == 0) DFM_LBWD(false, 0); else if (epi == 1) DFM_LBWD(false, 1); else DFM_LBWD(false, 2);
   }
 #undef DFM_LBWD
+  DFM_LAUNCH_CHECK();
+  return DFM_OK;
+}
+
+// =====================================================================================
+// bf16 x 6 tower (gemm_x6.h): plane producers, forward and backward GEMM launches
+// =====================================================================================
+namespace {
+constexpr int kMaxSplitJobs = 8;
+struct SplitJobs {
+  const float* src[kMaxSplitJobs];
+  int rows[kMaxSplitJobs], cols[kMaxSplitJobs], tiles_c[kMaxSplitJobs];
+  Planes f[kMaxSplitJobs], s[kMaxSplitJobs];
+  int first_block[kMaxSplitJobs + 1];
+  int count;
+};
+}  // namespace
+
+// fp32 matrix [rows][cols] -> planes in role F (contraction = columns) and / or role S (contraction = rows);
+// a workgroup owns a 32 x 64 tile.  One launch for every weight of the tower.
+__global__ __launch_bounds__(kApThreads) void split_planes_kernel(SplitJobs jobs) {
+  __shared__ __attribute__((aligned(16))) float tile[kTileRows * kTileStride];
+  int e = 0;
+  while (e + 1 < jobs.count && static_cast<int>(blockIdx.x) >= jobs.first_block[e + 1]) ++e;
+  const int lb = blockIdx.x - jobs.first_block[e];
+  const int R = jobs.rows[e], C = jobs.cols[e];
+  const int r0 = (lb / jobs.tiles_c[e]) * kTileRows, c0 = (lb % jobs.tiles_c[e]) * kTileCols;
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const float* src = jobs.src[e];
+#pragma unroll
+  for (int i = 0; i < kTileRows / kApRowLanes; ++i) {
+    const int m = r0 + rl + i * kApRowLanes, c = c0 + cl * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (m < R && c < C) v = ld4(src + static_cast<int64_t>(m) * C + c);
+    st4(&tile[(rl + i * kApRowLanes) * kTileStride + cl * 4], v);
+  }
+  __syncthreads();
+  emit_planes_from_tile(tile, r0, c0, R, C, jobs.f[e], jobs.s[e]);
+}
+
+template <int AK>   // A = x: OP_PLANES (role F planes of a lower layer's output) or OP_F32_KC (fp32, split here)
+__global__ __launch_bounds__(kThreads) void linear_bn_fwd_x6_kernel(
+    const float* __restrict__ x, int64_t ldx, Planes xp, Planes wp, const float* __restrict__ bias,
+    float* __restrict__ z, int M, int N, int K, int tiles_n, float* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char x6_lds[];
+  __bf16* smem = reinterpret_cast<__bf16*>(x6_lds);
+  const TilePos pos;
+  const int lt = xcd_logical_index(blockIdx.x, gridDim.x);
+  const int m0 = (lt / tiles_n) * BM, n0 = (lt % tiles_n) * BN;
+  f32x16 acc = {};
+  const X6Operand<OP_PLANES> ob(wp, n0);
+  if constexpr (AK == OP_PLANES) {
+    const X6Operand<OP_PLANES> oa(xp, m0);
+    mainloop_x6(oa, ob, 0, K, smem, pos, acc);
+  } else {
+    const X6Operand<OP_F32_KC> oa(x, ldx, m0, M);
+    mainloop_x6(oa, ob, 0, K, smem, pos, acc);
+  }
+  if (pos.khalf == 1) return;
+  fwd_tile_epilogue(acc, pos, m0, n0, M, N, bias, z, partial);
+}
+
+// backward of one Linear on planes: blocks [0, dw_blocks) d weight tiles x batch splits (A = d z role S, B = x role S
+// or fp32 x split here), the rest d input tiles (A = d z role F, B = W role S).
+template <int EPI, int XK>
+__global__ __launch_bounds__(kThreads) void linear_bwd_x6_kernel(
+    Planes dzf, Planes dzs, const float* __restrict__ x, Planes xs, Planes ws, float* __restrict__ g_x, int M, int N,
+    int K, int dw_tiles_n, int dw_tiles, int dw_blocks, int k_per_split, float* __restrict__ slabs, int dx_tiles_n,
+    BnBwd bn, FmBwd fmb) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char x6_lds[];
+  __bf16* smem = reinterpret_cast<__bf16*>(x6_lds);
+  const TilePos pos;
+  f32x16 acc = {};
+  const int wg = blockIdx.x;
+  const int bid = wg < dw_blocks ? xcd_logical_index(wg, dw_blocks)
+                                 : dw_blocks + xcd_logical_index_from(wg - dw_blocks, static_cast<int>(gridDim.x) - dw_blocks, dw_blocks);
+  if (bid < dw_blocks) {
+    const int tile = bid % dw_tiles, sp = bid / dw_tiles;
+    const int m0 = (tile / dw_tiles_n) * BM, n0 = (tile % dw_tiles_n) * BN;
+    const int kb = sp * k_per_split;
+    const int ke = kb + k_per_split < M ? kb + k_per_split : M;
+    const X6Operand<OP_PLANES> oa(dzs, m0);
+    if constexpr (XK == OP_PLANES) {
+      const X6Operand<OP_PLANES> ob(xs, n0);
+      mainloop_x6(oa, ob, kb, ke, smem, pos, acc);
+    } else {
+      const X6Operand<OP_F32_STRIDED> ob(x, K, n0, K);
+      mainloop_x6(oa, ob, kb, ke, smem, pos, acc);
+    }
+    dw_tile_store(acc, pos, m0, n0, N, K, slabs + static_cast<int64_t>(sp) * N * K);
+    return;
+  }
+  const int t = bid - dw_blocks;
+  const int m0 = (t / dx_tiles_n) * BM, n0 = (t % dx_tiles_n) * BN;
+  const X6Operand<OP_PLANES> oa(dzf, m0);
+  const X6Operand<OP_PLANES> ob(ws, n0);
+  mainloop_x6(oa, ob, 0, N, smem, pos, acc);
+  dx_tile_epilogue<EPI>(acc, pos, m0, n0, M, K, g_x, bn, fmb);
+}
+
+namespace {
+// batch split of the d-weight product on planes: whole 64-deep slices, about as many per workgroup as a d-input
+// workgroup runs (out_features / 64), so that both kinds of workgroup of the launch take the same time
+void dw_split_plan_x6(int n_out, int m, int* splits, int* k_per_split) {
+  const int target = tiles(n_out, X6_BK) + 1;
+  const int slices = tiles(m, X6_BK);
+  int per = slices < target ? slices : target;
+  *splits = (slices + per - 1) / per;
+  per = (slices + *splits - 1) / *splits;
+  *k_per_split = per * X6_BK;
+  *splits = (slices + per - 1) / per;
+}
+template <typename K>
+int x6_lds_attr(K kernel) {
+  DFM_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  kX6SmemBytes));
+  return DFM_OK;
+}
+}  // namespace
+
+extern "C" int dfm_tower_x6_supported(int64_t batch, int out_features, int in_features) {
+  return batch > 0 && batch < (1 << 30) && batch % 64 == 0 && out_features > 0 && out_features % 8 == 0 &&
+         in_features > 0 && in_features % 8 == 0;
+}
+
+extern "C" size_t dfm_planes_bytes(int64_t rows, int64_t contraction) {
+  if (rows <= 0 || contraction <= 0) return 0;
+  return align256(static_cast<size_t>(3) * planes_plane_elems(rows, contraction) * sizeof(__bf16));
+}
+
+extern "C" int dfm_split_planes(const dfm_split_job* jobs, int count, dfm_stream_t stream) {
+  DFM_REQUIRE(jobs && count >= 1 && count <= kMaxSplitJobs, "1 to %d jobs", kMaxSplitJobs);
+  SplitJobs sj = {};
+  int blocks = 0;
+  for (int i = 0; i < count; ++i) {
+    const dfm_split_job& j = jobs[i];
+    DFM_REQUIRE(j.src && aligned16(j.src) && j.rows > 0 && j.cols > 0 && j.rows < (1 << 30) && j.cols < (1 << 30) &&
+                    j.cols % 4 == 0, "job %d: source must be 16-byte aligned with cols %% 4 == 0", i);
+    DFM_REQUIRE(j.planes_f || j.planes_s, "job %d: no destination", i);
+    DFM_REQUIRE(!j.planes_f || (aligned16(j.planes_f) && j.cols % 8 == 0), "job %d: role F needs cols %% 8 == 0", i);
+    DFM_REQUIRE(!j.planes_s || (aligned16(j.planes_s) && j.rows % 8 == 0), "job %d: role S needs rows %% 8 == 0", i);
+    sj.src[i] = j.src;
+    sj.rows[i] = static_cast<int>(j.rows); sj.cols[i] = static_cast<int>(j.cols);
+    sj.tiles_c[i] = tiles(sj.cols[i], kTileCols);
+    sj.f[i] = j.planes_f ? make_planes(j.planes_f, j.rows, j.cols) : Planes{};
+    sj.s[i] = j.planes_s ? make_planes(j.planes_s, j.cols, j.rows) : Planes{};
+    sj.first_block[i] = blocks;
+    blocks += tiles(sj.rows[i], kTileRows) * sj.tiles_c[i];
+  }
+  sj.first_block[count] = blocks;
+  sj.count = count;
+  hipLaunchKernelGGL(split_planes_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kApThreads), 0, as_stream(stream), sj);
+  DFM_LAUNCH_CHECK();
+  return DFM_OK;
+}
+
+extern "C" int dfm_linear_bn_forward_x6(const float* d_x, int64_t ldx, const void* d_x_planes_f,
+                                        const void* d_w_planes_f, const float* d_bias, int64_t batch,
+                                        int out_features, int in_features, float* d_z, void* d_workspace,
+                                        dfm_stream_t stream) {
+  DFM_REQUIRE((d_x != nullptr) != (d_x_planes_f != nullptr), "exactly one of d_x / d_x_planes_f");
+  DFM_REQUIRE(d_w_planes_f && d_z && d_workspace, "null argument");
+  DFM_REQUIRE(dfm_tower_x6_supported(batch, out_features, in_features),
+              "bf16 x 6 tower: batch %% 64 == 0, features %% 8 == 0");
+  DFM_REQUIRE(!d_x || (aligned16(d_x) && ldx % 4 == 0 && ldx >= in_features), "d_x: 16-byte aligned rows");
+  DFM_REQUIRE(aligned16(d_w_planes_f) && (!d_x_planes_f || aligned16(d_x_planes_f)), "planes must be 16-byte aligned");
+  const int M = static_cast<int>(batch), N = out_features, K = in_features;
+  const int tn = tiles(N, BN);
+  const dim3 grid(static_cast<unsigned>(tiles(M, BM) * tn));
+  const Planes wp = make_planes(const_cast<void*>(d_w_planes_f), N, K);
+  float* partial = static_cast<float*>(d_workspace);
+  if (d_x) {
+    static const int attr = x6_lds_attr(linear_bn_fwd_x6_kernel<OP_F32_KC>);
+    if (attr != DFM_OK) return attr;
+    hipLaunchKernelGGL((linear_bn_fwd_x6_kernel<OP_F32_KC>), grid, dim3(kThreads), kX6SmemBytes, as_stream(stream), d_x,
+                       ldx, Planes{}, wp, d_bias, d_z, M, N, K, tn, partial);
+  } else {
+    static const int attr = x6_lds_attr(linear_bn_fwd_x6_kernel<OP_PLANES>);
+    if (attr != DFM_OK) return attr;
+    hipLaunchKernelGGL((linear_bn_fwd_x6_kernel<OP_PLANES>), grid, dim3(kThreads), kX6SmemBytes, as_stream(stream),
+                       nullptr, 0, make_planes(const_cast<void*>(d_x_planes_f), M, K), wp, d_bias, d_z, M, N, K, tn,
+                       partial);
+  }
+  DFM_LAUNCH_CHECK();
+  return DFM_OK;
+}
+
+extern "C" int dfm_linear_backward_x6_splits(int64_t batch, int out_features, int in_features) {
+  (void)in_features;
+  int splits, kps;
+  dw_split_plan_x6(out_features, static_cast<int>(batch), &splits, &kps);
+  return splits;
+}
+
+extern "C" size_t dfm_linear_backward_x6_workspace_bytes(int64_t batch, int out_features, int in_features) {
+  const int s = dfm_linear_backward_x6_splits(batch, out_features, in_features);
+  return align256(sizeof(float) * static_cast<size_t>(s) * out_features * in_features);
+}
+
+extern "C" int dfm_linear_backward_x6(const void* d_dz_planes_f, const void* d_dz_planes_s, int64_t batch,
+                                      int out_features, const float* d_x, const void* d_x_planes_s, int in_features,
+                                      const void* d_w_planes_s, float* d_g_x, const dfm_bn_bwd* bn_below,
+                                      const dfm_fm_bwd* fm, void* d_workspace, dfm_stream_t stream) {
+  DFM_REQUIRE(d_dz_planes_f && d_dz_planes_s && d_w_planes_s && d_workspace, "null argument");
+  DFM_REQUIRE((d_x != nullptr) != (d_x_planes_s != nullptr), "exactly one of d_x / d_x_planes_s");
+  DFM_REQUIRE(dfm_tower_x6_supported(batch, out_features, in_features),
+              "bf16 x 6 tower: batch %% 64 == 0, features %% 8 == 0");
+  DFM_REQUIRE(!d_x || aligned16(d_x), "d_x must be 16-byte aligned");
+  DFM_REQUIRE(!(bn_below && fm), "bn_below and fm are exclusive");
+  DFM_REQUIRE(bn_below || d_g_x, "d_g_x is required without bn_below");
+  const int M = static_cast<int>(batch), N = out_features, K = in_features;
+  BnBwd dbn = {};
+  if (bn_below) DFM_REQUIRE(fill_bn(bn_below, &dbn), "incomplete dfm_bn_bwd");
+  FmBwd dfm_ = {};
+  if (fm) {
+    DFM_REQUIRE(fm->g_fm || fm->addend, "dfm_fm_bwd: neither an FM gradient nor an addend");
+    DFM_REQUIRE(!fm->g_fm || (fm->fm_sum && fm->e && fm->dim > 0 && K % fm->dim == 0), "incomplete dfm_fm_bwd");
+    dfm_.g_fm = fm->g_fm; dfm_.fm_sum = fm->fm_sum; dfm_.e = fm->e; dfm_.addend = fm->addend;
+    dfm_.dim = fm->dim > 0 ? fm->dim : 1;
+  }
+  int splits, k_per_split;
+  dw_split_plan_x6(N, M, &splits, &k_per_split);
+  const int dw_tn = tiles(K, BN), dw_t = tiles(N, BM) * dw_tn;
+  const int dx_tn = tiles(K, BN), dx_t = tiles(M, BM) * dx_tn;
+  const int dw_blocks = dw_t * splits;
+  const dim3 grid(static_cast<unsigned>(dw_blocks + dx_t));
+  const Planes dzf = make_planes(const_cast<void*>(d_dz_planes_f), M, N);
+  const Planes dzs = make_planes(const_cast<void*>(d_dz_planes_s), N, M);
+  const Planes xs = d_x_planes_s ? make_planes(const_cast<void*>(d_x_planes_s), K, M) : Planes{};
+  const Planes ws = make_planes(const_cast<void*>(d_w_planes_s), K, N);
+  float* slabs = static_cast<float*>(d_workspace);
+#define DFM_LBWD6(E, XK)                                                                                          \
+  do {                                                                                                            \
+    static const int attr = x6_lds_attr(linear_bwd_x6_kernel<E, XK>);                                             \
+    if (attr != DFM_OK) return attr;                                                                              \
+    hipLaunchKernelGGL((linear_bwd_x6_kernel<E, XK>), grid, dim3(kThreads), kX6SmemBytes, as_stream(stream), dzf,   \
+                       dzs, d_x, xs, ws, d_g_x, M, N, K, dw_tn, dw_t, dw_blocks, k_per_split, slabs, dx_tn, dbn,    \
+                       dfm_);                                                                                     \
+  } while (0)
+  const int epi = bn_below ? 1 : (fm ? 2 : 0);
+  if (d_x) {
+    if (epi == 0) DFM_LBWD6(0, OP_F32_STRIDED); else if (epi == 1) DFM_LBWD6(1, OP_F32_STRIDED); else DFM_LBWD6(2, OP_F32_STRIDED);
+  } else {
+    if (epi == 0) DFM_LBWD6(0, OP_PLANES); else if (epi == 1) DFM_LBWD6(1, OP_PLANES); else DFM_LBWD6(2, OP_PLANES);
+  }
+#undef DFM_LBWD6
   DFM_LAUNCH_CHECK();
   return DFM_OK;
 }

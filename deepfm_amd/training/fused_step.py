@@ -95,6 +95,28 @@ class _FusedTowerStep(RowSparseTrainStep):
             self.ws_fwd.append(_zeros_bytes(lib.dfm_linear_bn_workspace_bytes(B, n), dev))
             self.ws_bn.append(_zeros_bytes(lib.dfm_bn_bwd_workspace_bytes(B, n), dev))
             self.ws_lin.append(_zeros_bytes(lib.dfm_linear_backward_workspace_bytes(B, n, k), dev))
+        # dfm_tower_set_mode(2): the tower's GEMMs on the bf16 pipe with the exact three-way operand split
+        # (csrc/gemm_x6.h).  Weights are split once per step (one launch), activations and d z by the kernels that
+        # produce them; the fp32 copies of a / d z are not written at all.  Shapes the planes cannot hold run mode 0.
+        self.tower_mode = int(lib.dfm_tower_get_mode())
+        self.x6 = self.tower_mode == 2 and all(
+            lib.dfm_tower_x6_supported(B, l.out_features, l.in_features) for l in self.lin)
+        if self.x6:
+            def planes(rows, contraction):
+                return _zeros_bytes(lib.dfm_planes_bytes(rows, contraction), dev)
+            self.w_f = [planes(l.out_features, l.in_features) for l in self.lin]     # z = x W^T
+            self.w_s = [planes(l.in_features, l.out_features) for l in self.lin]     # d x = d z W
+            self.a_f = [planes(B, l.out_features) for l in self.lin[:-1]]            # next layer's z
+            self.a_s = [planes(l.out_features, B) for l in self.lin[:-1]]            # next layer's d W
+            self.dz_f = [planes(B, l.out_features) for l in self.lin]                # d x
+            self.dz_s = [planes(l.out_features, B) for l in self.lin]                # d W
+            self.ws_lin = [_zeros_bytes(lib.dfm_linear_backward_x6_workspace_bytes(B, l.out_features, l.in_features), dev)
+                           for l in self.lin]
+            self._split_jobs = (_lib.SplitJob * self.L)()
+            for i, l in enumerate(self.lin):
+                j = self._split_jobs[i]
+                j.src, j.rows, j.cols = l.weight.data_ptr(), l.out_features, l.in_features
+                j.planes_f, j.planes_s = self.w_f[i].data_ptr(), self.w_s[i].data_ptr()
         self.seed = torch.randint(1, 2 ** 40, (1,), dtype=torch.int64, device=dev)
         if torch.distributed.is_available() and torch.distributed.is_initialized():
             # replicas are built from one seed (identical parameters) but must not share dropout masks
@@ -161,13 +183,22 @@ class _FusedTowerStep(RowSparseTrainStep):
         extra = self._interaction_forward()
         x = self.x0
         head = self.head
+        x6 = self.x6
+        if x6:      # this step's weights as planes (the optimizer wrote them at the end of the last step)
+            _lib.check(lib.dfm_split_planes(self._split_jobs, self.L, st))
         for i in range(self.L):
             lin, bn = self.lin[i], self.bn[i]
             n, k = lin.out_features, lin.in_features
             track = bn.track_running_stats and bn.running_mean is not None
-            _lib.check(lib.dfm_linear_bn_forward(
-                x.data_ptr(), k, lin.weight.data_ptr(), _lib.ptr(lin.bias), B, n, k, self.z[i].data_ptr(),
-                self.ws_fwd[i].data_ptr(), st))
+            if x6:
+                _lib.check(lib.dfm_linear_bn_forward_x6(
+                    x.data_ptr() if i == 0 else None, k, None if i == 0 else self.a_f[i - 1].data_ptr(),
+                    self.w_f[i].data_ptr(), _lib.ptr(lin.bias), B, n, k, self.z[i].data_ptr(),
+                    self.ws_fwd[i].data_ptr(), st))
+            else:
+                _lib.check(lib.dfm_linear_bn_forward(
+                    x.data_ptr(), k, lin.weight.data_ptr(), _lib.ptr(lin.bias), B, n, k, self.z[i].data_ptr(),
+                    self.ws_fwd[i].data_ptr(), st))
             stats = (self.stats[i].data_ptr(), bn.running_mean.data_ptr() if track else None,
                      bn.running_var.data_ptr() if track else None,
                      bn.num_batches_tracked.data_ptr() if track else None, float(bn.momentum), float(bn.eps))
@@ -180,9 +211,15 @@ class _FusedTowerStep(RowSparseTrainStep):
                     _lib.ptr(head.bias), self.fo.data_ptr(), _lib.ptr(extra), self.labels.data_ptr(),
                     self.logits.data_ptr(), self.g_logits.data_ptr(), C.byref(ctx), st))
                 break
-            _lib.check(lib.dfm_bn_relu_dropout_apply(
-                self.z[i].data_ptr(), B, n, self.ws_fwd[i].data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(),
-                *stats, self.drop_p[i], self.seed.data_ptr(), i, self.a[i].data_ptr(), st))
+            if x6:
+                _lib.check(lib.dfm_bn_relu_dropout_apply_planes(
+                    self.z[i].data_ptr(), B, n, self.ws_fwd[i].data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(),
+                    *stats, self.drop_p[i], self.seed.data_ptr(), i, None, self.a_f[i].data_ptr(),
+                    self.a_s[i].data_ptr(), st))
+            else:
+                _lib.check(lib.dfm_bn_relu_dropout_apply(
+                    self.z[i].data_ptr(), B, n, self.ws_fwd[i].data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(),
+                    *stats, self.drop_p[i], self.seed.data_ptr(), i, self.a[i].data_ptr(), st))
             x = self.a[i]
         tail = _lib.HeadTail()
         tail.g_w = head.weight.grad.data_ptr()
@@ -194,6 +231,18 @@ class _FusedTowerStep(RowSparseTrainStep):
         for i in range(self.L - 1, -1, -1):
             lin = self.lin[i]
             n, k = lin.out_features, lin.in_features
+            if x6:
+                _lib.check(lib.dfm_bn_backward_apply_planes(
+                    C.byref(ctx), B, n, C.byref(tail) if i == self.L - 1 else None, None, self.dz_f[i].data_ptr(),
+                    self.dz_s[i].data_ptr(), st))
+                if i > 0:
+                    ctx = self._bn_ctx(i - 1)
+                _lib.check(lib.dfm_linear_backward_x6(
+                    self.dz_f[i].data_ptr(), self.dz_s[i].data_ptr(), B, n, self.x0.data_ptr() if i == 0 else None,
+                    self.a_s[i - 1].data_ptr() if i > 0 else None, k, self.w_s[i].data_ptr(),
+                    self.g_x0.data_ptr() if i == 0 else None, C.byref(ctx) if i > 0 else None,
+                    C.byref(fmb) if (i == 0 and fmb is not None) else None, self.ws_lin[i].data_ptr(), st))
+                continue
             _lib.check(lib.dfm_bn_backward_apply(C.byref(ctx), B, n, C.byref(tail) if i == self.L - 1 else None,
                                                  self.dy[i].data_ptr(), st))
             xin = self.a[i - 1] if i > 0 else self.x0
@@ -219,6 +268,8 @@ class _FusedTowerStep(RowSparseTrainStep):
             r, lin = refs[i], self.lin[i]
             r.workspace, r.g_w = self.ws_lin[i].data_ptr(), lin.weight.grad.data_ptr()
             r.batch, r.out_features, r.in_features = B, lin.out_features, lin.in_features
+            if x6:
+                r.splits = lib.dfm_linear_backward_x6_splits(B, lin.out_features, lin.in_features)
         if self._dense_parts:            # the sliced DENSE-field gradients: the flat buffer's first n_l2 floats
             r = refs[self.L]
             r.workspace, r.g_w = self._dense_partial.data_ptr(), self.opt.flat_grad.data_ptr()

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DFM_ABI_VERSION 6   /* bump whenever a struct layout or a signature in this header changes */
+#define DFM_ABI_VERSION 7   /* bump whenever a struct layout or a signature in this header changes */
 #define DFM_MAX_FIELDS 64      /* per-call pointer tables travel as kernel arguments */
 #define DFM_MAX_RANKS 64       /* data-parallel ranks of one job (csrc/shard.hip) */
 #define DFM_ROWPLAN_CHUNK 4096 /* ids per sorted list (one LDS-resident sort) */
@@ -563,12 +563,56 @@ typedef struct dfm_slab_ref {
 } dfm_slab_ref;
 int dfm_linear_backward_finish(const dfm_slab_ref* refs, int count, dfm_stream_t stream);
 /* Number of batch splits (slabs) dfm_linear_backward leaves in its workspace for this shape. */
-/* Arithmetic of dfm_linear_backward's two GEMMs (the DNN tower's backward, dnn.py:45-59 under autograd): 0 = exact
- * fp32 matrix pipe (default), 1 = bf16 x 3 split on the bf16 pipe (fp32 accumulate, 2^-16 per product) — the
- * forward (dfm_linear_bn_forward, dfm_gemm_f32) always runs exact fp32, so ReLU / dropout masks never change.
- * Process-wide, explicit; applies to calls enqueued afterwards (a captured graph keeps what it captured). */
+/* Arithmetic of the DNN tower's GEMMs (dnn.py:45-59): 0 = exact fp32 matrix pipe; 1 = fp32 forward, bf16 x 3 split
+ * (fp32 accumulate, 2^-16 per product) inside dfm_linear_backward — ReLU / dropout masks never change; 2 = bf16 x 6
+ * (every fp32 operand split exactly into three bf16 values, the six largest partial products kept: 2^-23 per
+ * product, i.e. fp32-faithful) forward and backward — the fused training steps then run the tower through the
+ * *_x6 / *_planes entry points below; the library only records the choice.
+ * Process-wide, explicit; applies to steps built / calls enqueued afterwards (a captured graph keeps what it
+ * captured). */
 int dfm_tower_set_mode(int mode);
 int dfm_tower_get_mode(void);
+
+/* ---- bf16 x 6 tower (csrc/gemm_x6.h, tower.hip): operands of the tower's GEMMs as "planes" ---------------------
+ * A plane set holds an fp32 matrix split exactly into three bf16 matrices (x = h + m + l), laid out for one
+ * contraction: bf16 [3][G][Rp][8], G = 8 ceil(contraction / 64), Rp = 64 ceil(rows / 64).  "Role F" of a
+ * [rows][cols] matrix contracts over its columns (x in z = x W^T; d z in d x = d z W), "role S" over its rows
+ * (d z and x in d W = d z^T x; W in d x = d z W).  Buffers are dfm_planes_bytes(rows, contraction) bytes and must be
+ * ZERO-FILLED once by the caller (pads are never written and must read as zero). */
+size_t dfm_planes_bytes(int64_t rows, int64_t contraction);
+int dfm_tower_x6_supported(int64_t batch, int out_features, int in_features);   /* batch % 64, features % 8 */
+typedef struct {
+  const float* src;        /* [rows][cols] row-major, 16-byte aligned, cols % 4 == 0 */
+  int64_t rows, cols;
+  void* planes_f;          /* role F: dfm_planes_bytes(rows, cols); cols % 8 == 0; or NULL */
+  void* planes_s;          /* role S: dfm_planes_bytes(cols, rows); rows % 8 == 0; or NULL */
+} dfm_split_job;
+/* Up to 8 matrices in one launch (the tower's weights, once per step after the optimizer). */
+int dfm_split_planes(const dfm_split_job* jobs, int count, dfm_stream_t stream);
+/* dfm_linear_bn_forward on planes: x either fp32 (d_x, split by the kernel: the first layer's input) or role-F planes
+ * of (batch, in_features); W as role-F planes of (out_features, in_features).  Same workspace and statistics. */
+int dfm_linear_bn_forward_x6(const float* d_x, int64_t ldx, const void* d_x_planes_f, const void* d_w_planes_f,
+                             const float* d_bias, int64_t batch, int out_features, int in_features, float* d_z,
+                             void* d_workspace, dfm_stream_t stream);
+/* dfm_bn_relu_dropout_apply / dfm_bn_backward_apply that also (d_out / d_dz may be NULL: only) write their result as
+ * planes: role F of (batch, features) and role S = planes of (features, batch).  batch % 32 == 0, features % 8 == 0. */
+int dfm_bn_relu_dropout_apply_planes(const float* d_z, int64_t batch, int features, const void* d_workspace,
+                                     const float* d_gamma, const float* d_beta, float* d_mean_rstd,
+                                     float* d_running_mean, float* d_running_var, int64_t* d_num_batches,
+                                     float momentum, float eps, float p_drop, const int64_t* d_seed, int salt,
+                                     float* d_out, void* d_planes_f, void* d_planes_s, dfm_stream_t stream);
+int dfm_bn_backward_apply_planes(const dfm_bn_bwd* bn, int64_t batch, int features, const dfm_head_tail* head,
+                                 float* d_dz, void* d_planes_f, void* d_planes_s, dfm_stream_t stream);
+/* dfm_linear_backward (both parts) on planes: d z in both roles, x as role-S planes of (in_features, batch) or fp32
+ * (d_x, the first layer), W as role-S planes of (in_features, out_features).  Its own batch split:
+ * dfm_linear_backward_x6_splits slabs in a workspace of dfm_linear_backward_x6_workspace_bytes (pass the split count
+ * in dfm_slab_ref.splits). */
+int dfm_linear_backward_x6_splits(int64_t batch, int out_features, int in_features);
+size_t dfm_linear_backward_x6_workspace_bytes(int64_t batch, int out_features, int in_features);
+int dfm_linear_backward_x6(const void* d_dz_planes_f, const void* d_dz_planes_s, int64_t batch, int out_features,
+                           const float* d_x, const void* d_x_planes_s, int in_features, const void* d_w_planes_s,
+                           float* d_g_x, const dfm_bn_bwd* bn_below, const dfm_fm_bwd* fm, void* d_workspace,
+                           dfm_stream_t stream);
 
 int dfm_linear_backward_splits(int64_t batch, int out_features, int in_features);
 
