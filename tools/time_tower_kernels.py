@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Event-timed launches of the DNN tower's GEMM kernels at the headline shapes (B = 4096, 624 -> 256 -> 128 -> 64),
-exact-fp32 entry points beside the bf16 x 6 ones.  usage: python tools/time_tower_kernels.py [iters=200]"""
+exact-fp32 entry points beside the bf16 x 6 ones.  usage: python tools/time_tower_kernels.py [iters=200] [first layer in_features=624; configuration 4: 2496]"""
 import os
 import sys
 
@@ -25,13 +25,14 @@ def timed(fn, iters):
 
 def main():
     iters = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    first_in = int(sys.argv[2]) if len(sys.argv) > 2 else 624
     lib = _lib.load()
     st = _lib.stream_handle()
     B = 4096
-    dims = [624, 256, 128, 64]
+    dims = [first_in, 256, 128, 64]
     g = torch.Generator(device="cuda").manual_seed(0)
     out = []
-    for i in range(3):
+    for i in range(3 if first_in == 624 else 1):
         K, N = dims[i], dims[i + 1]
         x = torch.randn(B, K, device="cuda", generator=g)
         w = torch.randn(N, K, device="cuda", generator=g) / K ** 0.5
