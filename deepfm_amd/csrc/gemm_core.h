@@ -130,6 +130,12 @@ __device__ __forceinline__ void store_piece(float* __restrict__ lds, const float
 #ifndef GEMM_INTERLEAVE
 #define GEMM_INTERLEAVE 1
 #endif
+#ifndef GEMM_INTERLEAVE_TAIL
+#define GEMM_INTERLEAVE_TAIL 0   // 1: the checked steps (k tails, every step of a contraction shorter than 10 slices) use the gap schedule too — measured +-0 (d-input product of layer 1: 23.2 us either way; headline 0.2046 / 0.2045 ms)
+#endif
+#ifndef GEMM_ABLATE
+#define GEMM_ABLATE 0    // timing-only builds (tools/build_variant.sh), steady state of the fp32 loop: 1 no MFMAs, 2 no global loads, 4 no LDS stores, 8 no fragment reads, 16 no barrier
+#endif
 
 // The whole k loop of one output tile.  On return `acc` is complete in the waves with
 // pos.khalf == 0; every wave has passed the same barriers and `sm` is free for the epilogue.
@@ -171,7 +177,7 @@ __device__ __forceinline__ void pipe_step(const float* __restrict__ A, int64_t l
   constexpr bool kBareA = !CHECK && A_FAST, kBareB = !CHECK && B_FAST;
   if (CHECK && kc >= ke) return;
   float na[kFrag], nb[kFrag];
-  if constexpr (GEMM_INTERLEAVE && !CHECK) {
+  if constexpr (GEMM_INTERLEAVE && (!CHECK || GEMM_INTERLEAVE_TAIL)) {
     // Steady state, interleaved (round 3): the 8 MFMAs of a slice are one dependent chain — the wave sits at each
     // of them for its 64-cycle pass — and everything else of the step is independent of it (the NEXT slice's
     // fragment reads, the slice after's LDS writes, a far slice's global loads).  Issued in front of the chain they
@@ -182,9 +188,10 @@ __device__ __forceinline__ void pipe_step(const float* __restrict__ A, int64_t l
     const float* pb = sm.b[b1] + (pos.wn + pos.r) * LDS_STRIDE + pos.hf + pos.khalf * (BK / 2);
     static_assert(kFrag == 8, "the gap schedule below is written for 8 MFMAs per slice");
 #define DFM_GAP(I, STORE)                                                                   \
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[I], fb[I], acc, 0, 0, 0);                 \
-    na[I] = pa[2 * (I)]; nb[I] = pb[2 * (I)];                                               \
-    STORE;                                                                                  \
+    if (!(GEMM_ABLATE & 1)) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[I], fb[I], acc, 0, 0, 0); \
+    else acc[I] += fa[I] + fb[I];                                                            \
+    if (!(GEMM_ABLATE & 8)) { na[I] = pa[2 * (I)]; nb[I] = pb[2 * (I)]; } else { na[I] = fa[I]; nb[I] = fb[I]; } \
+    if (!(GEMM_ABLATE & 4)) { STORE; }                                                      \
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_sched_barrier(0);
     DFM_GAP(0, (store_piece<A_KC, !kBareA, 0>(sm.a[b2], va[slot], oka[slot])))
@@ -197,10 +204,12 @@ __device__ __forceinline__ void pipe_step(const float* __restrict__ A, int64_t l
     DFM_GAP(7, (store_piece<B_KC, !kBareB, 3>(sm.b[b2], vb[slot], okb[slot])))
 #undef DFM_GAP
     // the slot is free now: slice s + 6 on its way
+    if (!(GEMM_ABLATE & 2)) {
     if (kBareA) { va[slot] = spa.load(kc + (kPrefetch + 2) * BK); oka[slot] = true; }
     else load_slice<A_KC, A_FAST>(A, lda, m0, M, kc + (kPrefetch + 2) * BK, ke, va[slot], oka[slot]);
     if (kBareB) { vb[slot] = spb.load(kc + (kPrefetch + 2) * BK); okb[slot] = true; }
     else load_slice<B_KC, B_FAST>(B, ldb, n0, N, kc + (kPrefetch + 2) * BK, ke, vb[slot], okb[slot]);
+    }
     __builtin_amdgcn_sched_barrier(0);
   } else {
 #pragma unroll
@@ -223,7 +232,7 @@ __device__ __forceinline__ void pipe_step(const float* __restrict__ A, int64_t l
   for (int i = 0; i < kFrag; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[i], acc, 0, 0, 0);
   __builtin_amdgcn_sched_barrier(0);
   }
-  __syncthreads();
+  if (!(GEMM_ABLATE & 16) || CHECK) __syncthreads();
 #pragma unroll
   for (int i = 0; i < kFrag; ++i) { fa[i] = na[i]; fb[i] = nb[i]; }
 }
