@@ -453,32 +453,50 @@ def main():
             return [("timed" if k < n_timed else "single", lo + k) for k in range(n)]
         n_timed = min(n_timed, n)
         groups = (n - n_timed) // G
-        # the timed single steps OPEN the region: their ~0.5 ms of device time covers the host-side preparation of
-        # the first multi-step graph launch (three node updates per step + the launch of ~100 nodes: ~0.4 ms), which
-        # would otherwise leave the device idle right after the region's opening synchronisation (measured: one single
-        # in front instead of two costs the 20-step region 0.009 ms per step)
+        # groups first, the timed single steps CLOSE the region: the host enqueues their eager launches while the last
+        # group is still on the device.  (Round 3 had them open the region, where their ~0.5 ms of device time covered
+        # the host-side preparation of the first group launch — three node updates per step + the launch of ~100
+        # nodes, ~0.4 ms during which the device sat idle behind the opening synchronisation.  That preparation now
+        # happens BEFORE the synchronisation, RowSparseTrainStep.prepare_group: as in a training loop, where launch
+        # k + 1 is prepared while launch k runs.)
         out, i = [], lo
-        for _ in range(n_timed):
-            out.append(("timed", i)); i += 1
         for _ in range(groups):
             out.append(("group", i)); i += G
+        for _ in range(n_timed):
+            out.append(("timed", i)); i += 1
         while i < hi:
             out.append(("single", i)); i += 1
         return out
 
-    def execute(p, after=None):
-        """``after``: record index the launch that follows this plan starts with (None: unknown)."""
+    def group_args(p, j, after):
+        i = p[j][1]
+        nxt = p[j + 1][1] if j + 1 < len(p) else after
+        # the launch's last optimizer kernel also sorts the NEXT launch's first batch (training/step.py)
+        return [rec(i + k) for k in range(G)], (records[nxt] if (nxt is not None and feed is None) else None)
+
+    def execute(p, after=None, first_prepared=False):
+        """``after``: record index the launch that follows this plan starts with (None: unknown).
+        ``first_prepared``: the plan's first launch is a group whose host half ran already (prepare_first)."""
         for j, (kind, i) in enumerate(p):
-            nxt = p[j + 1][1] if j + 1 < len(p) else after
             if kind == "group":
                 if G > 1:
-                    # the launch's last optimizer kernel also sorts the NEXT launch's first batch (training/step.py)
-                    step.run_group([rec(i + k) for k in range(G)],
-                                   next_record=records[nxt] if (nxt is not None and feed is None) else None)
+                    if j == 0 and first_prepared:
+                        step.launch_prepared()
+                    else:
+                        recs, nxt = group_args(p, j, after)
+                        step.run_group(recs, next_record=nxt)
                 else:
                     step.run_from(rec(i))
             else:
                 step.run_from(rec(i), eager_gather=not args.no_graph)
+
+    def prepare_first(p, after=None):
+        """Host half of the plan's first launch, if that is a multi-step graph launch on resident records."""
+        if p and p[0][0] == "group" and G > 1 and feed is None and getattr(step, "slots", None):
+            recs, nxt = group_args(p, 0, after)
+            step.prepare_group(recs, next_record=nxt)
+            return True
+        return False
 
     if G > 1 and args.warmup < 2 * G and feed is None:
         # both instantiated copies of the step graph get one untimed launch (their first launch uploads the exec): W can
@@ -498,8 +516,13 @@ def main():
     n_timed = sum(1 for kind, _ in timed_plan if kind == "timed")
     if n_timed:
         _lib.check(lib.dfm_gather_timing_begin(n_timed))
+    prepared = prepare_first(timed_plan)        # node updates of the first launch: host work, nothing enqueued
+    if prepared:
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
-    execute(timed_plan)
+    execute(timed_plan, first_prepared=prepared)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -572,6 +595,10 @@ def main():
                                                 f" ({'field-sharded tables, 3 all-to-alls + 1 small all-gather per step' if step.exchange_in_body else 'replicated tables, one grouped all-gather per step'})"),
                 "hip_graph": bool(step.use_graph and not args.no_graph),
                 "steps_per_graph": G,
+                "region": ("graph launches of %d steps, then %d single step(s) with the gather dispatch event-timed" % (G, n_timed)
+                           if G > 1 else "single steps") +
+                          ("; the node updates of the first launch (host work) precede the opening synchronisation, as "
+                           "every later launch's overlap the launch before it" if prepared else ""),
                 "capture_fallback": capture_fallback,
                 "rowplan": ("inside the previous step's apply launch for steps 2.. of a graph; first step: "
                             if getattr(step, "_plan_sets", None) else "") +

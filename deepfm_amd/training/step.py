@@ -128,6 +128,7 @@ class RowSparseTrainStep:
         self._plan_sets = None
         self.cont_slots: List[_GraphSlot] = []
         self._turn_cont = 0
+        self._prepared = None                        # graph slot whose nodes prepare_group() has pointed at its records
         self._handoff_ptr: Optional[int] = None      # record (data_ptr) whose plan the previous launch left in the hand-off set
         self._record: torch.Tensor = self.inbox       # batch record the next gather reads
         F, D = len(specs), self.emb.fm_embed_dim
@@ -425,7 +426,7 @@ class RowSparseTrainStep:
         torch.cuda.synchronize()
         self.slots, self.body_graph, self.graph_b = [], None, None
         self.cont_slots, self._turn_cont, self._handoff_ptr = [], 0, None
-        self.steps_per_graph, self._turn = 1, 0
+        self.steps_per_graph, self._turn, self._prepared = 1, 0, None
         import gc
         gc.collect()
         torch.cuda.synchronize()
@@ -474,7 +475,32 @@ class RowSparseTrainStep:
                 raise ValueError("run_group expects contiguous, 16-byte aligned pack_batches() records")
         self._launch(list(records), next_record)
 
+    def prepare_group(self, records, next_record: Optional[torch.Tensor] = None) -> None:
+        """The host half of ``run_group``: picks the graph copy, waits for its last launch and points its nodes at
+        ``records`` — everything but the launch itself, which ``launch_prepared()`` does.  A training loop calls this
+        for launch k + 1 while launch k is on the device (two copies of the graph alternate for that); ``run_group``
+        is the two calls back to back."""
+        if len(records) != self.steps_per_graph or not self.slots:
+            raise ValueError(f"prepare_group needs captured graphs of {len(records)} steps")
+        if self._prepared is not None:
+            raise RuntimeError("a prepared launch is pending: call launch_prepared() first")
+        self._prepared = self._prepare(list(records), next_record)
+
+    def launch_prepared(self) -> None:
+        if self._prepared is None:
+            raise RuntimeError("nothing prepared")
+        slot, self._prepared = self._prepared, None
+        slot.graph.replay()
+        self._after_graph_a(slot.done)
+
     def _launch(self, records, next_record: Optional[torch.Tensor] = None) -> None:
+        if self._prepared is not None:
+            raise RuntimeError("a prepared launch is pending: call launch_prepared() first")
+        slot = self._prepare(records, next_record)
+        slot.graph.replay()
+        self._after_graph_a(slot.done)
+
+    def _prepare(self, records, next_record: Optional[torch.Tensor] = None):
         cont = bool(self.cont_slots) and self._handoff_ptr is not None and self._handoff_ptr == records[0].data_ptr()
         if cont:
             slot = self.cont_slots[self._turn_cont]
@@ -493,8 +519,7 @@ class RowSparseTrainStep:
                 nxt = records[k + 1] if k + 1 < len(records) else (next_record if next_record is not None else records[0])
                 self.opt.apply_plan_update(ex, apply_node, cur, nxt.data_ptr() + self._rec_id_offsets[0], target)
         self._handoff_ptr = next_record.data_ptr() if (next_record is not None and self.cont_slots) else None
-        slot.graph.replay()
-        self._after_graph_a(slot.done)
+        return slot
 
     def _after_graph_a(self, done) -> None:
         if self.graph_b is not None:
