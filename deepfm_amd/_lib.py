@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("DFM_LIB_PATH") or os.path.join(_HERE, "lib", "libdeep
 # == DFM_ABI_VERSION of include/deepfm_hip.h at the time SIGNATURES / the ctypes structs below were written:
 # bumped together with the header whenever a struct layout or an argument list changes, so that a stale .so
 # (the library is untracked and DFM_LIB_PATH can point anywhere) is refused instead of fed shifted arguments
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 MAX_FIELDS = 64
 MAX_RANKS = 64
@@ -75,6 +75,13 @@ class SplitJob(C.Structure):
     """struct dfm_split_job"""
     _fields_ = [("src", C.c_void_p), ("rows", C.c_int64), ("cols", C.c_int64), ("planes_f", C.c_void_p),
                 ("planes_s", C.c_void_p)]
+
+
+class PartialJob(C.Structure):
+    """struct dfm_partial_job"""
+    _fields_ = [("kind", C.c_int32), ("blocks", C.c_int32), ("n1", C.c_int32), ("n2", C.c_int32),
+                ("accumulate", C.c_int32), ("reserved", C.c_int32), ("partial", C.c_void_p), ("out_w", C.c_void_p),
+                ("out_b", C.c_void_p), ("ldw", C.c_int64)]
 
 
 class HeadTail(C.Structure):
@@ -173,6 +180,10 @@ SIGNATURES = {
                                  _L, _I, _P, _L, _P, _I, _L, _P, _P, _P, _P, _P, _P]),
     "dfm_step_apply_plan_update": (_I, [_P, _P, C.POINTER(Table), _I, _I, _I, _P, _P, _P, _P, _P, _P, _F, _F, _F, _F, _P,
                                         _P, _P, _P, _P, _L, _I, _P, _L, _P, _I, _L, _P, _P, _P, _P, _P]),
+    "dfm_weight_grad_partial_blocks": (_I, [_L]),
+    "dfm_weight_grad_partials_f32": (_I, [_P, _L, _P, _L, _L, _I, _I, _P, _P]),
+    "dfm_layernorm_partial_blocks": (_I, [_L]),
+    "dfm_partials_finish": (_I, [C.POINTER(PartialJob), _I, _P]),
     "dfm_tower_set_mode": (_I, [_I]),
     "dfm_tower_get_mode": (_I, []),
     "dfm_planes_bytes": (_SZ, [_L, _L]),

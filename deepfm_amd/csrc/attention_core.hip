@@ -10,6 +10,7 @@
 //   * layernorm_fwd / layernorm_bwd: LayerNorm(out + x) over D (:117-118), one row per lane
 //     group, parameter gradients as fixed-order partial sums.
 #include "common.h"
+#include "partial_reduce.h"
 
 using namespace dfm;
 
@@ -431,23 +432,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_finalize(const float* __res
                                                               float* __restrict__ d_gamma,
                                                               float* __restrict__ d_beta) {
   __shared__ float red[2][256];
-  const int d = blockIdx.x, t = threadIdx.x;
-  float sg = 0.f, sb = 0.f;
-  for (int i = t; i < blocks; i += 256) {
-    sg += partial[(static_cast<int64_t>(i) * 2 + 0) * D + d];
-    sb += partial[(static_cast<int64_t>(i) * 2 + 1) * D + d];
-  }
-  red[0][t] = sg;
-  red[1][t] = sb;
-  __syncthreads();
-  for (int w = 128; w > 0; w >>= 1) {
-    if (t < w) { red[0][t] += red[0][t + w]; red[1][t] += red[1][t + w]; }
-    __syncthreads();
-  }
-  if (t == 0) {
-    d_gamma[d] += red[0][0];
-    d_beta[d] += red[1][0];
-  }
+  partials::layernorm_finalize_body(blockIdx.x, partial, blocks, D, d_gamma, d_beta, red);
 }
 
 namespace {
@@ -659,8 +644,8 @@ extern "C" int dfm_layernorm_backward(const float* d_g_out, const float* d_y, co
                                       const float* d_stats, int64_t rows, int dim, const float* d_gamma,
                                       float* d_g_sum, float* d_g_gamma, float* d_g_beta, void* d_workspace,
                                       int64_t g_group_rows, int64_t g_group_stride, dfm_stream_t stream) {
-  DFM_REQUIRE(d_g_out && d_y && d_res && d_stats && d_gamma && d_g_sum && d_g_gamma && d_g_beta && d_workspace,
-              "null argument");
+  DFM_REQUIRE(d_g_out && d_y && d_res && d_stats && d_gamma && d_g_sum && d_workspace, "null argument");
+  DFM_REQUIRE((d_g_gamma != nullptr) == (d_g_beta != nullptr), "d_g_gamma and d_g_beta: both or (deferred finish) none");
   DFM_REQUIRE(rows >= 0 && dim > 0 && dim <= 64, "LayerNorm kernel supports 1 <= dim <= 64");
   DFM_REQUIRE(g_group_rows >= 0 && (g_group_rows == 0 || (g_group_stride >= g_group_rows * dim && g_group_stride % 4 == 0)),
               "bad gradient grouping");
@@ -678,8 +663,13 @@ extern "C" int dfm_layernorm_backward(const float* d_g_out, const float* d_y, co
     hipLaunchKernelGGL(layernorm_bwd, dim3(blocks), dim3(256), 0, st, d_g_out, d_y, d_res, d_stats, rows, dim,
                        ln_lanes(dim), d_gamma, d_g_sum, partial);
   DFM_LAUNCH_CHECK();
+  if (!d_g_gamma) return DFM_OK;        // deferred: dfm_partials_finish (kind 1, blocks = dfm_layernorm_partial_blocks(rows))
   hipLaunchKernelGGL(layernorm_bwd_finalize, dim3(dim), dim3(256), 0, st, partial, blocks, dim,
                      d_g_gamma, d_g_beta);
   DFM_LAUNCH_CHECK();
   return DFM_OK;
+}
+
+extern "C" int dfm_layernorm_partial_blocks(int64_t rows) {
+  return rows > 0 ? static_cast<int>((rows + kLnRows - 1) / kLnRows) : 0;
 }

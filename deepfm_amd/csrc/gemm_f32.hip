@@ -85,7 +85,7 @@ bool gemm_rows_try(const float* A, int64_t lda, const float* W, int64_t ldw, boo
 bool gemm_wgrad_supported(int64_t M, int N1, int N2);
 size_t gemm_wgrad_workspace_bytes(int64_t M, int N1, int N2);
 bool gemm_wgrad_try(const float* G, int64_t ldg, const float* X, int64_t ldx, int64_t M, int N1, int N2,
-                    float* dW, int64_t ldw, float* db, int accumulate, void* workspace, hipStream_t st);
+                    float* dW, int64_t ldw, float* db, int accumulate, void* workspace, hipStream_t st, bool defer);
 }  // namespace dfm
 
 namespace {
@@ -123,7 +123,7 @@ extern "C" int dfm_gemm_f32(const float* d_a, int64_t lda, int a_k_contiguous, c
   }
   if (!a_k_contiguous && !b_k_contiguous && !d_bias &&
       dfm::gemm_wgrad_try(d_a, lda, d_b, ldb, k, m, n, d_c, ldc, nullptr, accumulate, d_workspace,
-                          as_stream(stream))) {
+                          as_stream(stream), false)) {
     DFM_LAUNCH_CHECK();
     return DFM_OK;
   }

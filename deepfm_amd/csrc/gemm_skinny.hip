@@ -20,6 +20,7 @@
 // 256 VGPRs the extra registers are AGPRs, which loads and VALU reach only through copies —
 // weight gradient 59 -> 167 us, K = 192 rows kernel 55 -> 69 us.)
 #include "common.h"
+#include "partial_reduce.h"
 
 using namespace dfm;
 
@@ -234,38 +235,36 @@ __global__ __launch_bounds__(kWaves * 64, 2) void gemm_wgrad_kernel(
   }
 }
 
-// out[e] (+)= sum_blocks partial[block][e]  (fixed order); the last N1 entries go to db.
-// 64 elements per workgroup, four threads per element: thread (e, g) adds blocks g, g+4, g+8, ... and
-// the four sums are added in the order g = 0,1,2,3.
+// out[e] (+)= sum_blocks partial[block][e]  (fixed order); the last N1 entries go to db (partial_reduce.h).
 __global__ __launch_bounds__(256) void gemm_wgrad_reduce(const float* __restrict__ partial, int blocks, int n1n2,
                                                          int n1, int N2, float* __restrict__ dW, int64_t ldw,
                                                          float* __restrict__ db, int accumulate) {
   __shared__ float part[4][64];
-  const int el = threadIdx.x & 63, g = threadIdx.x >> 6;
-  const int e = blockIdx.x * 64 + el;
-  const int total = n1n2 + n1;
-  float acc = 0.f;
-  if (e < total) {
-    int s = g;
-    for (; s + 28 < blocks; s += 32) {
-      float t[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) t[u] = partial[static_cast<int64_t>(s + 4 * u) * total + e];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) acc += t[u];
-    }
-    for (; s < blocks; s += 4) acc += partial[static_cast<int64_t>(s) * total + e];
-  }
-  part[g][el] = acc;
-  __syncthreads();
-  if (g != 0 || e >= total) return;
-  acc = ((part[0][el] + part[1][el]) + part[2][el]) + part[3][el];
-  if (e < n1n2) {
-    float* dst = dW + static_cast<int64_t>(e / N2) * ldw + e % N2;
-    *dst = accumulate ? *dst + acc : acc;
-  } else if (db) {
-    db[e - n1n2] = accumulate ? db[e - n1n2] + acc : acc;
-  }
+  partials::wgrad_reduce_body(blockIdx.x, partial, blocks, n1n2, n1, N2, dW, ldw, db, accumulate, part);
+}
+
+// several finishes in one launch: job j owns workgroups [first_block[j], first_block[j + 1])
+constexpr int kMaxPartialJobs = 8;
+struct PartialJobs {
+  const float* partial[kMaxPartialJobs];
+  float* out_w[kMaxPartialJobs];
+  float* out_b[kMaxPartialJobs];
+  int64_t ldw[kMaxPartialJobs];
+  int kind[kMaxPartialJobs], blocks[kMaxPartialJobs], n1[kMaxPartialJobs], n2[kMaxPartialJobs], accumulate[kMaxPartialJobs];
+  int first_block[kMaxPartialJobs + 1];
+  int count;
+};
+__global__ __launch_bounds__(256) void partials_finish_kernel(PartialJobs jobs) {
+  __shared__ float red[2][256];
+  int j = 0;
+  while (j + 1 < jobs.count && static_cast<int>(blockIdx.x) >= jobs.first_block[j + 1]) ++j;
+  const int blk = blockIdx.x - jobs.first_block[j];
+  if (jobs.kind[j] == 0)
+    partials::wgrad_reduce_body(blk, jobs.partial[j], jobs.blocks[j], jobs.n1[j] * jobs.n2[j], jobs.n1[j], jobs.n2[j],
+                                jobs.out_w[j], jobs.ldw[j], jobs.out_b[j], jobs.accumulate[j],
+                                reinterpret_cast<float (*)[64]>(&red[0][0]));
+  else
+    partials::layernorm_finalize_body(blk, jobs.partial[j], jobs.blocks[j], jobs.n1[j], jobs.out_w[j], jobs.out_b[j], red);
 }
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -327,7 +326,7 @@ bool gemm_wgrad_supported(int64_t M, int N1, int N2) {
 
 // dW (+)= G^T X, db (+)= column sums of G (db may be null); false if the shape is not taken
 bool gemm_wgrad_try(const float* G, int64_t ldg, const float* X, int64_t ldx, int64_t M, int N1, int N2,
-                    float* dW, int64_t ldw, float* db, int accumulate, void* workspace, hipStream_t st) {
+                    float* dW, int64_t ldw, float* db, int accumulate, void* workspace, hipStream_t st, bool defer) {
   if (!workspace || !gemm_wgrad_supported(M, N1, N2)) return false;
   int cpw;
   const int blocks = wgrad_blocks(M, &cpw);
@@ -338,10 +337,15 @@ bool gemm_wgrad_try(const float* G, int64_t ldg, const float* X, int64_t ldx, in
     hipLaunchKernelGGL((gemm_wgrad_kernel<T1_, T2_>), grid, block, 0, st, G, ldg, X, ldx, M, partial, cpw);
   DFM_WG(6, 1) DFM_WG(1, 2) DFM_WG(1, 1) DFM_WG(2, 1) DFM_WG(3, 1) DFM_WG(2, 2) DFM_WG(1, 3)
 #undef DFM_WG
+  if (defer) return true;               // the partials stay in the workspace: dfm_partials_finish
   const int total = N1 * N2 + N1;
   hipLaunchKernelGGL(gemm_wgrad_reduce, dim3((total + 63) / 64), dim3(256), 0, st, partial, blocks, N1 * N2, N1,
                      N2, dW, ldw, db, accumulate);
   return true;
+}
+int gemm_wgrad_partial_blocks(int64_t M) {
+  int cpw;
+  return wgrad_blocks(M, &cpw);
 }
 }  // namespace dfm
 
@@ -355,9 +359,44 @@ extern "C" int dfm_weight_grad_f32(const float* d_g, int64_t ldg, const float* d
   DFM_REQUIRE(d_g && d_x && d_dw, "null argument");
   DFM_REQUIRE(rows > 0 && n1 > 0 && n2 > 0, "bad shape");
   if (!dfm::gemm_wgrad_try(d_g, ldg, d_x, ldx, rows, n1, n2, d_dw, lddw, d_db, accumulate, d_workspace,
-                           as_stream(stream)))
+                           as_stream(stream), false))
     return fail(DFM_ERR_UNSUPPORTED, "dfm_weight_grad_f32: no kernel for rows=%lld n1=%d n2=%d (workspace %p)",
                 (long long)rows, n1, n2, d_workspace);
+  DFM_LAUNCH_CHECK();
+  return DFM_OK;
+}
+
+// The streamed pass of dfm_weight_grad_f32 alone: per-workgroup partials [blocks][n1 * n2 + n1] stay in the workspace
+// for dfm_partials_finish (kind 0 with blocks = dfm_weight_grad_partial_blocks(rows)).
+extern "C" int dfm_weight_grad_partial_blocks(int64_t rows) { return rows > 0 ? dfm::gemm_wgrad_partial_blocks(rows) : 0; }
+extern "C" int dfm_weight_grad_partials_f32(const float* d_g, int64_t ldg, const float* d_x, int64_t ldx, int64_t rows,
+                                            int n1, int n2, void* d_workspace, dfm_stream_t stream) {
+  DFM_REQUIRE(d_g && d_x && d_workspace, "null argument");
+  DFM_REQUIRE(rows > 0 && n1 > 0 && n2 > 0, "bad shape");
+  if (!dfm::gemm_wgrad_try(d_g, ldg, d_x, ldx, rows, n1, n2, nullptr, 0, nullptr, 0, d_workspace, as_stream(stream), true))
+    return fail(DFM_ERR_UNSUPPORTED, "dfm_weight_grad_partials_f32: no kernel for rows=%lld n1=%d n2=%d",
+                (long long)rows, n1, n2);
+  DFM_LAUNCH_CHECK();
+  return DFM_OK;
+}
+
+extern "C" int dfm_partials_finish(const dfm_partial_job* jobs, int count, dfm_stream_t stream) {
+  DFM_REQUIRE(jobs && count >= 1 && count <= kMaxPartialJobs, "1 to %d jobs", kMaxPartialJobs);
+  PartialJobs pj = {};
+  int blocks = 0;
+  for (int i = 0; i < count; ++i) {
+    const dfm_partial_job& j = jobs[i];
+    DFM_REQUIRE(j.kind == 0 || j.kind == 1, "job %d: kind 0 (weight gradient) or 1 (LayerNorm)", i);
+    DFM_REQUIRE(j.partial && j.out_w && j.blocks > 0 && j.n1 > 0, "job %d: incomplete", i);
+    DFM_REQUIRE(j.kind == 0 ? (j.n2 > 0 && j.ldw >= j.n2) : (j.out_b != nullptr), "job %d: incomplete", i);
+    pj.partial[i] = j.partial; pj.out_w[i] = j.out_w; pj.out_b[i] = j.out_b; pj.ldw[i] = j.ldw;
+    pj.kind[i] = j.kind; pj.blocks[i] = j.blocks; pj.n1[i] = j.n1; pj.n2[i] = j.n2; pj.accumulate[i] = j.accumulate;
+    pj.first_block[i] = blocks;
+    blocks += j.kind == 0 ? (j.n1 * j.n2 + j.n1 + 63) / 64 : j.n1;
+  }
+  pj.first_block[count] = blocks;
+  pj.count = count;
+  hipLaunchKernelGGL(partials_finish_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, as_stream(stream), pj);
   DFM_LAUNCH_CHECK();
   return DFM_OK;
 }

@@ -15,6 +15,7 @@ import ctypes as C
 import math
 
 import torch
+from typing import Optional
 import torch.nn as nn
 
 from deepfm_amd import _lib
@@ -107,17 +108,36 @@ def _ptrs(tensors):
 
 
 def _weight_grad(g: torch.Tensor, x: torch.Tensor, rows: int, n1: int, n2: int, d_w: torch.Tensor,
-                 d_b: torch.Tensor) -> bool:
+                 d_b: torch.Tensor, finish: Optional[list] = None) -> bool:
     """dW = g^T x and db = column sums of g in one streamed pass (csrc/gemm_skinny.hip) when the shape
-    is one the kernel takes; False -> the caller uses the general GEMM (+ a ones-column GEMM)."""
+    is one the kernel takes; False -> the caller uses the general GEMM (+ a ones-column GEMM).
+    ``finish``: a list -> only the streamed pass runs and the reduction of its partial sums is appended
+    as a job for ``_finish_partials`` (one launch for all of a block's reductions)."""
     lib = _lib.load()
     ws_bytes = lib.dfm_weight_grad_workspace_bytes(rows, n1, n2)
     if not ws_bytes:
         return False
     ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=g.device)
-    _lib.check(lib.dfm_weight_grad_f32(g.data_ptr(), n1, x.data_ptr(), n2, rows, n1, n2, d_w.data_ptr(), n2,
-                                       d_b.data_ptr(), 0, ws.data_ptr(), _lib.stream_handle()))
+    if finish is None:
+        _lib.check(lib.dfm_weight_grad_f32(g.data_ptr(), n1, x.data_ptr(), n2, rows, n1, n2, d_w.data_ptr(), n2,
+                                           d_b.data_ptr(), 0, ws.data_ptr(), _lib.stream_handle()))
+        return True
+    _lib.check(lib.dfm_weight_grad_partials_f32(g.data_ptr(), n1, x.data_ptr(), n2, rows, n1, n2, ws.data_ptr(),
+                                                _lib.stream_handle()))
+    finish.append(dict(kind=0, blocks=lib.dfm_weight_grad_partial_blocks(rows), n1=n1, n2=n2, accumulate=0,
+                       partial=ws, out_w=d_w.data_ptr(), out_b=d_b.data_ptr(), ldw=n2))
     return True
+
+
+def _finish_partials(jobs: list) -> None:
+    """The deferred reductions of a backward pass (weight-gradient partials, LayerNorm partials) in ONE launch."""
+    if not jobs:
+        return
+    arr = (_lib.PartialJob * len(jobs))()
+    for a, j in zip(arr, jobs):
+        a.kind, a.blocks, a.n1, a.n2, a.accumulate = j["kind"], j["blocks"], j["n1"], j["n2"], j["accumulate"]
+        a.partial, a.out_w, a.out_b, a.ldw = j["partial"].data_ptr(), j["out_w"], j["out_b"], j["ldw"]
+    _lib.check(_lib.load().dfm_partials_finish(arr, len(jobs), _lib.stream_handle()))
 
 
 class _AttnGemmFn(torch.autograd.Function):
@@ -220,6 +240,7 @@ class _AttnGemmFn(torch.autograd.Function):
         g = g_out if g_stride else g_out.contiguous().view(M, D)
         from deepfm_amd.models.layers.linear import ones_column
         grads = []
+        finish: list = []          # deferred reductions of this block's backward: ONE launch at its end
         if block.use_residual:
             g_y = torch.empty(M, D, dtype=torch.float32, device=dev)
             if direct:                           # accumulated into: zero at this point of the step
@@ -228,15 +249,17 @@ class _AttnGemmFn(torch.autograd.Function):
                 d_gamma = torch.zeros(D, dtype=torch.float32, device=dev)
                 d_beta = torch.zeros(D, dtype=torch.float32, device=dev)
             ws = torch.empty(max(lib.dfm_layernorm_workspace_bytes(M, D) // 4, 1), dtype=torch.float32, device=dev)
+            # d gamma / d beta: the partial planes stay in ws, added by the block's one finish launch below
             _lib.check(lib.dfm_layernorm_backward(g.data_ptr(), y.data_ptr(), X.data_ptr(), stats.data_ptr(), M, D,
-                                                  gamma.data_ptr(), g_y.data_ptr(), d_gamma.data_ptr(),
-                                                  d_beta.data_ptr(), ws.data_ptr(), F if g_stride else 0, g_stride,
-                                                  _lib.stream_handle()))
+                                                  gamma.data_ptr(), g_y.data_ptr(), None, None, ws.data_ptr(),
+                                                  F if g_stride else 0, g_stride, _lib.stream_handle()))
+            finish.append(dict(kind=1, blocks=lib.dfm_layernorm_partial_blocks(M), n1=D, n2=0, accumulate=1,
+                               partial=ws, out_w=d_gamma.data_ptr(), out_b=d_beta.data_ptr(), ldw=0))
         else:
             g_y = g
         d_wo = block.W_out.weight.grad if direct else torch.empty(D, A, dtype=torch.float32, device=dev)
         d_bo = block.W_out.bias.grad.view(D, 1) if direct else torch.empty(D, 1, dtype=torch.float32, device=dev)
-        if not _weight_grad(g_y, o, M, D, A, d_wo, d_bo):
+        if not _weight_grad(g_y, o, M, D, A, d_wo, d_bo, finish):
             _gemm(g_y, D, False, o, A, False, d_wo, D, A, M)                     # dWo = g_y^T O
             _gemm(g_y, D, False, ones_column(M, dev), 1, False, d_bo, D, 1, M)
         d_qkv = torch.empty(M, 3 * A, dtype=torch.float32, device=dev)
@@ -265,9 +288,10 @@ class _AttnGemmFn(torch.autograd.Function):
             else:
                 _lib.check(lib.dfm_attention_core_backward(qkv.data_ptr(), d_o.data_ptr(), B, F, A, H,
                                                            d_qkv.data_ptr(), _lib.stream_handle()))
-        if not _weight_grad(d_qkv, X, M, 3 * A, D, d_wqkv, d_bqkv):
+        if not _weight_grad(d_qkv, X, M, 3 * A, D, d_wqkv, d_bqkv, finish):
             _gemm(d_qkv, 3 * A, False, X, D, False, d_wqkv, 3 * A, D, M)         # dWqkv = dQKV^T X
             _gemm(d_qkv, 3 * A, False, ones_column(M, dev), 1, False, d_bqkv, 3 * A, 1, M)
+        _finish_partials(finish)
         if whole:
             pass
         elif block.use_residual:

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DFM_ABI_VERSION 7   /* bump whenever a struct layout or a signature in this header changes */
+#define DFM_ABI_VERSION 8   /* bump whenever a struct layout or a signature in this header changes */
 #define DFM_MAX_FIELDS 64      /* per-call pointer tables travel as kernel arguments */
 #define DFM_MAX_RANKS 64       /* data-parallel ranks of one job (csrc/shard.hip) */
 #define DFM_ROWPLAN_CHUNK 4096 /* ids per sorted list (one LDS-resident sort) */
@@ -713,6 +713,29 @@ size_t dfm_weight_grad_workspace_bytes(int64_t rows, int n1, int n2);
 int dfm_weight_grad_f32(const float* d_g, int64_t ldg, const float* d_x, int64_t ldx, int64_t rows, int n1,
                         int n2, float* d_dw, int64_t lddw, float* d_db, int accumulate, void* d_workspace,
                         dfm_stream_t stream);
+/* Deferred finish: dfm_weight_grad_partials_f32 runs the streamed pass only and leaves
+ * dfm_weight_grad_partial_blocks(rows) partial rows of n1 * n2 + n1 floats in the workspace; dfm_layernorm_backward
+ * with d_g_gamma == d_g_beta == NULL leaves dfm_layernorm_partial_blocks(rows) partial planes [2][dim] in its
+ * workspace.  dfm_partials_finish then adds up to 8 such sets in ONE launch (same fixed order as the stand-alone
+ * finishes: bit-identical) — an attention block's backward (attention.py:91-120 under autograd) ends in one
+ * reduction launch instead of three. */
+int dfm_weight_grad_partial_blocks(int64_t rows);
+int dfm_weight_grad_partials_f32(const float* d_g, int64_t ldg, const float* d_x, int64_t ldx, int64_t rows, int n1,
+                                 int n2, void* d_workspace, dfm_stream_t stream);
+int dfm_layernorm_partial_blocks(int64_t rows);
+typedef struct {
+  int32_t kind;            /* 0: weight gradient partials -> out_w = dW (row stride ldw), out_b = db or NULL;
+                            * 1: LayerNorm partials -> out_w = d gamma, out_b = d beta (always accumulated into) */
+  int32_t blocks;          /* partial rows */
+  int32_t n1, n2;          /* kind 0: dW is n1 x n2; kind 1: n1 = dim */
+  int32_t accumulate;      /* kind 0: 0 store, 1 add */
+  int32_t reserved;
+  const float* partial;
+  float* out_w;
+  float* out_b;
+  int64_t ldw;
+} dfm_partial_job;
+int dfm_partials_finish(const dfm_partial_job* jobs, int count, dfm_stream_t stream);
 
 /* ---------------------------------------------------------------------------------
  * Field-sharded embedding tables under data parallelism (csrc/shard.hip).  The reference trains on one

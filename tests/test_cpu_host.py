@@ -23,7 +23,7 @@ def test_library_exports_every_header_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in deepfm_hip.h but not exported"
     assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
-    assert lib.dfm_abi_version() == _lib.ABI_VERSION == 7
+    assert lib.dfm_abi_version() == _lib.ABI_VERSION == 8
 
 
 def test_cin_layout_helpers_match_reference_bookkeeping():
