@@ -182,6 +182,7 @@ SIGNATURES = {
                                         _P, _P, _P, _P, _L, _I, _P, _L, _P, _I, _L, _P, _P, _P, _P, _P]),
     "dfm_weight_grad_partial_blocks": (_I, [_L]),
     "dfm_weight_grad_partials_f32": (_I, [_P, _L, _P, _L, _L, _I, _I, _P, _P]),
+    "dfm_weight_grad_partials_pair_f32": (_I, [_P, _L, _P, _L, _I, _I, _P, _P, _L, _P, _L, _I, _I, _P, _L, _P]),
     "dfm_layernorm_partial_blocks": (_I, [_L]),
     "dfm_partials_finish": (_I, [C.POINTER(PartialJob), _I, _P]),
     "dfm_tower_set_mode": (_I, [_I]),
@@ -236,6 +237,9 @@ def load() -> C.CDLL:
                               f"(stale {LIB_PATH}? rebuild with make -C deepfm_amd/csrc)")
     _lib = lib
     return lib
+
+
+ERR_UNSUPPORTED = 3        # enum dfm_status: DFM_ERR_UNSUPPORTED
 
 
 def check(rc: int) -> None:

@@ -133,15 +133,14 @@ __global__ __launch_bounds__(kWaves * 64, 2) void gemm_rows_kernel(
 // ---- weight-gradient kernel ----------------------------------------------------------------------
 // partial[block][N1*N2 + N1]: the workgroup's dW (row-major N1 x N2) followed by its db
 template <int T1, int T2>
-__global__ __launch_bounds__(kWaves * 64, 2) void gemm_wgrad_kernel(
+__device__ __forceinline__ void gemm_wgrad_body(
     const float* __restrict__ G, int64_t ldg, const float* __restrict__ X, int64_t ldx, int64_t M,
-    float* __restrict__ partial, int chunks_per_wave) {
+    float* __restrict__ partial, int chunks_per_wave, int blk, float* __restrict__ red) {
   constexpr int N1 = T1 * 32, N2 = T2 * 32;
-  constexpr int PS = N1 * N2 + N1;
-  __shared__ float red[2 * PS];                    // two waves' partials at a time (<= 50 KB)
+  constexpr int PS = N1 * N2 + N1;                 // red: 2 * PS floats (two waves' partials at a time, <= 50 KB)
   const int lane = lane_id(), wave = wave_id_uniform();
   const int r = lane & 31, hf = lane >> 5;
-  const int64_t wid = static_cast<int64_t>(blockIdx.x) * kWaves + wave;
+  const int64_t wid = static_cast<int64_t>(blk) * kWaves + wave;
   const int64_t nchunks = (M + 31) / 32;
   f32x16 acc[T1][T2];
   float colsum[T1];
@@ -231,8 +230,31 @@ __global__ __launch_bounds__(kWaves * 64, 2) void gemm_wgrad_kernel(
   __syncthreads();
   if (wave == 0) {
     add(red);
-    put(partial + static_cast<int64_t>(blockIdx.x) * PS);
+    put(partial + static_cast<int64_t>(blk) * PS);
   }
+}
+
+template <int T1, int T2>
+__global__ __launch_bounds__(kWaves * 64, 2) void gemm_wgrad_kernel(
+    const float* __restrict__ G, int64_t ldg, const float* __restrict__ X, int64_t ldx, int64_t M,
+    float* __restrict__ partial, int chunks_per_wave) {
+  __shared__ float red[2 * (T1 * 32 * T2 * 32 + T1 * 32)];
+  gemm_wgrad_body<T1, T2>(G, ldg, X, ldx, M, partial, chunks_per_wave, blockIdx.x, red);
+}
+
+// Two weight gradients over the same rows in ONE launch (an attention block's dW_qkv and dW_out): workgroups
+// [0, blocks) run the first, [blocks, 2 blocks) the second — one ramp and one tail instead of two.
+template <int T1A, int T2A, int T1B, int T2B>
+__global__ __launch_bounds__(kWaves * 64, 2) void gemm_wgrad_pair_kernel(
+    const float* __restrict__ GA, int64_t ldgA, const float* __restrict__ XA, int64_t ldxA, float* __restrict__ partialA,
+    const float* __restrict__ GB, int64_t ldgB, const float* __restrict__ XB, int64_t ldxB, float* __restrict__ partialB,
+    int64_t M, int chunks_per_wave, int blocks) {
+  constexpr int PSA = T1A * 32 * T2A * 32 + T1A * 32, PSB = T1B * 32 * T2B * 32 + T1B * 32;
+  __shared__ float red[2 * (PSA > PSB ? PSA : PSB)];
+  if (static_cast<int>(blockIdx.x) < blocks)
+    gemm_wgrad_body<T1A, T2A>(GA, ldgA, XA, ldxA, M, partialA, chunks_per_wave, blockIdx.x, red);
+  else
+    gemm_wgrad_body<T1B, T2B>(GB, ldgB, XB, ldxB, M, partialB, chunks_per_wave, blockIdx.x - blocks, red);
 }
 
 // out[e] (+)= sum_blocks partial[block][e]  (fixed order); the last N1 entries go to db (partial_reduce.h).
@@ -343,6 +365,18 @@ bool gemm_wgrad_try(const float* G, int64_t ldg, const float* X, int64_t ldx, in
                      N2, dW, ldw, db, accumulate);
   return true;
 }
+// the (6, 1) + (1, 2) pair (attention_dim 64, embed_dim 32: dW_qkv and dW_out of configuration 4) in one launch
+bool gemm_wgrad_pair_try(const float* GA, int64_t ldgA, const float* XA, int64_t ldxA, int n1A, int n2A, void* wsA,
+                         const float* GB, int64_t ldgB, const float* XB, int64_t ldxB, int n1B, int n2B, void* wsB,
+                         int64_t M, hipStream_t st) {
+  if (!wsA || !wsB || !gemm_wgrad_supported(M, n1A, n2A) || !gemm_wgrad_supported(M, n1B, n2B)) return false;
+  if (!(n1A == 192 && n2A == 32 && n1B == 32 && n2B == 64)) return false;
+  int cpw;
+  const int blocks = wgrad_blocks(M, &cpw);
+  hipLaunchKernelGGL((gemm_wgrad_pair_kernel<6, 1, 1, 2>), dim3(2 * blocks), dim3(kWaves * 64), 0, st, GA, ldgA, XA, ldxA,
+                     static_cast<float*>(wsA), GB, ldgB, XB, ldxB, static_cast<float*>(wsB), M, cpw, blocks);
+  return true;
+}
 int gemm_wgrad_partial_blocks(int64_t M) {
   int cpw;
   return wgrad_blocks(M, &cpw);
@@ -397,6 +431,22 @@ extern "C" int dfm_partials_finish(const dfm_partial_job* jobs, int count, dfm_s
   pj.first_block[count] = blocks;
   pj.count = count;
   hipLaunchKernelGGL(partials_finish_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, as_stream(stream), pj);
+  DFM_LAUNCH_CHECK();
+  return DFM_OK;
+}
+
+// Two dfm_weight_grad_partials_f32 passes over the same rows in one launch; DFM_ERR_UNSUPPORTED for a pair of shapes
+// without a joint kernel (the caller then makes the two calls).
+extern "C" int dfm_weight_grad_partials_pair_f32(const float* d_g_a, int64_t ldg_a, const float* d_x_a, int64_t ldx_a,
+                                                 int n1_a, int n2_a, void* d_workspace_a, const float* d_g_b,
+                                                 int64_t ldg_b, const float* d_x_b, int64_t ldx_b, int n1_b, int n2_b,
+                                                 void* d_workspace_b, int64_t rows, dfm_stream_t stream) {
+  DFM_REQUIRE(d_g_a && d_x_a && d_workspace_a && d_g_b && d_x_b && d_workspace_b, "null argument");
+  DFM_REQUIRE(rows > 0, "bad shape");
+  if (!dfm::gemm_wgrad_pair_try(d_g_a, ldg_a, d_x_a, ldx_a, n1_a, n2_a, d_workspace_a, d_g_b, ldg_b, d_x_b, ldx_b, n1_b,
+                                n2_b, d_workspace_b, rows, as_stream(stream)))
+    return fail(DFM_ERR_UNSUPPORTED, "dfm_weight_grad_partials_pair_f32: no joint kernel for (%d, %d) + (%d, %d)", n1_a,
+                n2_a, n1_b, n2_b);
   DFM_LAUNCH_CHECK();
   return DFM_OK;
 }

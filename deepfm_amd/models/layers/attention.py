@@ -129,6 +129,28 @@ def _weight_grad(g: torch.Tensor, x: torch.Tensor, rows: int, n1: int, n2: int, 
     return True
 
 
+def _weight_grad_pair(ga, xa, n1a, n2a, dwa, dba, gb, xb, n1b, n2b, dwb, dbb, rows: int, finish: list) -> bool:
+    """Two ``_weight_grad`` streamed passes over the same ``rows`` as one launch; False when the library has no joint
+    kernel for the two shapes (nothing was enqueued)."""
+    lib = _lib.load()
+    wa, wb = lib.dfm_weight_grad_workspace_bytes(rows, n1a, n2a), lib.dfm_weight_grad_workspace_bytes(rows, n1b, n2b)
+    if not wa or not wb:
+        return False
+    ws_a = torch.empty(wa // 4, dtype=torch.float32, device=ga.device)
+    ws_b = torch.empty(wb // 4, dtype=torch.float32, device=ga.device)
+    rc = lib.dfm_weight_grad_partials_pair_f32(ga.data_ptr(), n1a, xa.data_ptr(), n2a, n1a, n2a, ws_a.data_ptr(),
+                                               gb.data_ptr(), n1b, xb.data_ptr(), n2b, n1b, n2b, ws_b.data_ptr(), rows,
+                                               _lib.stream_handle())
+    if rc == _lib.ERR_UNSUPPORTED:
+        return False
+    _lib.check(rc)
+    blocks = lib.dfm_weight_grad_partial_blocks(rows)
+    for n1, n2, ws, dw, db in ((n1a, n2a, ws_a, dwa, dba), (n1b, n2b, ws_b, dwb, dbb)):
+        finish.append(dict(kind=0, blocks=blocks, n1=n1, n2=n2, accumulate=0, partial=ws, out_w=dw.data_ptr(),
+                           out_b=db.data_ptr(), ldw=n2))
+    return True
+
+
 def _finish_partials(jobs: list) -> None:
     """The deferred reductions of a backward pass (weight-gradient partials, LayerNorm partials) in ONE launch."""
     if not jobs:
@@ -259,9 +281,6 @@ class _AttnGemmFn(torch.autograd.Function):
             g_y = g
         d_wo = block.W_out.weight.grad if direct else torch.empty(D, A, dtype=torch.float32, device=dev)
         d_bo = block.W_out.bias.grad.view(D, 1) if direct else torch.empty(D, 1, dtype=torch.float32, device=dev)
-        if not _weight_grad(g_y, o, M, D, A, d_wo, d_bo, finish):
-            _gemm(g_y, D, False, o, A, False, d_wo, D, A, M)                     # dWo = g_y^T O
-            _gemm(g_y, D, False, ones_column(M, dev), 1, False, d_bo, D, 1, M)
         d_qkv = torch.empty(M, 3 * A, dtype=torch.float32, device=dev)
         d_wqkv = gq if direct else torch.empty(3 * A, D, dtype=torch.float32, device=dev)
         d_bqkv = gb.view(3 * A, 1) if direct else torch.empty(3 * A, 1, dtype=torch.float32, device=dev)
@@ -288,9 +307,15 @@ class _AttnGemmFn(torch.autograd.Function):
             else:
                 _lib.check(lib.dfm_attention_core_backward(qkv.data_ptr(), d_o.data_ptr(), B, F, A, H,
                                                            d_qkv.data_ptr(), _lib.stream_handle()))
-        if not _weight_grad(d_qkv, X, M, 3 * A, D, d_wqkv, d_bqkv, finish):
-            _gemm(d_qkv, 3 * A, False, X, D, False, d_wqkv, 3 * A, D, M)         # dWqkv = dQKV^T X
-            _gemm(d_qkv, 3 * A, False, ones_column(M, dev), 1, False, d_bqkv, 3 * A, 1, M)
+        # dWqkv = dQKV^T X and dWo = g_y^T O (+ their bias gradients): both streamed passes in one launch when the pair
+        # of shapes has a joint kernel, their reductions and the LayerNorm's in the block's one finish launch
+        if not _weight_grad_pair(d_qkv, X, 3 * A, D, d_wqkv, d_bqkv, g_y, o, D, A, d_wo, d_bo, M, finish):
+            if not _weight_grad(g_y, o, M, D, A, d_wo, d_bo, finish):
+                _gemm(g_y, D, False, o, A, False, d_wo, D, A, M)
+                _gemm(g_y, D, False, ones_column(M, dev), 1, False, d_bo, D, 1, M)
+            if not _weight_grad(d_qkv, X, M, 3 * A, D, d_wqkv, d_bqkv, finish):
+                _gemm(d_qkv, 3 * A, False, X, D, False, d_wqkv, 3 * A, D, M)
+                _gemm(d_qkv, 3 * A, False, ones_column(M, dev), 1, False, d_bqkv, 3 * A, 1, M)
         _finish_partials(finish)
         if whole:
             pass

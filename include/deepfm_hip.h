@@ -722,6 +722,12 @@ int dfm_weight_grad_f32(const float* d_g, int64_t ldg, const float* d_x, int64_t
 int dfm_weight_grad_partial_blocks(int64_t rows);
 int dfm_weight_grad_partials_f32(const float* d_g, int64_t ldg, const float* d_x, int64_t ldx, int64_t rows, int n1,
                                  int n2, void* d_workspace, dfm_stream_t stream);
+/* Two such passes over the same rows in one launch (an attention block's dW_qkv and dW_out); DFM_ERR_UNSUPPORTED when
+ * the pair of shapes has no joint kernel ((192, 32) + (32, 64) has one) — make the two calls then. */
+int dfm_weight_grad_partials_pair_f32(const float* d_g_a, int64_t ldg_a, const float* d_x_a, int64_t ldx_a, int n1_a,
+                                      int n2_a, void* d_workspace_a, const float* d_g_b, int64_t ldg_b,
+                                      const float* d_x_b, int64_t ldx_b, int n1_b, int n2_b, void* d_workspace_b,
+                                      int64_t rows, dfm_stream_t stream);
 int dfm_layernorm_partial_blocks(int64_t rows);
 typedef struct {
   int32_t kind;            /* 0: weight gradient partials -> out_w = dW (row stride ldw), out_b = db or NULL;
