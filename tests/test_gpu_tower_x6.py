@@ -242,3 +242,53 @@ def test_unsupported_shapes_are_refused():
     assert lib.dfm_tower_x6_supported(4000, 400, 624) == 0      # batch % 64
     assert lib.dfm_tower_x6_supported(4096, 396, 624) == 0      # features % 8
     assert lib.dfm_tower_x6_supported(4096, 400, 429) == 0
+
+
+def test_fused_step_on_planes_vs_oracle_and_graph():
+    """dfm_tower_set_mode(2) end to end, in the default test run: the fused DeepFM step takes the planes path
+    (weight split launch, *_x6 GEMMs, apply kernels that write planes only), three steps against the numpy oracle at the
+    bar of tests/test_gpu_fused_tower.py::test_fused_deepfm_steps_vs_oracle, and its graph replay is bit-identical to
+    its eager run.  (The whole suite under this mode: DFM_TEST_TOWER_MODE=2, tests/conftest.py.)"""
+    from oracle import ctr_oracle as O
+    from tests.test_gpu_fused_tower import _fused_pair, _oracle_state, _pool
+    _l, lib = _lib()
+    old = lib.dfm_tower_get_mode()
+    B = 512
+    try:
+        _l.check(lib.dfm_tower_set_mode(2))
+        fields, cfg, model, hp, opt, Step = _fused_pair(B)
+        params, state = _oracle_state(model)
+        step = Step(model, opt, B, use_graph=False)
+        assert step.x6, "batch 512, hidden units multiples of 8: the planes path must be taken"
+        rng = np.random.default_rng(3)
+        ids, dense, labels = _pool(fields, 3, B, rng)
+        ocfg = dict(fm_dim=16, hidden_units=cfg.dnn.hidden_units)
+        for i in range(3):
+            step.load_batch(torch.from_numpy(ids[i]).cuda(), torch.from_numpy(dense[i]).cuda(), torch.from_numpy(labels[i]).cuda())
+            step.run()
+            batch = {f["name"]: ids[i, j] for j, f in enumerate(fields[:26])}
+            batch.update({f["name"]: dense[i, j] for j, f in enumerate(fields[26:])})
+            oloss = O.deepfm_train_step_rowsparse(fields, params, state, batch, labels[i], ocfg, hp, i + 1, exact_order=True)
+            assert abs(float(step.loss) - float(oloss)) < 2e-5 + 1e-4 * abs(float(oloss)), (i, float(step.loss), float(oloss))
+        got = {k: npy(v) for k, v in model.state_dict().items()}
+        for k, want in params.items():
+            if "running_" in k:
+                continue
+            if k.startswith("dnn.mlp.") and k.endswith(".bias") and int(k.split(".")[2]) % 4 == 0:
+                continue        # zero-gradient parameter (Linear bias in front of BatchNorm)
+            assert_close(got[k], want, rtol=1e-4, atol_scale=0.0, floor=1e-4, what=k)
+        # graph replay == eager, bit for bit
+        results = []
+        for use_graph in (False, True):
+            _, _, model, hp, opt, Step = _fused_pair(B, seed=4)
+            step = Step(model, opt, B, use_graph=use_graph)
+            recs = step.pack_batches(torch.from_numpy(ids).cuda(), torch.from_numpy(dense).cuda(), torch.from_numpy(labels).cuda())
+            step.capture()
+            for i in range(3):
+                step.run_from(recs[i])
+            torch.cuda.synchronize()
+            results.append({k: npy(v).copy() for k, v in model.state_dict().items()})
+        for k in results[0]:
+            assert np.array_equal(results[0][k], results[1][k]), f"planes path: graph != eager: {k}"
+    finally:
+        _l.check(lib.dfm_tower_set_mode(old))
