@@ -32,7 +32,7 @@ def pytest_collection_modifyitems(config, items):
 def _tower_mode_from_env():
     """DFM_TEST_TOWER_MODE=1 / 2: run the whole GPU suite with the tower in that arithmetic mode (dfm_tower_set_mode:
     1 bf16 x 3 backward, 2 bf16 x 6 forward and backward) — the acceptance test of a mode is that every parity test
-    passes with no tolerance edited (DESIGN.md section 7r3 records the outcome: 237 / 253 and 275 / 276)."""
+    passes with no tolerance edited (DESIGN.md section 7r3 records the outcome: 263 / 277 and 276 / 277)."""
     mode = os.environ.get("DFM_TEST_TOWER_MODE")
     if mode is not None:
         import torch
