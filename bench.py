@@ -82,6 +82,8 @@ def parse():
                     help="arithmetic of the DNN tower's GEMMs (dfm_tower_set_mode): 0 exact fp32 matrix pipe, 1 fp32 forward + "
                          "bf16 x 3 backward, 2 bf16 x 6 (fp32-faithful) forward and backward; -1 = the package default "
                          "(training/step.py::TOWER_MODE_DEFAULT)")
+    ap.add_argument("--region-order", choices=("groups-first", "singles-first"), default="groups-first",
+                    help="A/B: where the event-timed single steps sit in the timed region")
     ap.add_argument("--gather-samples", type=int, default=32,
                     help="timed gather dispatches wanted for the roofline: those of the timed region plus single steps "
                          "run after it (outside `value`) until this many are collected")
@@ -460,10 +462,14 @@ def main():
         # happens BEFORE the synchronisation, RowSparseTrainStep.prepare_group: as in a training loop, where launch
         # k + 1 is prepared while launch k runs.)
         out, i = [], lo
+        if args.region_order == "singles-first":
+            for _ in range(n_timed):
+                out.append(("timed", i)); i += 1
         for _ in range(groups):
             out.append(("group", i)); i += G
-        for _ in range(n_timed):
-            out.append(("timed", i)); i += 1
+        if args.region_order != "singles-first":
+            for _ in range(n_timed):
+                out.append(("timed", i)); i += 1
         while i < hi:
             out.append(("single", i)); i += 1
         return out
@@ -474,13 +480,13 @@ def main():
         # the launch's last optimizer kernel also sorts the NEXT launch's first batch (training/step.py)
         return [rec(i + k) for k in range(G)], (records[nxt] if (nxt is not None and feed is None) else None)
 
-    def execute(p, after=None, first_prepared=False):
+    def execute(p, after=None, prepared_at=-1):
         """``after``: record index the launch that follows this plan starts with (None: unknown).
-        ``first_prepared``: the plan's first launch is a group whose host half ran already (prepare_first)."""
+        ``prepared_at``: index of the plan's group whose host half ran already (prepare_first)."""
         for j, (kind, i) in enumerate(p):
             if kind == "group":
                 if G > 1:
-                    if j == 0 and first_prepared:
+                    if j == prepared_at:
                         step.launch_prepared()
                     else:
                         recs, nxt = group_args(p, j, after)
@@ -491,12 +497,15 @@ def main():
                 step.run_from(rec(i), eager_gather=not args.no_graph)
 
     def prepare_first(p, after=None):
-        """Host half of the plan's first launch, if that is a multi-step graph launch on resident records."""
-        if p and p[0][0] == "group" and G > 1 and feed is None and getattr(step, "slots", None):
-            recs, nxt = group_args(p, 0, after)
-            step.prepare_group(recs, next_record=nxt)
-            return True
-        return False
+        """Host half of the plan's first GROUP launch (multi-step graph on resident records); returns its index in the
+        plan or -1."""
+        if G > 1 and feed is None and getattr(step, "slots", None):
+            for j, (kind, _) in enumerate(p):
+                if kind == "group":
+                    recs, nxt = group_args(p, j, after)
+                    step.prepare_group(recs, next_record=nxt)
+                    return j
+        return -1
 
     if G > 1 and args.warmup < 2 * G and feed is None:
         # both instantiated copies of the step graph get one untimed launch (their first launch uploads the exec): W can
@@ -516,13 +525,14 @@ def main():
     n_timed = sum(1 for kind, _ in timed_plan if kind == "timed")
     if n_timed:
         _lib.check(lib.dfm_gather_timing_begin(n_timed))
-    prepared = prepare_first(timed_plan)        # node updates of the first launch: host work, nothing enqueued
+    prepared_at = prepare_first(timed_plan)     # node updates of the first group launch: host work, nothing enqueued
+    prepared = prepared_at >= 0
     if prepared:
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
     t0 = time.perf_counter()
-    execute(timed_plan, first_prepared=prepared)
+    execute(timed_plan, prepared_at=prepared_at)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -1,5 +1,5 @@
 #!/bin/bash
-# the driver's form (--steps 20 --warmup 5) against variants: where do the ~12 us per step over the long run go?
+# the driver's form (--steps 20 --warmup 5) against variants: where do the us per step over the long run go?
 mkdir -p gpurun_out
 run() {
   timeout -k 10 200 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra-configs --no-gather-sweep "$@" > gpurun_out/w_bench.json 2> gpurun_out/w_bench.err || { tail -5 gpurun_out/w_bench.err; exit 1; }
@@ -11,7 +11,6 @@ PY
 }
 for i in 1 2 3; do
 run
+run --region-order singles-first
 run --no-gather-timing --steps-per-graph 5
-run --no-gather-timing --steps-per-graph 4
-run --steps-per-graph 6 --gather-samples 2
 done
