@@ -507,12 +507,14 @@ def main():
                     return j
         return -1
 
+    execute(plan(0, args.warmup, 0), after=args.warmup if args.warmup < total else None)
     if G > 1 and args.warmup < 2 * G and feed is None:
         # both instantiated copies of the step graph get one untimed launch (their first launch uploads the exec): W can
-        # be smaller than two graphs (the driver's --warmup 5); these steps come on top of the W warm-up steps
-        for _ in range(2):
-            step.run_group([records[k % total] for k in range(G)])
-    execute(plan(0, args.warmup, 0), after=args.warmup if args.warmup < total else None)
+        # be smaller than two graphs (the driver's --warmup 5); these steps come on top of the W warm-up steps.  The
+        # second one announces the timed region's first record, as every launch announces its successor's.
+        first_timed = records[args.warmup] if args.warmup < total else None
+        for j in range(2):
+            step.run_group([records[k % total] for k in range(G)], next_record=first_timed if j == 1 else None)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()

@@ -6,11 +6,11 @@ run() {
   python - "$*" <<'PY'
 import json,sys
 d=json.loads(open("gpurun_out/w_bench.json").read().strip().splitlines()[-1])
-print(f"{sys.argv[1]:50s} ms {d['ms_per_step']:.4f}")
+print(f"{sys.argv[1]:50s} ms {d['ms_per_step']:.4f} loss {d['config']['final_loss']:.6f}")
 PY
 }
-for i in 1 2 3; do
+for i in 1 2 3 4; do
 run
+done
 run --region-order singles-first
 run --no-gather-timing --steps-per-graph 5
-done
