@@ -265,7 +265,7 @@ def extra_config(name, args, dev, lib, ids_dist="uniform"):
     cin_sizes = [128, 128, 128] if name == "xdeepfm" else None
     model, opt, step, fields, cfg, hp, fused = build_step(name, V, D, B, dev, args, cin_sizes)
     n_sparse, n_dense = 26, 13
-    G = 1 if (args.no_graph or (opt.split and not step.exchange_in_body)) else (args.steps_per_graph or 4)
+    G = 1 if (args.no_graph or (opt.split and not step.exchange_in_body)) else (args.steps_per_graph or 6)
     warm, steps = -(-10 // G) * G, max(args.extra_steps // G, 1) * G                   # whole graph launches
     ids, dense, labels = make_pool(warm + steps, n_sparse, n_dense, B, V, 101, dev, ids_dist)     # every batch used once
     records = step.pack_batches(ids, dense, labels)
