@@ -92,6 +92,22 @@ def test_same_seed_same_initial_weights_and_padding_row_zero():
         assert float(a.second_order_embeddings[name].weight[0].abs().sum()) == 0.0     # embedding.py:66-74
 
 
+def test_rowsparse_mode_refuses_non_uniform_schemas():
+    """The row-sparse gradient path (packed records, row plans, fused steps) is for uniform SPARSE / DENSE schemas; a
+    schema with a SEQUENCE field, a projection or mixed embedding widths trains in dense mode."""
+    from deepfm_amd.models.layers.embedding import FeatureEmbedding
+    g = load("emb_layers_test_schema")                      # SPARSE + SEQUENCE + projections
+    emb = FeatureEmbedding(schema_from_fields(fields_of(g)), 16)
+    with pytest.raises(NotImplementedError):
+        emb.set_grad_mode("rowsparse")
+    with pytest.raises(ValueError):
+        emb.set_grad_mode("sparse")
+    assert emb.set_grad_mode("dense") is emb
+    uniform = [dict(name=f"C{i}", type="sparse", vocab=50, dim=8, max_len=1, combiner="mean") for i in range(3)] + \
+              [dict(name="I0", type="dense", vocab=0, dim=8, max_len=1, combiner="mean")]
+    assert FeatureEmbedding(schema_from_fields(uniform), 8).set_grad_mode("rowsparse").grad_mode == "rowsparse"
+
+
 def test_cpu_tensors_fail_loudly_no_fallback():
     from deepfm_amd.models.layers.attention import MultiHeadSelfAttention
     from deepfm_amd.models.layers.cin import CIN
